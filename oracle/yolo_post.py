@@ -1,0 +1,121 @@
+"""ORACLE (test infrastructure): YOLOv8 decode + NMS restatements.
+
+* ``decode_c`` / ``batch_nms_c``  — ctypes wrappers over oracle/csrc/yolo_post_ref.c (sequential C,
+  follows yolov8/plugin/yololayer.cu:178-220,282-316 and yolov8/src/postprocess.cpp:71-129).
+* ``decode_np``  — an independent vectorised NumPy restatement of the same decode
+  (used to cross-check the C restatement).
+* ``nms_py``     — an independent pure-Python restatement of nms() for small cases.
+
+Parity status: parity unpinned (no reference goldens exist for this path).
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import lib
+
+DET_FLOATS = 90  # yolov8/include/types.h:4-12 (4 + 1 + 1 + 32 + 17*3 + 1)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def decode_c(inputs, classes, net_h, net_w, strides, max_out=1000):
+    """inputs: list of [B, 4+classes, gh*gw] float32 arrays (one per stride level)."""
+    ins = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+    batch = ins[0].shape[0]
+    out = np.zeros((batch, 1 + max_out * DET_FLOATS), dtype=np.float32)
+    ptrs = (ctypes.POINTER(ctypes.c_float) * len(ins))(*[_fp(x) for x in ins])
+    st = (ctypes.c_int * len(strides))(*strides)
+    lib().yolo_decode_ref(ptrs, batch, classes, net_h, net_w, st, len(strides), max_out, _fp(out))
+    return out
+
+
+def batch_nms_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    output = np.ascontiguousarray(output, dtype=np.float32)
+    batch = output.shape[0]
+    keep_idx = np.full((batch, max_out), -1, dtype=np.int32)
+    keep_cnt = np.zeros((batch,), dtype=np.int32)
+    keep_det = np.zeros((batch, max_out, 6), dtype=np.float32)
+    lib().yolo_batch_nms_ref(
+        _fp(output), batch, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+        keep_idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+        keep_cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(keep_det))
+    return keep_idx, keep_cnt, keep_det
+
+
+def decode_np(inputs, classes, net_h, net_w, strides, max_out=1000):
+    """Vectorised restatement of CalDetection (yololayer.cu:178-220), canonical (level, cell) order."""
+    batch = inputs[0].shape[0]
+    out = np.zeros((batch, 1 + max_out * DET_FLOATS), dtype=np.float32)
+    one = np.float32(1.0)
+    for b in range(batch):
+        recs = []
+        for x, s in zip(inputs, strides):
+            gh, gw = net_h // s, net_w // s
+            cur = np.asarray(x[b], dtype=np.float32)  # [4+classes, total]
+            with np.errstate(over="ignore"):
+                p = one / (one + np.exp(-cur[4:4 + classes], dtype=np.float32))
+            # strict '>' scan starting from (0.0, class 0)  == first index attaining the maximum
+            cls = np.argmax(p, axis=0)
+            mx = p[cls, np.arange(p.shape[1])]
+            cls = np.where(mx > 0, cls, 0)
+            sel = np.nonzero(~(mx.astype(np.float64) < 0.1))[0]
+            e = sel.astype(np.int64)
+            row = (e // gw).astype(np.float32)
+            col = (e % gw).astype(np.float32)
+            half = np.float32(0.5)
+            sf = np.float32(s)
+            rec = np.zeros((len(e), DET_FLOATS), dtype=np.float32)
+            rec[:, 0] = (col + half - cur[0, e]) * sf
+            rec[:, 1] = (row + half - cur[1, e]) * sf
+            rec[:, 2] = (col + half + cur[2, e]) * sf
+            rec[:, 3] = (row + half + cur[3, e]) * sf
+            rec[:, 4] = mx[e]
+            rec[:, 5] = cls[e].astype(np.float32)
+            recs.append(rec)
+        rec = np.concatenate(recs, axis=0)[:max_out]
+        out[b, 0] = len(rec)
+        out[b, 1:1 + rec.size] = rec.reshape(-1)
+    return out
+
+
+def _iou(l, r):
+    f = np.float32
+    ib0, ib1 = max(l[0], r[0]), min(l[2], r[2])
+    ib2, ib3 = max(l[1], r[1]), min(l[3], r[3])
+    if ib2 > ib3 or ib0 > ib1:
+        return f(0.0)
+    inter = f(f(ib1 - ib0) * f(ib3 - ib2))
+    uni = f(f(f(f(l[2] - l[0]) * f(l[3] - l[1])) + f(f(r[2] - r[0]) * f(r[3] - r[1]))) - inter)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return f(inter / uni)
+
+
+def nms_py(output_row, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """Pure-Python restatement of nms() (postprocess.cpp:94-121) for one image; returns kept slot indices."""
+    count = min(int(output_row[0]), max_out)
+    buckets = {}
+    for i in range(count):
+        det = output_row[1 + DET_FLOATS * i: 1 + DET_FLOATS * (i + 1)]
+        conf = det[4]
+        if conf <= np.float32(conf_thresh) or math.isnan(conf):
+            continue
+        buckets.setdefault(float(det[5]), []).append((i, det))
+    keep = []
+    for cls in sorted(buckets):
+        dets = sorted(buckets[cls], key=lambda t: (-float(t[1][4]), float(t[1][0]), t[0]))
+        m = 0
+        while m < len(dets):
+            item = dets[m]
+            keep.append(item[0])
+            n = m + 1
+            while n < len(dets):
+                if _iou(item[1], dets[n][1]) > np.float32(nms_thresh):
+                    del dets[n]
+                else:
+                    n += 1
+            m += 1
+    return keep

@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI in include/trtx_hip.h (section 1: plugin operators + single kernels)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class TrtxError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        msg = lib().trtx_status_string(status).decode() if _LIB is not None else "?"
+        super().__init__(f"{what}: status {status} ({msg})")
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libtrtx_hip.so")
+
+
+def lib() -> ctypes.CDLL:
+    """Load libtrtx_hip.so.  Fails loudly when the extension has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = ctypes.CDLL(p)
+        L.trtx_status_string.restype = ctypes.c_char_p
+        L.trtx_status_string.argtypes = [ctypes.c_int32]
+        L.trtx_yolo_decode_workspace.restype = ctypes.c_size_t
+        _LIB = L
+    return _LIB
+
+
+def check(status, what):
+    if status != 0:
+        raise TrtxError(status, what)
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+DET_FLOATS = 90  # yolov8/include/types.h:4-12
+
+
+def yolo_decode(inputs, classes, net_h, net_w, strides, max_out=1000, out=None):
+    """YoloLayerPlugin::enqueue replacement (yolov8/plugin/yololayer.cu:167-316).
+    inputs: list of CUDA fp32 tensors [B, 4+classes, gh*gw]. Returns [B, 1+max_out*90] fp32."""
+    import torch
+    L = lib()
+    B = inputs[0].shape[0]
+    n = len(inputs)
+    ins = [x.contiguous() for x in inputs]
+    for x in ins:
+        assert x.is_cuda and x.dtype == torch.float32
+    arr = (ctypes.c_void_p * n)(*[x.data_ptr() for x in ins])
+    st = (ctypes.c_int * n)(*strides)
+    ws_bytes = L.trtx_yolo_decode_workspace(B, net_h, net_w, st, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=ins[0].device)
+    if out is None:
+        out = torch.empty((B, 1 + max_out * DET_FLOATS), dtype=torch.float32, device=ins[0].device)
+    check(L.trtx_yolo_decode(arr, n, B, classes, net_h, net_w, st, max_out, _p(out), _p(ws),
+                             ctypes.c_size_t(ws_bytes), _stream()), "trtx_yolo_decode")
+    return out
+
+
+def yolo_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45, with_dets=True):
+    """batch_nms replacement (yolov8/src/postprocess.cpp:71-129). Returns keep_idx, keep_cnt, keep_det."""
+    import torch
+    L = lib()
+    B = decode_out.shape[0]
+    dev = decode_out.device
+    keep_idx = torch.full((B, max_out), -1, dtype=torch.int32, device=dev)
+    keep_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    keep_det = torch.zeros((B, max_out, 6), dtype=torch.float32, device=dev) if with_dets else None
+    check(L.trtx_yolo_nms(_p(decode_out), B, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+                          _p(keep_idx), _p(keep_cnt), _p(keep_det), _stream()), "trtx_yolo_nms")
+    return keep_idx, keep_cnt, keep_det
+
+
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "silu": 3, "leaky": 4, "tanh": 5}
+
+
+def pack_conv_weights_f16(w_kcrs, cin_pad=None, ch_scale=None):
+    """Host: KCRS fp32 numpy -> (packed uint16 [Cout_pad, Kpad], cout_pad, kpad, bn)."""
+    import numpy as np
+    L = lib()
+    w = np.ascontiguousarray(w_kcrs, dtype=np.float32)
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin_pad or (cin + 7) // 8 * 8
+    cp, kp, bn = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(L.trtx_conv_packed_dims(cout, cin_pad, kh, kw, ctypes.byref(cp), ctypes.byref(kp), ctypes.byref(bn)),
+          "trtx_conv_packed_dims")
+    packed = np.zeros((cp.value, kp.value), dtype=np.uint16)
+    sc = None
+    if ch_scale is not None:
+        sc = np.ascontiguousarray(ch_scale, dtype=np.float32)
+    check(L.trtx_conv_pack_weights_f16(w.ctypes.data_as(ctypes.c_void_p), cout, cin, kh, kw, cin_pad,
+                                       sc.ctypes.data_as(ctypes.c_void_p) if sc is not None else None,
+                                       packed.ctypes.data_as(ctypes.c_void_p)), "trtx_conv_pack_weights_f16")
+    return packed, cp.value, kp.value, bn.value
+
+
+def conv2d_nhwc_f16(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", residual=None, act2="none",
+                    out=None, out_ld=None):
+    """Single fused conv launch on NHWC fp16 tensors (x: [N,H,W,Cin] CUDA half)."""
+    import torch
+    L = lib()
+    N, H, W, Cin = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, cout), dtype=torch.float16, device=x.device)
+    ld_out = out_ld or out.shape[-1]
+    check(L.trtx_op_conv2d_nhwc_f16(_p(x), N, H, W, Cin, x.stride(2), _p(wpacked), _p(bias), _p(out), cout, ld_out,
+                                    kh, kw, stride, stride, pad, pad, ACT[act1], _p(residual),
+                                    residual.stride(2) if residual is not None else 0, ACT[act2], _stream()),
+          "trtx_op_conv2d_nhwc_f16")
+    return out

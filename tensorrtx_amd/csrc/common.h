@@ -1,0 +1,50 @@
+// Internal helpers shared by the HIP kernels and the runtime (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "trtx_hip.h"
+
+namespace trtx {
+
+constexpr int kYoloDetFloats = 90;  // sizeof(Detection)/4, yolov8/include/types.h:4-12
+
+inline size_t align_up(size_t v, size_t a) {
+    return (v + a - 1) / a * a;
+}
+
+// Launch errors are reported, never swallowed: the product path must fail loudly.
+inline int32_t check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "[trtx_hip] %s: %s\n", what, hipGetErrorString(e));
+        return TRTX_ERR_HIP;
+    }
+    return TRTX_OK;
+}
+
+#define TRTX_HIP_TRY(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            fprintf(stderr, "[trtx_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr,            \
+                    hipGetErrorString(e__));                                                     \
+            return TRTX_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+// Monotone map float -> uint32 (ascending).  -0.0f is folded onto +0.0f so that keys compare the
+// way IEEE '<' / '==' do.
+__host__ __device__ inline uint32_t ord_f32(float f) {
+    f = f + 0.0f;
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.f = f;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+
+}  // namespace trtx

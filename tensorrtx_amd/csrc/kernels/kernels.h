@@ -1,0 +1,87 @@
+// Internal kernel-launcher interface (C++), used by the runtime executor and by the thin
+// extern "C" test/bench entry points in ops_capi.cpp.  Everything here runs on a HIP stream;
+// nothing falls back to the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace trtx {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SILU = 3, ACT_LEAKY = 4, ACT_TANH = 5 };
+enum DType : int { DT_F32 = 0, DT_F16 = 1 };
+enum EwOp : int { EW_SUM = 0, EW_PROD = 1, EW_MAX = 2, EW_MIN = 3, EW_SUB = 4, EW_DIV = 5, EW_POW = 6 };
+enum PoolOp : int { POOL_MAX = 0, POOL_AVG = 1 };
+
+// One fused convolution launch.  Activations are NHWC; `in`/`out`/`residual` already point at the
+// first channel of the slice they address and ld_* is the channel stride of the underlying buffer.
+struct ConvArgs {
+    const void* in;
+    const void* wgt;    // igemm: fp16 [Cout_pad][Kpad], k = (r*kw+q)*Cin + c.  direct: fp32 [Cout][kh*kw*Cin/groups]
+    const float* bias;  // [Cout_pad] (folded BN shift / conv bias) or nullptr
+    void* out;
+    const void* residual;  // same geometry as out, or nullptr
+    int N, H, W, Cin, ld_in;
+    int Ho, Wo, Cout, Cout_pad, ld_out, ld_res;
+    int kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+    int K, Kpad, M;
+    int act1, act2;
+    float alpha1, alpha2;
+    int bn;  // igemm column-tile width (16/32/64/80/128)
+};
+
+// --- conv -------------------------------------------------------------------------------------------
+int conv_igemm_pick_bn(int cout);
+bool conv_igemm_supported(const ConvArgs& a);
+int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// generic direct convolution (any groups / dilation / channel count), T = activation dtype, fp32 weights
+int32_t conv_direct(const ConvArgs& a, int dtype, hipStream_t s);
+// generic transposed convolution, fp32 weights laid out [Cin][kh][kw][Cout/groups]
+int32_t deconv_direct(const ConvArgs& a, int dtype, hipStream_t s);
+
+// --- layout / dtype conversion ----------------------------------------------------------------------
+// LINEAR fp32 [N][C][H][W] -> NHWC dtype, channels [C, Cpad) zero-filled
+int32_t nchw_f32_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad, int ld_out,
+                         hipStream_t s);
+// NHWC dtype -> LINEAR fp32 [N][C][H][W]
+int32_t nhwc_to_nchw_f32(const void* in, int dtype, float* out, int N, int C, int H, int W, int ld_in, hipStream_t s);
+
+// --- NHWC element ops (dtype = DT_F16 / DT_F32), strided channel slices ---------------------------------
+int32_t nhwc_pool(const void* in, void* out, int dtype, int op, int N, int H, int W, int C, int ld_in, int Ho, int Wo,
+                  int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int avg_exclusive, hipStream_t s);
+int32_t nhwc_resize_nearest(const void* in, void* out, int dtype, int N, int H, int W, int C, int ld_in, int Ho,
+                            int Wo, int ld_out, hipStream_t s);
+int32_t nhwc_elementwise(const void* a, const void* b, void* out, int dtype, int op, long pixels, int C, int ld_a,
+                         int ld_b, int ld_out, hipStream_t s);
+int32_t nhwc_activation(const void* in, void* out, int dtype, int act, float alpha, long pixels, int C, int ld_in,
+                        int ld_out, hipStream_t s);
+int32_t nhwc_scale(const void* in, void* out, int dtype, const float* scale, const float* shift, long pixels, int C,
+                   int ld_in, int ld_out, hipStream_t s);
+int32_t nhwc_copy(const void* in, void* out, int dtype, long pixels, int C, int ld_in, int ld_out, hipStream_t s);
+// mean over H*W: NHWC [N][H][W][C] -> NHWC [N][1][1][C]
+int32_t nhwc_reduce_hw_avg(const void* in, void* out, int dtype, int N, int HW, int C, int ld_in, int ld_out,
+                           hipStream_t s);
+
+// --- LINEAR fp32 ops (rank <= 6, row-major, batch outermost) -----------------------------------------------
+struct StridedView {
+    int rank;
+    long shape[6];
+    long stride_in[6];   // element strides into the source (0 = broadcast)
+    long stride_in2[6];  // second operand (elementwise only)
+};
+// out (dense row-major `shape`) = in[gather by stride_in]   (permute / slice / broadcast copy)
+int32_t lin_gather(const float* in, float* out, const StridedView& v, hipStream_t s);
+// dense source -> strided destination (concat placement): out[stride_in-indexed] = in
+int32_t lin_scatter(const float* in, float* out, const StridedView& v, hipStream_t s);
+int32_t lin_elementwise(const float* a, const float* b, float* out, int op, const StridedView& v, hipStream_t s);
+int32_t lin_activation(const float* in, float* out, int act, float alpha, long n, hipStream_t s);
+int32_t lin_softmax(const float* in, float* out, long outer, long axis, long inner, hipStream_t s);
+// C[b][m][n] = sum_k A(b,m,k) * B(b,k,n); ta/tb: operand stored transposed; batch stride 0 = broadcast
+int32_t lin_matmul(const float* A, const float* B, float* C, int batch, int M, int N, int K, int ta, int tb,
+                   long bsA, long bsB, hipStream_t s);
+int32_t lin_reduce(const float* in, float* out, int op /*0 sum,1 avg,2 max*/, long outer, long axis, long inner,
+                   hipStream_t s);
+int32_t lin_scale(const float* in, float* out, const float* scale, const float* shift, const float* power, int mode,
+                  long outer, long C, long inner, hipStream_t s);
+
+}  // namespace trtx

@@ -1,0 +1,481 @@
+// NHWC activation-tensor kernels for gfx950: layout/dtype conversion, pooling, nearest resize,
+// element-wise, activation, per-channel scale, channel-slice copy, spatial mean, and the generic
+// direct (de)convolution used for shapes the MFMA implicit-GEMM kernel does not cover.
+//
+// These are the engine-side implementations of the TensorRT layers the reference builders add
+// around the convolutions: addPoolingNd (yolov8/src/block.cpp:219-233 SPPF, resnet/resnet50.cpp:172),
+// addResize NEAREST (yolov8/src/model.cpp:145-158), addElementWise (block.cpp:106, resnet50.cpp:146),
+// addActivation, addScale, addConcatenation fall-backs, addReduce AVG (rcnn/rcnn.cpp:166).
+//
+// All are HBM-bound: one pass over the data, 16-byte accesses per lane whenever the channel count and
+// the channel stride allow it (VEC = 8 halfs / 4 floats), grid-stride loops capped at 256 CUs x 8 WGs.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../common.h"
+#include "kernels.h"
+
+namespace trtx {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+inline int grid_for(long work) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+    T v[V];
+};
+
+template <typename T>
+__device__ __forceinline__ float to_f(T x) {
+    return (float)x;
+}
+template <typename T>
+__device__ __forceinline__ T from_f(float x) {
+    return (T)x;
+}
+
+__device__ __forceinline__ float act_f(float v, int act, float alpha) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        case ACT_LEAKY: return v > 0.f ? v : v * alpha;
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float ew_f(float a, float b, int op) {
+    switch (op) {
+        case EW_SUM: return a + b;
+        case EW_PROD: return a * b;
+        case EW_MAX: return a > b ? a : b;
+        case EW_MIN: return a < b ? a : b;
+        case EW_SUB: return a - b;
+        case EW_DIV: return a / b;
+        case EW_POW: return powf(a, b);
+        default: return a;
+    }
+}
+
+// ---- layout conversion -------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int H, int W,
+                                    int Cpad, int ld) {
+    const long HW = (long)H * W;
+    const long total = (long)N * HW * Cpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long px = i / Cpad;  // n*HW + hw
+        const long n = px / HW;
+        const long hw = px - n * HW;
+        const float v = c < C ? in[(n * C + c) * HW + hw] : 0.f;
+        out[px * ld + c] = from_f<T>(v);
+    }
+}
+
+// tiled transpose through LDS: reads coalesced along C (NHWC), writes coalesced along HW (NCHW)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int C, long HW, int ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long hw0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long hw = hw0 + r;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (hw < HW && c < C) v = to_f(in[((long)n * HW + hw) * ld + c]);
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const long hw = hw0 + tx;
+        if (hw < HW && c < C) out[((long)n * C + c) * HW + hw] = tile[tx][r];
+    }
+}
+
+// ---- pooling --------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void pool_kernel(const T* __restrict__ in, T* __restrict__ out, int op, int N, int H, int W, int C,
+                            int ld_in, int Ho, int Wo, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                            int avg_excl) {
+    const int CV = C / V;
+    const long total = (long)N * Ho * Wo * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long px = i / CV;
+        const int wo = (int)(px % Wo);
+        px /= Wo;
+        const int ho = (int)(px % Ho);
+        const long n = px / Ho;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = op == POOL_MAX ? -INFINITY : 0.f;
+        int cnt = 0;
+        for (int r = 0; r < kh; ++r) {
+            const int hi = ho * sh - ph + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < kw; ++q) {
+                const int wi = wo * sw - pw + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const Pack<T, V> x = *reinterpret_cast<const Pack<T, V>*>(in + ((n * H + hi) * W + wi) * ld_in + cv * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float f = to_f(x.v[e]);
+                    acc[e] = op == POOL_MAX ? (f > acc[e] ? f : acc[e]) : acc[e] + f;
+                }
+                ++cnt;
+            }
+        }
+        Pack<T, V> o;
+        const float div = avg_excl ? (float)(cnt > 0 ? cnt : 1) : (float)(kh * kw);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] = from_f<T>(op == POOL_MAX ? acc[e] : acc[e] / div);
+        *reinterpret_cast<Pack<T, V>*>(out + ((n * Ho + ho) * Wo + wo) * ld_out + cv * V) = o;
+    }
+}
+
+template <typename T, int V>
+__global__ void resize_nearest_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C,
+                                      int ld_in, int Ho, int Wo, int ld_out) {
+    const int CV = C / V;
+    const long total = (long)N * Ho * Wo * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long px = i / CV;
+        const int wo = (int)(px % Wo);
+        px /= Wo;
+        const int ho = (int)(px % Ho);
+        const long n = px / Ho;
+        int hi = (int)(((long)ho * H) / Ho);
+        int wi = (int)(((long)wo * W) / Wo);
+        hi = hi < H ? hi : H - 1;
+        wi = wi < W ? wi : W - 1;
+        *reinterpret_cast<Pack<T, V>*>(out + ((n * Ho + ho) * Wo + wo) * ld_out + cv * V) =
+                *reinterpret_cast<const Pack<T, V>*>(in + ((n * H + hi) * W + wi) * ld_in + cv * V);
+    }
+}
+
+template <typename T, int V>
+__global__ void elementwise_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int op,
+                                   long pixels, int C, int ld_a, int ld_b, int ld_out) {
+    const int CV = C / V;
+    const long total = pixels * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long px = i / CV;
+        const Pack<T, V> x = *reinterpret_cast<const Pack<T, V>*>(a + px * ld_a + cv * V);
+        const Pack<T, V> y = *reinterpret_cast<const Pack<T, V>*>(b + px * ld_b + cv * V);
+        Pack<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] = from_f<T>(ew_f(to_f(x.v[e]), to_f(y.v[e]), op));
+        *reinterpret_cast<Pack<T, V>*>(out + px * ld_out + cv * V) = o;
+    }
+}
+
+template <typename T, int V>
+__global__ void activation_kernel(const T* __restrict__ in, T* __restrict__ out, int act, float alpha, long pixels,
+                                  int C, int ld_in, int ld_out) {
+    const int CV = C / V;
+    const long total = pixels * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long px = i / CV;
+        const Pack<T, V> x = *reinterpret_cast<const Pack<T, V>*>(in + px * ld_in + cv * V);
+        Pack<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] = from_f<T>(act_f(to_f(x.v[e]), act, alpha));
+        *reinterpret_cast<Pack<T, V>*>(out + px * ld_out + cv * V) = o;
+    }
+}
+
+template <typename T, int V>
+__global__ void scale_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ scale,
+                             const float* __restrict__ shift, long pixels, int C, int ld_in, int ld_out) {
+    const int CV = C / V;
+    const long total = pixels * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long px = i / CV;
+        const Pack<T, V> x = *reinterpret_cast<const Pack<T, V>*>(in + px * ld_in + cv * V);
+        Pack<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = cv * V + e;
+            const float sc = scale ? scale[c] : 1.f;
+            const float sh = shift ? shift[c] : 0.f;
+            o.v[e] = from_f<T>(to_f(x.v[e]) * sc + sh);
+        }
+        *reinterpret_cast<Pack<T, V>*>(out + px * ld_out + cv * V) = o;
+    }
+}
+
+template <typename T, int V>
+__global__ void copy_kernel(const T* __restrict__ in, T* __restrict__ out, long pixels, int C, int ld_in,
+                            int ld_out) {
+    const int CV = C / V;
+    const long total = pixels * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long px = i / CV;
+        *reinterpret_cast<Pack<T, V>*>(out + px * ld_out + cv * V) =
+                *reinterpret_cast<const Pack<T, V>*>(in + px * ld_in + cv * V);
+    }
+}
+
+template <typename T>
+__global__ void reduce_hw_avg_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C, int ld_in,
+                                     int ld_out) {
+    // one workgroup per (n, 64-channel group); threads = 64 channels x 4 pixel lanes
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int p = part; p < HW; p += 4) acc += to_f(in[((long)n * HW + p) * ld_in + c]);
+    __shared__ float s[4][64];
+    s[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float t = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+        out[(long)n * ld_out + c] = from_f<T>(t / (float)HW);
+    }
+}
+
+// ---- generic direct convolution / transposed convolution -----------------------------------------------
+template <typename T>
+__global__ void conv_direct_kernel(const ConvArgs p) {
+    const T* __restrict__ in = static_cast<const T*>(p.in);
+    const float* __restrict__ w = static_cast<const float*>(p.wgt);
+    const T* __restrict__ res = static_cast<const T*>(p.residual);
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const int cin_g = p.Cin / p.groups;
+    const int cout_g = p.Cout / p.groups;
+    const long total = (long)p.M * p.Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % p.Cout);
+        const long m = i / p.Cout;
+        const int wo = (int)(m % p.Wo);
+        const long t = m / p.Wo;
+        const int ho = (int)(t % p.Ho);
+        const long n = t / p.Ho;
+        const int g = co / cout_g;
+        float acc = p.bias ? p.bias[co] : 0.f;
+        const float* wk = w + (size_t)co * p.kh * p.kw * cin_g;
+        for (int r = 0; r < p.kh; ++r) {
+            const int hi = ho * p.stride_h - p.pad_h + r * p.dil_h;
+            if ((unsigned)hi >= (unsigned)p.H) continue;
+            for (int q = 0; q < p.kw; ++q) {
+                const int wi = wo * p.stride_w - p.pad_w + q * p.dil_w;
+                if ((unsigned)wi >= (unsigned)p.W) continue;
+                const T* ip = in + ((n * p.H + hi) * p.W + wi) * p.ld_in + g * cin_g;
+                const float* wp = wk + (r * p.kw + q) * cin_g;
+                for (int c = 0; c < cin_g; ++c) acc = fmaf(to_f(ip[c]), wp[c], acc);
+            }
+        }
+        acc = act_f(acc, p.act1, p.alpha1);
+        if (res) acc += to_f(res[m * p.ld_res + co]);
+        acc = act_f(acc, p.act2, p.alpha2);
+        out[m * p.ld_out + co] = from_f<T>(acc);
+    }
+}
+
+// weights pre-arranged as [Cout][kh][kw][Cin/groups] (gather form)
+template <typename T>
+__global__ void deconv_direct_kernel(const ConvArgs p) {
+    const T* __restrict__ in = static_cast<const T*>(p.in);
+    const float* __restrict__ w = static_cast<const float*>(p.wgt);
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const int cin_g = p.Cin / p.groups;
+    const int cout_g = p.Cout / p.groups;
+    const long total = (long)p.M * p.Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % p.Cout);
+        const long m = i / p.Cout;
+        const int wo = (int)(m % p.Wo);
+        const long t = m / p.Wo;
+        const int ho = (int)(t % p.Ho);
+        const long n = t / p.Ho;
+        const int g = co / cout_g;
+        float acc = p.bias ? p.bias[co] : 0.f;
+        const float* wk = w + (size_t)co * p.kh * p.kw * cin_g;
+        for (int r = 0; r < p.kh; ++r) {
+            const int th = ho + p.pad_h - r * p.dil_h;
+            if (th < 0 || th % p.stride_h) continue;
+            const int hi = th / p.stride_h;
+            if (hi >= p.H) continue;
+            for (int q = 0; q < p.kw; ++q) {
+                const int tw = wo + p.pad_w - q * p.dil_w;
+                if (tw < 0 || tw % p.stride_w) continue;
+                const int wi = tw / p.stride_w;
+                if (wi >= p.W) continue;
+                const T* ip = in + ((n * p.H + hi) * p.W + wi) * p.ld_in + g * cin_g;
+                const float* wp = wk + (r * p.kw + q) * cin_g;
+                for (int c = 0; c < cin_g; ++c) acc = fmaf(to_f(ip[c]), wp[c], acc);
+            }
+        }
+        acc = act_f(acc, p.act1, p.alpha1);
+        out[m * p.ld_out + co] = from_f<T>(acc);
+    }
+}
+
+template <typename T>
+constexpr int vec_of() {
+    return 16 / sizeof(T);
+}
+
+inline bool can_vec(int dtype, int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    const int v = dtype == DT_F16 ? 8 : 4;
+    if (C % v) return false;
+    for (int ld : lds)
+        if (ld % v) return false;
+    for (const void* p : ptrs)
+        if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+    return true;
+}
+
+#define DISPATCH_T_V(dtype, vec, CALL)                            \
+    do {                                                          \
+        if ((dtype) == DT_F16) {                                  \
+            if (vec) { CALL(_Float16, 8); } else { CALL(_Float16, 1); } \
+        } else {                                                  \
+            if (vec) { CALL(float, 4); } else { CALL(float, 1); } \
+        }                                                         \
+    } while (0)
+
+}  // namespace
+
+int32_t nchw_f32_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad, int ld_out,
+                         hipStream_t s) {
+    const long total = (long)N * H * W * Cpad;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, dim3(grid_for(total)), dim3(kThreads), 0, s, in,
+                           static_cast<_Float16*>(out), N, C, H, W, Cpad, ld_out);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, s, in,
+                           static_cast<float*>(out), N, C, H, W, Cpad, ld_out);
+    return check_launch("nchw_f32_to_nhwc");
+}
+
+int32_t nhwc_to_nchw_f32(const void* in, int dtype, float* out, int N, int C, int H, int W, int ld_in, hipStream_t s) {
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16*>(in), out,
+                           C, HW, ld_in);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(in), out, C, HW,
+                           ld_in);
+    return check_launch("nhwc_to_nchw_f32");
+}
+
+int32_t nhwc_pool(const void* in, void* out, int dtype, int op, int N, int H, int W, int C, int ld_in, int Ho, int Wo,
+                  int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int avg_exclusive, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});
+#define CALL(T, V)                                                                                                  \
+    hipLaunchKernelGGL((pool_kernel<T, V>), dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(kThreads), 0, s,     \
+                       static_cast<const T*>(in), static_cast<T*>(out), op, N, H, W, C, ld_in, Ho, Wo, ld_out, kh, \
+                       kw, sh, sw, ph, pw, avg_exclusive)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_pool");
+}
+
+int32_t nhwc_resize_nearest(const void* in, void* out, int dtype, int N, int H, int W, int C, int ld_in, int Ho,
+                            int Wo, int ld_out, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});
+#define CALL(T, V)                                                                                                   \
+    hipLaunchKernelGGL((resize_nearest_kernel<T, V>), dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(kThreads), \
+                       0, s, static_cast<const T*>(in), static_cast<T*>(out), N, H, W, C, ld_in, Ho, Wo, ld_out)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_resize_nearest");
+}
+
+int32_t nhwc_elementwise(const void* a, const void* b, void* out, int dtype, int op, long pixels, int C, int ld_a,
+                         int ld_b, int ld_out, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_a, ld_b, ld_out}, {a, b, out});
+#define CALL(T, V)                                                                                               \
+    hipLaunchKernelGGL((elementwise_kernel<T, V>), dim3(grid_for(pixels * (C / V))), dim3(kThreads), 0, s,      \
+                       static_cast<const T*>(a), static_cast<const T*>(b), static_cast<T*>(out), op, pixels, C, \
+                       ld_a, ld_b, ld_out)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_elementwise");
+}
+
+int32_t nhwc_activation(const void* in, void* out, int dtype, int act, float alpha, long pixels, int C, int ld_in,
+                        int ld_out, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});
+#define CALL(T, V)                                                                                          \
+    hipLaunchKernelGGL((activation_kernel<T, V>), dim3(grid_for(pixels * (C / V))), dim3(kThreads), 0, s,  \
+                       static_cast<const T*>(in), static_cast<T*>(out), act, alpha, pixels, C, ld_in, ld_out)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_activation");
+}
+
+int32_t nhwc_scale(const void* in, void* out, int dtype, const float* scale, const float* shift, long pixels, int C,
+                   int ld_in, int ld_out, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});
+#define CALL(T, V)                                                                                     \
+    hipLaunchKernelGGL((scale_kernel<T, V>), dim3(grid_for(pixels * (C / V))), dim3(kThreads), 0, s,  \
+                       static_cast<const T*>(in), static_cast<T*>(out), scale, shift, pixels, C, ld_in, ld_out)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_scale");
+}
+
+int32_t nhwc_copy(const void* in, void* out, int dtype, long pixels, int C, int ld_in, int ld_out, hipStream_t s) {
+    const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});
+#define CALL(T, V)                                                                                    \
+    hipLaunchKernelGGL((copy_kernel<T, V>), dim3(grid_for(pixels * (C / V))), dim3(kThreads), 0, s,  \
+                       static_cast<const T*>(in), static_cast<T*>(out), pixels, C, ld_in, ld_out)
+    DISPATCH_T_V(dtype, vec, CALL);
+#undef CALL
+    return check_launch("nhwc_copy");
+}
+
+int32_t nhwc_reduce_hw_avg(const void* in, void* out, int dtype, int N, int HW, int C, int ld_in, int ld_out,
+                           hipStream_t s) {
+    dim3 grid((C + 63) / 64, N);
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(reduce_hw_avg_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16*>(in),
+                           static_cast<_Float16*>(out), HW, C, ld_in, ld_out);
+    else
+        hipLaunchKernelGGL(reduce_hw_avg_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(in),
+                           static_cast<float*>(out), HW, C, ld_in, ld_out);
+    return check_launch("nhwc_reduce_hw_avg");
+}
+
+int32_t conv_direct(const ConvArgs& a, int dtype, hipStream_t s) {
+    const long total = (long)a.M * a.Cout;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(conv_direct_kernel<_Float16>, dim3(grid_for(total)), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv_direct_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, s, a);
+    return check_launch("conv_direct");
+}
+
+int32_t deconv_direct(const ConvArgs& a, int dtype, hipStream_t s) {
+    const long total = (long)a.M * a.Cout;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(deconv_direct_kernel<_Float16>, dim3(grid_for(total)), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(deconv_direct_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, s, a);
+    return check_launch("deconv_direct");
+}
+
+}  // namespace trtx

@@ -1,0 +1,92 @@
+// extern "C" entry points that expose single kernels (for parity tests, micro-benchmarks and
+// reference-style plugin classes) plus the library-level queries.  See include/trtx_hip.h.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "kernels/kernels.h"
+#include "runtime/pack.h"
+
+using namespace trtx;
+
+extern "C" const char* trtx_status_string(int32_t s) {
+    switch (s) {
+        case TRTX_OK: return "ok";
+        case TRTX_ERR_INVALID: return "invalid argument";
+        case TRTX_ERR_HIP: return "HIP error";
+        case TRTX_ERR_WORKSPACE: return "workspace too small";
+        case TRTX_ERR_UNSUPPORTED: return "unsupported configuration";
+        case TRTX_ERR_NO_DEVICE: return "no HIP device";
+        case TRTX_ERR_IO: return "I/O or parse error";
+        case TRTX_ERR_STATE: return "invalid call order";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int32_t trtx_abi_version(void) {
+    return TRTX_ABI_VERSION;
+}
+
+extern "C" int32_t trtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int32_t trtx_conv_packed_dims(int cout, int cin_pad, int kh, int kw, int32_t* cout_pad, int32_t* kpad,
+                                         int32_t* bn) {
+    if (cout < 1 || cin_pad < 1 || kh < 1 || kw < 1) return TRTX_ERR_INVALID;
+    const int b = conv_igemm_pick_bn(cout);
+    if (bn) *bn = b;
+    if (cout_pad) *cout_pad = (cout + b - 1) / b * b;
+    if (kpad) *kpad = (kh * kw * cin_pad + 31) / 32 * 32;
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_conv_pack_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
+                                              const float* ch_scale, uint16_t* packed) {
+    if (!w_kcrs || !packed || cin_pad < cin) return TRTX_ERR_INVALID;
+    pack_conv_weights_f16(w_kcrs, cout, cin, kh, kw, cin_pad, ch_scale, packed);
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked,
+                                           const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int sh,
+                                           int sw, int ph, int pw, int act1, const void* residual, int ld_res,
+                                           int act2, trtx_stream_t stream) {
+    ConvArgs a{};
+    a.in = in;
+    a.wgt = wpacked;
+    a.bias = bias;
+    a.out = out;
+    a.residual = residual;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in;
+    a.Ho = (H + 2 * ph - kh) / sh + 1;
+    a.Wo = (W + 2 * pw - kw) / sw + 1;
+    a.Cout = Cout;
+    a.bn = conv_igemm_pick_bn(Cout);
+    a.Cout_pad = (Cout + a.bn - 1) / a.bn * a.bn;
+    a.ld_out = ld_out; a.ld_res = ld_res;
+    a.kh = kh; a.kw = kw; a.stride_h = sh; a.stride_w = sw; a.pad_h = ph; a.pad_w = pw; a.dil_h = 1; a.dil_w = 1;
+    a.groups = 1;
+    a.K = kh * kw * Cin;
+    a.Kpad = (a.K + 31) / 32 * 32;
+    a.M = N * a.Ho * a.Wo;
+    a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
+    return conv_igemm_f16(a, stream);
+}
+
+extern "C" int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad,
+                                                int ld_out, trtx_stream_t stream) {
+    return nchw_f32_to_nhwc(in, out, DT_F16, N, C, H, W, Cpad, ld_out, stream);
+}
+
+extern "C" int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ld_in,
+                                                trtx_stream_t stream) {
+    return nhwc_to_nchw_f32(in, DT_F16, out, N, C, H, W, ld_in, stream);
+}

@@ -1,0 +1,219 @@
+// YOLOv8 anchor-free decode for gfx950 (MI355X) — deterministic two-pass compaction.
+//
+// Replaces YoloLayerPlugin::forwardGpu + CalDetection of the reference
+// (yolov8/plugin/yololayer.cu:178-220, 282-316).  Same arithmetic per cell:
+//   p_c = 1/(1+expf(-logit_c)); argmax with strict '>' from (0.0, class 0); drop if p < 0.1;
+//   bbox = [(col+.5-l)*s, (row+.5-t)*s, (col+.5+r)*s, (row+.5+b)*s]; conf = p; class_id = argmax.
+// Differences (both documented in DESIGN.md):
+//   * slots are handed out in canonical (level, cell) order by a prefix scan instead of atomicAdd,
+//     so the output is bit-reproducible (the reference's slot order is a race);
+//   * out[b][0] is clamped to max_out (the reference lets the counter run past the buffer).
+//
+// HBM-bound: reads (4+classes) x cells x 4 B per image once (pass 1, 16 B per lane, coalesced along
+// the cell axis), then 8 B/cell of scratch + the 4 box channels of the surviving cells (pass 2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+constexpr int kChunk = 512;  // cells per workgroup in both passes
+
+struct LevelTable {
+    const float* in[kMaxLevels];  // device pointers, [batch][4+classes][cells]
+    int cell_off[kMaxLevels + 1];  // cumulative cell offsets
+    int grid_w[kMaxLevels];
+    int stride[kMaxLevels];
+    int n_levels;
+};
+
+__device__ __forceinline__ float logist(float x) {
+    return 1.0f / (1.0f + expf(-x));
+}
+
+__device__ __forceinline__ int find_level(const LevelTable& t, int g) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < t.n_levels && g >= t.cell_off[i])
+            l = i;
+    return l;
+}
+
+// Pass 1: per cell best class/prob.  VEC cells per thread (VEC = 4 -> 16-byte loads).
+template <int VEC>
+__global__ __launch_bounds__(kChunk / VEC) void yolo_score_kernel(LevelTable t, int classes, int total_cells,
+                                                                  float* __restrict__ score,
+                                                                  int* __restrict__ cls_out,
+                                                                  int* __restrict__ chunk_cnt, int n_chunks) {
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int g0 = chunk * kChunk + threadIdx.x * VEC;
+    int nflag = 0;
+    if (g0 < total_cells) {
+        const int l = find_level(t, g0);
+        const int cells = t.cell_off[l + 1] - t.cell_off[l];
+        const int e0 = g0 - t.cell_off[l];
+        const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e0;
+        float best[VEC];
+        int bcls[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            best[v] = 0.0f;
+            bcls[v] = 0;
+        }
+#pragma unroll 4
+        for (int c = 0; c < classes; ++c) {
+            float x[VEC];
+            const float* p = cur + (size_t)(4 + c) * cells;
+            if constexpr (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x[v] = p[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float pr = logist(x[v]);
+                if (pr > best[v]) {
+                    best[v] = pr;
+                    bcls[v] = c;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int g = g0 + v;
+            if (g < total_cells) {
+                const bool keep = !((double)best[v] < 0.1);  // same comparison as yololayer.cu:203
+                score[(size_t)b * total_cells + g] = keep ? best[v] : -1.0f;
+                cls_out[(size_t)b * total_cells + g] = bcls[v];
+                nflag += keep ? 1 : 0;
+            }
+        }
+    }
+    // workgroup reduction of nflag
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int w = nflag;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&s_cnt, w);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[b * n_chunks + chunk] = s_cnt;
+}
+
+// Pass 2: ordered compaction.  One thread per cell, kChunk threads per workgroup.
+__global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int classes, int total_cells,
+                                                           const float* __restrict__ score,
+                                                           const int* __restrict__ cls_in,
+                                                           const int* __restrict__ chunk_cnt, int n_chunks,
+                                                           int max_out, int out_elem, float* __restrict__ output) {
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int kWaves = kChunk / 64;
+    __shared__ int s_wave[kWaves];
+    __shared__ int s_base;
+
+    // slots used by earlier chunks of this image
+    if (wave == 0) {
+        int acc = 0;
+        for (int j = lane; j < chunk; j += 64) acc += chunk_cnt[b * n_chunks + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) s_base = acc;
+    }
+    const int g = chunk * kChunk + threadIdx.x;
+    float sc = -1.0f;
+    if (g < total_cells) sc = score[(size_t)b * total_cells + g];
+    const bool keep = sc >= 0.0f;
+    const unsigned long long m = __ballot(keep);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = s_base;
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv)
+        if (wv < wave) before += s_wave[wv];
+    const int slot = before + in_wave;
+    float* out = output + (size_t)b * out_elem;
+    if (keep && slot < max_out) {
+        const int l = find_level(t, g);
+        const int cells = t.cell_off[l + 1] - t.cell_off[l];
+        const int e = g - t.cell_off[l];
+        const int gw = t.grid_w[l];
+        const float stride = (float)t.stride[l];
+        const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e;
+        const int row = e / gw, col = e - row * gw;
+        float* det = out + 1 + (size_t)slot * trtx::kYoloDetFloats;
+        det[0] = (col + 0.5f - cur[0]) * stride;
+        det[1] = (row + 0.5f - cur[(size_t)cells]) * stride;
+        det[2] = (col + 0.5f + cur[(size_t)2 * cells]) * stride;
+        det[3] = (row + 0.5f + cur[(size_t)3 * cells]) * stride;
+        det[4] = sc;
+        det[5] = (float)cls_in[(size_t)b * total_cells + g];
+    }
+    if (chunk == n_chunks - 1 && threadIdx.x == kChunk - 1) {
+        int total = before + in_wave + (keep ? 1 : 0);  // last thread of the last chunk sees the full count
+        out[0] = (float)(total < max_out ? total : max_out);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t trtx_yolo_decode_workspace(int batch, int net_h, int net_w, const int* strides, int n_levels) {
+    size_t cells = 0;
+    for (int i = 0; i < n_levels; ++i) cells += (size_t)(net_h / strides[i]) * (net_w / strides[i]);
+    const size_t n_chunks = (cells + kChunk - 1) / kChunk;
+    return trtx::align_up((size_t)batch * cells * sizeof(float), 256) +
+           trtx::align_up((size_t)batch * cells * sizeof(int), 256) +
+           trtx::align_up((size_t)batch * n_chunks * sizeof(int), 256);
+}
+
+extern "C" int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, int classes, int net_h,
+                                    int net_w, const int* strides, int max_out, float* output, void* workspace,
+                                    size_t workspace_bytes, hipStream_t stream) {
+    if (n_levels < 1 || n_levels > kMaxLevels || batch < 1 || classes < 1 || max_out < 1 || !inputs || !output ||
+        !workspace)
+        return TRTX_ERR_INVALID;
+    if (workspace_bytes < trtx_yolo_decode_workspace(batch, net_h, net_w, strides, n_levels)) return TRTX_ERR_WORKSPACE;
+    LevelTable t{};
+    t.n_levels = n_levels;
+    bool vec4 = true;
+    int off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const int gh = net_h / strides[i], gw = net_w / strides[i];
+        t.in[i] = inputs[i];
+        t.cell_off[i] = off;
+        t.grid_w[i] = gw;
+        t.stride[i] = strides[i];
+        off += gh * gw;
+        if ((gh * gw) % 4 != 0 || (reinterpret_cast<uintptr_t>(inputs[i]) & 15) != 0) vec4 = false;
+    }
+    for (int i = n_levels; i <= kMaxLevels; ++i) t.cell_off[i] = off;
+    const int total_cells = off;
+    const int n_chunks = (total_cells + kChunk - 1) / kChunk;
+    char* ws = static_cast<char*>(workspace);
+    float* score = reinterpret_cast<float*>(ws);
+    ws += trtx::align_up((size_t)batch * total_cells * sizeof(float), 256);
+    int* cls = reinterpret_cast<int*>(ws);
+    ws += trtx::align_up((size_t)batch * total_cells * sizeof(int), 256);
+    int* chunk_cnt = reinterpret_cast<int*>(ws);
+    const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
+    dim3 grid(n_chunks, batch);
+    if (vec4)
+        hipLaunchKernelGGL(yolo_score_kernel<4>, grid, dim3(kChunk / 4), 0, stream, t, classes, total_cells, score,
+                           cls, chunk_cnt, n_chunks);
+    else
+        hipLaunchKernelGGL(yolo_score_kernel<1>, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
+                           chunk_cnt, n_chunks);
+    hipLaunchKernelGGL(yolo_emit_kernel, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
+                       chunk_cnt, n_chunks, max_out, out_elem, output);
+    return trtx::check_launch("trtx_yolo_decode");
+}

@@ -1,0 +1,65 @@
+#include "pack.h"
+
+#include <string.h>
+
+#include "../kernels/kernels.h"
+
+namespace trtx {
+
+uint16_t f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)f;  // round-to-nearest-even, same as the device conversion
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+float f16_bits_to_f32(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+void pack_conv_weights_f16(const float* w, int cout, int cin, int kh, int kw, int cin_pad, const float* ch_scale,
+                           uint16_t* packed) {
+    const int bn = conv_igemm_pick_bn(cout);
+    const int cout_pad = (cout + bn - 1) / bn * bn;
+    const int K = kh * kw * cin_pad;
+    const int kpad = (K + 31) / 32 * 32;
+    memset(packed, 0, sizeof(uint16_t) * (size_t)cout_pad * kpad);
+    for (int co = 0; co < cout; ++co) {
+        const float sc = ch_scale ? ch_scale[co] : 1.0f;
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int q = 0; q < kw; ++q) {
+                    const float v = w[(((size_t)co * cin + c) * kh + r) * kw + q] * sc;
+                    packed[(size_t)co * kpad + (size_t)(r * kw + q) * cin_pad + c] = f32_to_f16_bits(v);
+                }
+    }
+}
+
+void pack_conv_weights_f32(const float* w, int cout, int cin_g, int kh, int kw, const float* ch_scale, float* packed) {
+    for (int co = 0; co < cout; ++co) {
+        const float sc = ch_scale ? ch_scale[co] : 1.0f;
+        for (int c = 0; c < cin_g; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int q = 0; q < kw; ++q)
+                    packed[(((size_t)co * kh + r) * kw + q) * cin_g + c] =
+                            w[(((size_t)co * cin_g + c) * kh + r) * kw + q] * sc;
+    }
+}
+
+void pack_deconv_weights_f32(const float* w, int cin, int cout, int groups, int kh, int kw, float* packed) {
+    const int cin_g = cin / groups, cout_g = cout / groups;
+    for (int co = 0; co < cout; ++co) {
+        const int g = co / cout_g, col = co % cout_g;
+        for (int c = 0; c < cin_g; ++c) {
+            const int ci = g * cin_g + c;
+            for (int r = 0; r < kh; ++r)
+                for (int q = 0; q < kw; ++q)
+                    packed[(((size_t)co * kh + r) * kw + q) * cin_g + c] =
+                            w[(((size_t)ci * cout_g + col) * kh + r) * kw + q];
+        }
+    }
+}
+
+}  // namespace trtx

@@ -1,0 +1,44 @@
+"""Seeded synthetic inputs of the shapes SURVEY.md §8(d) prescribes (no datasets / weights offline)."""
+import numpy as np
+
+
+def yolo_head_tensors(batch, classes=80, net_h=640, net_w=640, strides=(8, 16, 32), objects=(40, 180), seed=0,
+                      bg_mean=-8.0, bg_std=1.5):
+    """Planted-object head tensors for the YoloLayer plugin: list of [B, 4+classes, gh*gw] fp32.
+
+    Box channels ltrb ~ U(0, 10) cells, class logits ~ N(bg_mean, bg_std^2); per image K in `objects`
+    planted objects: one class gets logit +4..+8 on 3-8 neighbouring cells with consistent boxes so
+    that NMS clusters exist (candidates(sigma >= 0.1) << 1000, survivors(conf > 0.5) ~ 100-600).
+    """
+    rng = np.random.default_rng(seed)
+    outs = []
+    for s in strides:
+        gh, gw = net_h // s, net_w // s
+        x = np.empty((batch, 4 + classes, gh * gw), dtype=np.float32)
+        x[:, :4] = rng.uniform(0.0, 10.0, size=(batch, 4, gh * gw)).astype(np.float32)
+        x[:, 4:] = rng.normal(bg_mean, bg_std, size=(batch, classes, gh * gw)).astype(np.float32)
+        outs.append(x)
+    for b in range(batch):
+        k_obj = int(rng.integers(objects[0], objects[1] + 1))
+        for _ in range(k_obj):
+            l = int(rng.integers(0, len(strides)))
+            s = strides[l]
+            gh, gw = net_h // s, net_w // s
+            row, col = int(rng.integers(1, gh - 1)), int(rng.integers(1, gw - 1))
+            cls = int(rng.integers(0, classes))
+            # object box in pixels around the anchor point
+            cx, cy = (col + 0.5) * s, (row + 0.5) * s
+            hw_, hh_ = rng.uniform(1.0, 6.0) * s, rng.uniform(1.0, 6.0) * s
+            x1, y1, x2, y2 = cx - hw_, cy - hh_, cx + hw_, cy + hh_
+            n_cells = int(rng.integers(3, 9))
+            for _c in range(n_cells):
+                r = min(max(row + int(rng.integers(-1, 2)), 0), gh - 1)
+                c = min(max(col + int(rng.integers(-1, 2)), 0), gw - 1)
+                e = r * gw + c
+                jit = rng.normal(0.0, 0.15, size=4)
+                outs[l][b, 0, e] = (c + 0.5) - x1 / s + jit[0]
+                outs[l][b, 1, e] = (r + 0.5) - y1 / s + jit[1]
+                outs[l][b, 2, e] = x2 / s - (c + 0.5) + jit[2]
+                outs[l][b, 3, e] = y2 / s - (r + 0.5) + jit[3]
+                outs[l][b, 4 + cls, e] = rng.uniform(0.5, 8.0)
+    return outs

@@ -1,0 +1,84 @@
+"""GPU numerics: fused implicit-GEMM MFMA convolution vs a plain PyTorch fp32 reference of the same op
+(conv2d on the fp16-rounded operands, fp32 math).  Shapes are taken from the YOLOv8n / ResNet-50
+inventories."""
+import numpy as np
+import pytest
+
+from tensorrtx_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x_nhwc_h, w, bias, stride, pad, act1, res_h, act2):
+    import torch
+    import torch.nn.functional as F
+    x = x_nhwc_h.float().permute(0, 3, 1, 2)
+    y = F.conv2d(x, w.half().float(), bias, stride=stride, padding=pad)
+    act = {"none": lambda t: t, "relu": torch.relu, "silu": F.silu, "sigmoid": torch.sigmoid,
+           "leaky": lambda t: F.leaky_relu(t, 0.1)}
+    y = act[act1](y)
+    if res_h is not None:
+        y = y.half().float() + res_h.float().permute(0, 3, 1, 2)  # kernel rounds to fp16 before the add
+    y = act[act2](y)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, s, p, act1, residual, act2
+    (2, 40, 40, 8, 16, 3, 2, 1, "silu", False, "none"),      # stem-like (Cin padded to 8, K=72 -> Kpad 96)
+    (2, 32, 32, 16, 32, 3, 2, 1, "silu", False, "none"),
+    (2, 20, 20, 32, 32, 1, 1, 0, "silu", False, "none"),
+    (2, 20, 20, 16, 16, 3, 1, 1, "silu", True, "none"),      # C2F bottleneck with shortcut
+    (1, 20, 20, 64, 80, 3, 1, 1, "silu", False, "none"),     # cv3 branch, Cout = 80 (5 fragments)
+    (1, 20, 20, 80, 80, 3, 1, 1, "silu", False, "none"),     # Cin = 80 (tap boundary inside a k-tile)
+    (1, 20, 20, 80, 80, 1, 1, 0, "none", False, "none"),     # detect head 1x1 with bias
+    (2, 10, 10, 128, 256, 3, 2, 1, "silu", False, "none"),
+    (1, 10, 10, 384, 256, 1, 1, 0, "silu", False, "none"),
+    (1, 14, 14, 256, 64, 1, 1, 0, "none", True, "relu"),     # resnet bottleneck tail: relu(conv + shortcut)
+    (1, 17, 13, 48, 64, 3, 1, 1, "relu", False, "none"),     # ragged M (221 pixels), Cin 48
+    (1, 9, 9, 24, 40, 5, 1, 2, "leaky", False, "none"),      # 5x5, Cout 40 (padded to 48 -> bn 16)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_igemm_vs_torch(gpu, case):
+    import torch
+    N, H, W, Cin, Cout, k, s, p, act1, use_res, act2 = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.0).half()
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = (torch.randn(N, Ho, Wo, Cout, generator=g)).half() if use_res else None
+    packed, cout_pad, kpad, bn = capi.pack_conv_weights_f16(w.numpy(), cin_pad=Cin)
+    bias_pad = torch.zeros(cout_pad)
+    bias_pad[:Cout] = bias
+    y = capi.conv2d_nhwc_f16(x.to(gpu), torch.from_numpy(packed.view(np.int16)).to(gpu), bias_pad.to(gpu), Cout, k, k,
+                             s, p, act1, res.to(gpu) if use_res else None, act2)
+    torch.cuda.synchronize()
+    ref = _ref(x, w, bias, s, p, act1, res, act2)
+    got = y.float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"max err {err} (scale {scale})"
+
+
+def test_conv_writes_channel_slice_of_wider_buffer(gpu):
+    """Concat fusion: the conv stores into channels [16, 48) of a 64-channel NHWC buffer and reads a
+    32-channel slice of a 64-channel input (strided views, block.cpp:134-149 C2F without copies)."""
+    import torch
+    g = torch.Generator().manual_seed(3)
+    xin = torch.randn(2, 12, 12, 64, generator=g).half()
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.06
+    packed, cout_pad, kpad, bn = capi.pack_conv_weights_f16(w.numpy(), cin_pad=32)
+    buf = torch.full((2, 12, 12, 64), 7.0).half().to(gpu)
+    xg = xin.to(gpu)
+    x_view = xg[..., 32:]            # channel slice, stride(2) stays 64
+    out_view = buf[..., 16:48]
+    capi.conv2d_nhwc_f16(x_view, torch.from_numpy(packed.view(np.int16)).to(gpu), None, 32, 3, 3, 1, 1, "none",
+                         out=out_view, out_ld=64)
+    torch.cuda.synchronize()
+    ref = _ref(xin[..., 32:].contiguous(), w, None, 1, 1, "none", None, "none")
+    got = buf.float().cpu()
+    assert (got[..., :16] == 7.0).all() and (got[..., 48:] == 7.0).all()
+    assert (got[..., 16:48] - ref).abs().max().item() < 5e-3
