@@ -73,6 +73,255 @@ int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, in
 int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
                       int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, trtx_stream_t stream);
 
+
+/* ---- single-kernel entry points (parity tests / micro-benchmarks) ----------------------------- */
+/* activation codes for the fused conv epilogue */
+#define TRTX_ACT_NONE 0
+#define TRTX_ACT_RELU 1
+#define TRTX_ACT_SIGMOID 2
+#define TRTX_ACT_SILU 3
+#define TRTX_ACT_LEAKY 4
+#define TRTX_ACT_TANH 5
+/* dims of the packed fp16 weight image [cout_pad][kpad] the implicit-GEMM kernel reads */
+int32_t trtx_conv_packed_dims(int cout, int cin_pad, int kh, int kw, int32_t* cout_pad, int32_t* kpad, int32_t* bn);
+/* host: KCRS fp32 -> packed fp16 (optional per-output-channel scale = folded BatchNorm) */
+int32_t trtx_conv_pack_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
+                                   const float* ch_scale, uint16_t* packed);
+/* one fused convolution launch: NHWC fp16 in/out (channel strides ld_*), y = act2(act1(conv+bias) + residual) */
+int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked,
+                                const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int sh, int sw,
+                                int ph, int pw, int act1, const void* residual, int ld_res, int act2,
+                                trtx_stream_t stream);
+int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad, int ld_out,
+                                     trtx_stream_t stream);
+int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ld_in,
+                                     trtx_stream_t stream);
+
+/* ================= Section 2: network definition / engine / execution context =================== */
+/*
+ * Mirrors, object for object, the nvinfer1 API subset the reference builders use (SURVEY.md §2.3,
+ * §8b): IBuilder / IBuilderConfig / INetworkDefinition / ITensor / ILayer / IHostMemory / IRuntime /
+ * ICudaEngine / IExecutionContext / IPluginV2 / IPluginCreator / getPluginRegistry().
+ * include/NvInfer.h is the header-only C++ shim that gives these the nvinfer1 spelling.
+ *
+ * Ownership: layers and tensors are owned by their network (never freed by the caller); weights are
+ * COPIED when a layer is added, so the caller may free its host blobs after build (the reference frees
+ * them after buildSerializedNetwork, yolov8/src/model.cpp:332-334).
+ */
+typedef struct trtx_builder trtx_builder;
+typedef struct trtx_network trtx_network;
+typedef struct trtx_hostmem trtx_hostmem;
+typedef struct trtx_engine trtx_engine;
+typedef struct trtx_context trtx_context;
+typedef struct trtx_plugin trtx_plugin; /* runtime-side handle of one plugin instance */
+
+#define TRTX_MAX_DIMS 8
+typedef struct trtx_dims {
+    int32_t nb;
+    int64_t d[TRTX_MAX_DIMS];
+} trtx_dims;
+
+/* nvinfer1::DataType */
+#define TRTX_DTYPE_FLOAT 0
+#define TRTX_DTYPE_HALF 1
+#define TRTX_DTYPE_INT8 2
+#define TRTX_DTYPE_INT32 3
+/* nvinfer1::ActivationType */
+#define TRTX_ACTIVATION_RELU 0
+#define TRTX_ACTIVATION_SIGMOID 1
+#define TRTX_ACTIVATION_TANH 2
+#define TRTX_ACTIVATION_LEAKY_RELU 3
+/* nvinfer1::PoolingType */
+#define TRTX_POOLING_MAX 0
+#define TRTX_POOLING_AVERAGE 1
+/* nvinfer1::ElementWiseOperation */
+#define TRTX_ELEMENTWISE_SUM 0
+#define TRTX_ELEMENTWISE_PROD 1
+#define TRTX_ELEMENTWISE_MAX 2
+#define TRTX_ELEMENTWISE_MIN 3
+#define TRTX_ELEMENTWISE_SUB 4
+#define TRTX_ELEMENTWISE_DIV 5
+#define TRTX_ELEMENTWISE_POW 6
+/* nvinfer1::ScaleMode */
+#define TRTX_SCALE_UNIFORM 0
+#define TRTX_SCALE_CHANNEL 1
+#define TRTX_SCALE_ELEMENTWISE 2
+/* nvinfer1::ReduceOperation */
+#define TRTX_REDUCE_SUM 0
+#define TRTX_REDUCE_PROD 1
+#define TRTX_REDUCE_MAX 2
+#define TRTX_REDUCE_MIN 3
+#define TRTX_REDUCE_AVG 4
+/* nvinfer1::MatrixOperation */
+#define TRTX_MATMUL_NONE 0
+#define TRTX_MATMUL_TRANSPOSE 1
+#define TRTX_MATMUL_VECTOR 2
+/* nvinfer1::ResizeMode */
+#define TRTX_RESIZE_NEAREST 0
+#define TRTX_RESIZE_LINEAR 1
+/* nvinfer1::BuilderFlag */
+#define TRTX_FLAG_FP16 0
+#define TRTX_FLAG_INT8 1
+/* layer parameter ids for trtx_layer_set_ints / _floats / _dims */
+#define TRTX_P_STRIDE 1
+#define TRTX_P_PADDING 2
+#define TRTX_P_DILATION 3
+#define TRTX_P_GROUPS 4
+#define TRTX_P_ALPHA 5
+#define TRTX_P_BETA 6
+#define TRTX_P_AXIS 7          /* concat axis; softmax / reduce axes bitmask */
+#define TRTX_P_RESHAPE 8       /* IShuffleLayer::setReshapeDimensions */
+#define TRTX_P_FIRST_TRANSPOSE 9
+#define TRTX_P_SECOND_TRANSPOSE 10
+#define TRTX_P_RESIZE_MODE 11
+#define TRTX_P_RESIZE_SCALES 12
+#define TRTX_P_RESIZE_OUT_DIMS 13
+#define TRTX_P_AVG_EXCLUSIVE 14
+#define TRTX_P_KERNEL 15
+#define TRTX_P_NB_OUT 16
+
+/* --- plugins: C v-table an IPluginV2-style object is driven through --------------------------- */
+/* Every callback receives `self`.  Semantics and call order follow IPluginV2Ext/IOExt as the reference
+ * uses them (yolov8/plugin/yololayer.h:7-81; rcnn/RpnDecodePlugin.h:29-187; SURVEY.md §8b lifecycle):
+ * clone at addPluginV2 -> configure -> workspace_size -> initialize -> serialize at plan write;
+ * on load: creator.deserialize -> configure -> initialize -> enqueue xN -> terminate -> destroy.
+ * Tensors at the plugin edge are fp32 LINEAR (NCHW), as supportsFormatCombination demands in the
+ * reference (yololayer.h:32-35). */
+typedef struct trtx_plugin_vtbl {
+    void* self;
+    int32_t (*get_nb_outputs)(void* self);
+    int32_t (*get_output_dims)(void* self, int32_t index, const trtx_dims* inputs, int32_t nb_inputs, trtx_dims* out);
+    int32_t (*configure)(void* self, const trtx_dims* in, int32_t nb_in, const trtx_dims* out, int32_t nb_out,
+                         int32_t max_batch);
+    int32_t (*initialize)(void* self);
+    void (*terminate)(void* self);
+    size_t (*workspace_size)(void* self, int32_t max_batch);
+    int32_t (*enqueue)(void* self, int32_t batch, const void* const* inputs, void* const* outputs, void* workspace,
+                       trtx_stream_t stream); /* 0 = OK, as IPluginV2::enqueue */
+    size_t (*serialization_size)(void* self);
+    void (*serialize)(void* self, void* buffer);
+    const char* (*plugin_type)(void* self);
+    const char* (*plugin_version)(void* self);
+    /* fills *out with a v-table for an independent copy; returns 0 on success */
+    int32_t (*clone)(void* self, struct trtx_plugin_vtbl* out);
+    void (*destroy)(void* self);
+} trtx_plugin_vtbl;
+
+typedef struct trtx_plugin_field {
+    const char* name;
+    const void* data;
+    int32_t type; /* nvinfer1::PluginFieldType: 0 f16, 1 f32, 2 f64, 3 i8, 4 i16, 5 i32, 6 char */
+    int32_t length;
+} trtx_plugin_field;
+
+typedef struct trtx_creator_vtbl {
+    void* self;
+    const char* (*plugin_name)(void* self);
+    const char* (*plugin_version)(void* self);
+    int32_t (*create)(void* self, const char* name, const trtx_plugin_field* fields, int32_t nb_fields,
+                      trtx_plugin_vtbl* out);
+    int32_t (*deserialize)(void* self, const char* name, const void* data, size_t length, trtx_plugin_vtbl* out);
+} trtx_creator_vtbl;
+
+/* getPluginRegistry()->registerCreator / getPluginCreator (REGISTER_TENSORRT_PLUGIN, yololayer.h:109).
+ * Built-in HIP plugins are pre-registered: "YoloLayer_TRT"/"1", "Decode_TRT"/"1" (retinaface). */
+int32_t trtx_registry_register(const trtx_creator_vtbl* creator);
+int32_t trtx_registry_get(const char* name, const char* version, trtx_creator_vtbl* out);
+
+/* --- .wts weight files (loadWeights, lenet/utils.h:49-80; yolov8/src/block.cpp:13-43) ----------- */
+typedef struct trtx_wts trtx_wts;
+int32_t trtx_wts_load(const char* path, trtx_wts** out);
+int32_t trtx_wts_count(const trtx_wts* w);
+/* i-th entry in file order; values are the host fp32 array owned by `w` */
+int32_t trtx_wts_entry(const trtx_wts* w, int32_t i, const char** name, const float** values, int64_t* count);
+int32_t trtx_wts_find(const trtx_wts* w, const char* name, const float** values, int64_t* count);
+void trtx_wts_free(trtx_wts* w);
+
+/* --- builder / config (createInferBuilder, IBuilderConfig) --------------------------------------- */
+int32_t trtx_builder_create(trtx_builder** out);
+void trtx_builder_destroy(trtx_builder* b);
+int32_t trtx_builder_set_max_batch(trtx_builder* b, int32_t n);        /* IBuilder::setMaxBatchSize */
+int32_t trtx_builder_set_flag(trtx_builder* b, int32_t flag, int32_t on); /* IBuilderConfig::setFlag */
+int32_t trtx_builder_set_workspace(trtx_builder* b, size_t bytes);     /* setMaxWorkspaceSize / setMemoryPoolLimit */
+/* createNetworkV2(flags): bit 0 = kEXPLICIT_BATCH */
+int32_t trtx_network_create(trtx_builder* b, uint32_t flags, trtx_network** out);
+void trtx_network_destroy(trtx_network* n);
+const char* trtx_network_last_error(const trtx_network* n);
+
+/* --- INetworkDefinition::add*: return a layer index (>= 0) or -1; outputs via trtx_layer_output ---- */
+int32_t trtx_add_input(trtx_network* n, const char* name, int32_t dtype, const trtx_dims* dims); /* tensor id */
+int32_t trtx_add_convolution(trtx_network* n, int32_t input, int32_t nb_out, int32_t kh, int32_t kw,
+                             const float* kernel, int64_t kernel_count, const float* bias, int64_t bias_count);
+int32_t trtx_add_deconvolution(trtx_network* n, int32_t input, int32_t nb_out, int32_t kh, int32_t kw,
+                               const float* kernel, int64_t kernel_count, const float* bias, int64_t bias_count);
+int32_t trtx_add_fully_connected(trtx_network* n, int32_t input, int32_t nb_out, const float* kernel,
+                                 int64_t kernel_count, const float* bias, int64_t bias_count);
+int32_t trtx_add_activation(trtx_network* n, int32_t input, int32_t type);
+int32_t trtx_add_pooling(trtx_network* n, int32_t input, int32_t type, int32_t kh, int32_t kw);
+int32_t trtx_add_scale(trtx_network* n, int32_t input, int32_t mode, const float* shift, int64_t shift_count,
+                       const float* scale, int64_t scale_count, const float* power, int64_t power_count);
+int32_t trtx_add_elementwise(trtx_network* n, int32_t a, int32_t b, int32_t op);
+int32_t trtx_add_concatenation(trtx_network* n, const int32_t* inputs, int32_t nb_inputs);
+int32_t trtx_add_slice(trtx_network* n, int32_t input, const trtx_dims* start, const trtx_dims* size,
+                       const trtx_dims* stride);
+int32_t trtx_add_shuffle(trtx_network* n, int32_t input);
+int32_t trtx_add_resize(trtx_network* n, int32_t input);
+int32_t trtx_add_softmax(trtx_network* n, int32_t input);
+int32_t trtx_add_matrix_multiply(trtx_network* n, int32_t a, int32_t op_a, int32_t b, int32_t op_b);
+int32_t trtx_add_constant(trtx_network* n, const trtx_dims* dims, const float* values, int64_t count);
+int32_t trtx_add_reduce(trtx_network* n, int32_t input, int32_t op, uint32_t axes, int32_t keep_dims);
+int32_t trtx_add_identity(trtx_network* n, int32_t input);
+/* addPluginV2: the runtime clones the plugin through vtbl->clone (as TensorRT does) */
+int32_t trtx_add_plugin_v2(trtx_network* n, const int32_t* inputs, int32_t nb_inputs, const trtx_plugin_vtbl* plugin);
+
+/* ILayer / ITensor accessors */
+int32_t trtx_layer_nb_outputs(const trtx_network* n, int32_t layer);
+int32_t trtx_layer_output(const trtx_network* n, int32_t layer, int32_t index); /* tensor id */
+int32_t trtx_layer_set_name(trtx_network* n, int32_t layer, const char* name);
+int32_t trtx_layer_set_ints(trtx_network* n, int32_t layer, int32_t param, const int32_t* v, int32_t count);
+int32_t trtx_layer_set_floats(trtx_network* n, int32_t layer, int32_t param, const float* v, int32_t count);
+int32_t trtx_layer_set_dims(trtx_network* n, int32_t layer, int32_t param, const trtx_dims* d);
+int32_t trtx_tensor_get_dims(const trtx_network* n, int32_t tensor, trtx_dims* out);
+int32_t trtx_tensor_set_name(trtx_network* n, int32_t tensor, const char* name);
+const char* trtx_tensor_get_name(const trtx_network* n, int32_t tensor);
+int32_t trtx_mark_output(trtx_network* n, int32_t tensor);
+
+/* IBuilder::buildSerializedNetwork -> IHostMemory.  Works without a GPU (pure host work). */
+int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_hostmem** out);
+const void* trtx_hostmem_data(const trtx_hostmem* m);
+size_t trtx_hostmem_size(const trtx_hostmem* m);
+void trtx_hostmem_destroy(trtx_hostmem* m);
+/* JSON description of a serialized plan: network definition with weight offsets into the plan
+ * (used by the test oracle's graph interpreter) and, with lowered != 0, the fused kernel schedule,
+ * buffer plan and FLOP/byte counts the engine would execute.  Caller frees with trtx_string_free. */
+int32_t trtx_plan_describe(const void* plan, size_t size, int32_t lowered, char** json_out);
+void trtx_string_free(char* s);
+
+/* --- IRuntime / ICudaEngine / IExecutionContext ---------------------------------------------------- */
+/* deserializeCudaEngine: needs a gfx950 device (TRTX_ERR_NO_DEVICE otherwise — no CPU fallback) */
+int32_t trtx_engine_deserialize(const void* plan, size_t size, trtx_engine** out);
+int32_t trtx_engine_serialize(const trtx_engine* e, trtx_hostmem** out);
+void trtx_engine_destroy(trtx_engine* e);
+int32_t trtx_engine_nb_bindings(const trtx_engine* e);
+int32_t trtx_engine_binding_index(const trtx_engine* e, const char* name);
+const char* trtx_engine_binding_name(const trtx_engine* e, int32_t index);
+int32_t trtx_engine_binding_is_input(const trtx_engine* e, int32_t index);
+int32_t trtx_engine_binding_dims(const trtx_engine* e, int32_t index, trtx_dims* out);
+int32_t trtx_engine_binding_dtype(const trtx_engine* e, int32_t index);
+int32_t trtx_engine_max_batch(const trtx_engine* e);
+size_t trtx_engine_device_memory(const trtx_engine* e);
+int32_t trtx_context_create(trtx_engine* e, trtx_context** out);
+void trtx_context_destroy(trtx_context* c);
+/* IExecutionContext::enqueue(batch, bindings, stream, nullptr) — implicit batch */
+int32_t trtx_context_enqueue(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream);
+/* setTensorAddress + enqueueV3 — explicit batch */
+int32_t trtx_context_set_tensor_address(trtx_context* c, const char* name, void* ptr);
+int32_t trtx_context_enqueue_v3(trtx_context* c, trtx_stream_t stream);
+/* per-kernel timing of the last profiled enqueue (IProfiler::reportLayerTime analogue):
+ * runs one enqueue with hipEvents around every launch and returns JSON [{name, kind, ms}, ...] */
+int32_t trtx_context_profile(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream,
+                             char** json_out);
+
 #ifdef __cplusplus
 }
 #endif

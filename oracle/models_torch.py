@@ -1,0 +1,220 @@
+"""ORACLE (test infrastructure): PyTorch-CPU fp32 restatements of the reference network builders,
+layer by layer, loading the same seeded synthetic `.wts` the MI355X engine loads.
+
+  LeNet-5     lenet/gen_wts.py:10-45  <->  lenet/lenet.cpp:36-155
+  ResNet-50   resnet/resnet50.cpp:77-229  (BN eps 1e-5, stride on the 3x3, relu(conv3 + shortcut))
+  YOLOv8n-det yolov8/src/block.cpp:45-257 + yolov8/src/model.cpp:9-25,98-310 (BN eps 1e-3, SiLU, C2F, SPPF,
+              DFL = softmax(16) . arange via 1x1 conv); output = the three [B, 4+nc, g] plugin inputs.
+
+Each model is a function over a `Params` provider: in "init" mode the provider creates seeded weights of
+the shapes the forward pass asks for (that is how the synthetic .wts is generated); in "load" mode it
+returns the tensors read back from a .wts file.  Real trained weights cannot be obtained offline, so the
+weights are He-scaled random with near-identity BatchNorm statistics.
+
+Parity status: parity unpinned (the reference ships no weights, goldens or tests).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class Params:
+    """name -> tensor provider.  init mode: creates + records; load mode: looks up (and checks shapes)."""
+
+    def __init__(self, tensors=None, seed=0):
+        self.load = tensors is not None
+        self.t = OrderedDict()
+        self.src = tensors
+        self.g = torch.Generator().manual_seed(seed)
+
+    def _get(self, name, shape, init):
+        if self.load:
+            v = torch.as_tensor(np.asarray(self.src[name], dtype=np.float32)).reshape(shape)
+        else:
+            v = init().float()
+        self.t[name] = v
+        return v
+
+    def randn(self, *shape):
+        return torch.randn(*shape, generator=self.g)
+
+    def rand(self, *shape):
+        return torch.rand(*shape, generator=self.g)
+
+    def conv_w(self, name, cout, cin, k, gain=2.0):
+        fan = cin * k * k
+        return self._get(name, (cout, cin, k, k), lambda: self.randn(cout, cin, k, k) * math.sqrt(gain / fan))
+
+    def vec(self, name, n, init):
+        return self._get(name, (n,), init)
+
+    def bn(self, prefix, c):
+        w = self.vec(prefix + ".weight", c, lambda: 0.9 + 0.2 * self.rand(c))
+        b = self.vec(prefix + ".bias", c, lambda: 0.1 * self.randn(c))
+        m = self.vec(prefix + ".running_mean", c, lambda: 0.1 * self.randn(c))
+        v = self.vec(prefix + ".running_var", c, lambda: 0.8 + 0.4 * self.rand(c))
+        # exporters also dump num_batches_tracked (a 0-dim tensor -> 1 value); keep it for format fidelity
+        self._get(prefix + ".num_batches_tracked", (1,), lambda: torch.zeros(1))
+        return w, b, m, v
+
+
+# --------------------------------------------------------------------------------------------- LeNet-5
+def lenet(p: Params, x):
+    """lenet/gen_wts.py:26-45 (max pooling; softmax appended as in lenet.cpp:133-137)."""
+    y = F.conv2d(x, p._get("conv1.weight", (6, 1, 5, 5), lambda: p.randn(6, 1, 5, 5) * 0.2),
+                 p.vec("conv1.bias", 6, lambda: 0.1 * p.randn(6)))
+    y = F.max_pool2d(F.relu(y), 2, 2)
+    y = F.conv2d(y, p._get("conv2.weight", (16, 6, 5, 5), lambda: p.randn(16, 6, 5, 5) * 0.08),
+                 p.vec("conv2.bias", 16, lambda: 0.1 * p.randn(16)))
+    y = F.max_pool2d(F.relu(y), 2, 2)
+    y = y.reshape(y.shape[0], -1)
+    for name, o, i, relu in (("fc1", 120, 400, True), ("fc2", 84, 120, True), ("fc3", 10, 84, False)):
+        w = p._get(name + ".weight", (o, i), lambda o=o, i=i: p.randn(o, i) * math.sqrt(2.0 / i))
+        b = p.vec(name + ".bias", o, lambda o=o: 0.1 * p.randn(o))
+        y = F.linear(y, w, b)
+        if relu:
+            y = F.relu(y)
+    return F.softmax(y, dim=1)
+
+
+# ------------------------------------------------------------------------------------------- ResNet-50
+def _bn_eval(x, stats, eps):
+    w, b, m, v = stats
+    return F.batch_norm(x, m, v, w, b, training=False, eps=eps)
+
+
+def resnet50(p: Params, x):
+    """resnet/resnet50.cpp:155-229; returns the FC-1000 logits [B, 1000] (no softmax, as the reference)."""
+    eps = 1e-5
+
+    def conv_bn(x, cname, bname, cout, k, s, pad):
+        cin = x.shape[1]
+        y = F.conv2d(x, p.conv_w(cname + ".weight", cout, cin, k), None, stride=s, padding=pad)
+        return _bn_eval(y, p.bn(bname, cout), eps)
+
+    def bottleneck(x, inch, outch, stride, l):
+        a = F.relu(conv_bn(x, l + "conv1", l + "bn1", outch, 1, 1, 0))
+        b = F.relu(conv_bn(a, l + "conv2", l + "bn2", outch, 3, stride, 1))
+        c = conv_bn(b, l + "conv3", l + "bn3", outch * 4, 1, 1, 0)
+        sc = x
+        if stride != 1 or inch != outch * 4:
+            sc = conv_bn(x, l + "downsample.0", l + "downsample.1", outch * 4, 1, stride, 0)
+        return F.relu(sc + c)
+
+    y = F.relu(conv_bn(x, "conv1", "bn1", 64, 7, 2, 3))
+    y = F.max_pool2d(y, 3, 2, 1)
+    inch = 64
+    for stage, nblk in enumerate((3, 4, 6, 3)):
+        width = 64 << stage
+        for b in range(nblk):
+            stride = 2 if (b == 0 and stage > 0) else 1
+            y = bottleneck(y, inch, width, stride, f"layer{stage + 1}.{b}.")
+            inch = width * 4
+    y = F.avg_pool2d(y, y.shape[-1], 1).flatten(1)
+    w = p._get("fc.weight", (1000, 2048), lambda: p.randn(1000, 2048) * math.sqrt(1.0 / 2048))
+    b = p.vec("fc.bias", 1000, lambda: 0.1 * p.randn(1000))
+    return F.linear(y, w, b)
+
+
+# ------------------------------------------------------------------------------------------ YOLOv8-det
+def _get_width(x, gw, max_channels, divisor=8):  # model.cpp:13-16
+    ch = int(math.ceil((x * gw) / divisor)) * divisor
+    return max_channels if ch >= max_channels else ch
+
+
+def _get_depth(x, gd):  # model.cpp:18-25
+    if x == 1:
+        return 1
+    r = int(math.floor(x * gd + 0.5))  # C round(): half away from zero
+    if x * gd - int(x * gd) == 0.5 and int(x * gd) % 2 == 0:
+        r -= 1
+    return max(r, 1)
+
+
+def yolov8_det(p: Params, x, num_class=80, gd=0.33, gw=0.25, max_channels=1024, cls_bias=-7.0, cls_gain=80.0):
+    """Returns ([B, 4+nc, g] for stride 8/16/32, strides) — exactly what feeds YoloLayer_TRT."""
+    eps = 1e-3
+
+    def cbs(x, name, cout, k, s, pad):  # convBnSiLU, block.cpp:79-96
+        y = F.conv2d(x, p.conv_w(name + ".conv.weight", cout, x.shape[1], k), None, stride=s, padding=pad)
+        y = _bn_eval(y, p.bn(name + ".bn", cout), eps)
+        return y * torch.sigmoid(y)
+
+    def bottleneck(x, c1, c2, shortcut, name):  # block.cpp:98-110
+        y = cbs(cbs(x, name + ".cv1", c2, 3, 1, 1), name + ".cv2", c2, 3, 1, 1)
+        return x + y if (shortcut and c1 == c2) else y
+
+    def c2f(x, c2, n, shortcut, name, e=0.5):  # block.cpp:126-155
+        c_ = int(float(c2) * e)
+        y = cbs(x, name + ".cv1", 2 * c_, 1, 1, 0)
+        parts = [y[:, :c_], y[:, c_:]]
+        cur = parts[1]
+        for i in range(n):
+            cur = bottleneck(cur, c_, c_, shortcut, f"{name}.m.{i}")
+            parts.append(cur)
+        return cbs(torch.cat(parts, 1), name + ".cv2", c2, 1, 1, 0)
+
+    def sppf(x, c1, c2, k, name):  # block.cpp:214-237
+        y = cbs(x, name + ".cv1", c1 // 2, 1, 1, 0)
+        ps = [y]
+        for _ in range(3):
+            ps.append(F.max_pool2d(ps[-1], k, 1, k // 2))
+        return cbs(torch.cat(ps, 1), name + ".cv2", c2, 1, 1, 0)
+
+    def up(x):
+        return F.interpolate(x, scale_factor=2, mode="nearest")
+
+    W = lambda v: _get_width(v, gw, max_channels)  # noqa: E731
+    H_in, W_in = x.shape[2], x.shape[3]
+    p1 = cbs(x, "model.0", W(64), 3, 2, 1)
+    p2 = cbs(p1, "model.1", W(128), 3, 2, 1)
+    c2 = c2f(p2, W(128), _get_depth(3, gd), True, "model.2")
+    p3 = cbs(c2, "model.3", W(256), 3, 2, 1)
+    c4 = c2f(p3, W(256), _get_depth(6, gd), True, "model.4")
+    p4 = cbs(c4, "model.5", W(512), 3, 2, 1)
+    c6 = c2f(p4, W(512), _get_depth(6, gd), True, "model.6")
+    p5 = cbs(c6, "model.7", W(1024), 3, 2, 1)
+    c8 = c2f(p5, W(1024), _get_depth(3, gd), True, "model.8")
+    c9 = sppf(c8, W(1024), W(1024), 5, "model.9")
+    c12 = c2f(torch.cat([up(c9), c6], 1), W(512), _get_depth(3, gd), False, "model.12")
+    c15 = c2f(torch.cat([up(c12), c4], 1), W(256), _get_depth(3, gd), False, "model.15")
+    c16 = cbs(c15, "model.16", W(256), 3, 2, 1)
+    c18 = c2f(torch.cat([c16, c12], 1), W(512), _get_depth(3, gd), False, "model.18")
+    c19 = cbs(c18, "model.19", W(512), 3, 2, 1)
+    c21 = c2f(torch.cat([c19, c9], 1), W(1024), _get_depth(3, gd), False, "model.21")
+
+    base_in = 80 if gw == 1.25 else 64
+    base_out = max(64, min(num_class, 100)) if gw == 0.25 else W(256)
+    strides = [H_in // t.shape[2] for t in (p3, p4, p5)]
+    outs = []
+    dfl_w = None
+    for lv, feat in enumerate((c15, c18, c21)):
+        s = str(lv)
+        b = cbs(cbs(feat, f"model.22.cv2.{s}.0", base_in, 3, 1, 1), f"model.22.cv2.{s}.1", base_in, 3, 1, 1)
+        box = F.conv2d(b, p.conv_w(f"model.22.cv2.{s}.2.weight", 64, base_in, 1, gain=4.0),
+                       p.vec(f"model.22.cv2.{s}.2.bias", 64, lambda: 1.0 + 0.1 * p.randn(64)))
+        k = cbs(cbs(feat, f"model.22.cv3.{s}.0", base_out, 3, 1, 1), f"model.22.cv3.{s}.1", base_out, 3, 1, 1)
+        cls = F.conv2d(k, p.conv_w(f"model.22.cv3.{s}.2.weight", num_class, base_out, 1, gain=cls_gain),
+                       p.vec(f"model.22.cv3.{s}.2.bias", num_class, lambda: cls_bias + 0.1 * p.randn(num_class)))
+        cat = torch.cat([box, cls], 1)
+        g = cat.shape[2] * cat.shape[3]
+        flat = cat.reshape(cat.shape[0], 64 + num_class, g)
+        boxp, clsp = flat[:, :64], flat[:, 64:]
+        if dfl_w is None:
+            dfl_w = p._get("model.22.dfl.conv.weight", (1, 16, 1, 1), lambda: torch.arange(16.0).reshape(1, 16, 1, 1))
+        # DFL, block.cpp:239-257: (64,g)->(4,16,g)->(16,4,g) softmax over the 16 bins, 1x1 conv(arange)
+        t = boxp.reshape(-1, 4, 16, g).permute(0, 2, 1, 3)
+        t = F.conv2d(F.softmax(t, dim=1), dfl_w).reshape(-1, 4, g)
+        outs.append(torch.cat([t, clsp], 1).contiguous())
+    return outs, strides
+
+
+def make_weights(model_fn, example_input, seed=0, **kw):
+    """Run `model_fn` in init mode on `example_input`; returns (OrderedDict name -> tensor, output)."""
+    p = Params(None, seed)
+    with torch.inference_mode():
+        out = model_fn(p, example_input, **kw)
+    return p.t, out

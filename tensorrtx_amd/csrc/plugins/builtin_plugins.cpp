@@ -1,0 +1,185 @@
+// Built-in HIP plugins, registered under the names the reference host code asks the registry for.
+//   "YoloLayer_TRT"/"1"  — yolov8/plugin/yololayer.{h,cu} (creator: yololayer.cu:320-369)
+// Each plugin is a small host object exposed through the C v-table of include/trtx_hip.h; its
+// enqueue calls the HIP operator entry points of section 1.  Serialization blobs keep the reference's
+// field order so a plan round-trips byte for byte.
+#include <string.h>
+
+#include <vector>
+
+#include "../common.h"
+#include "../runtime/plugin.h"
+
+namespace trtx {
+namespace {
+
+template <typename T>
+void put(std::vector<uint8_t>& b, const T& v) {
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(&v);
+    b.insert(b.end(), p, p + sizeof(T));
+}
+template <typename T>
+bool get(const uint8_t*& p, const uint8_t* end, T& v) {
+    if (p + sizeof(T) > end) return false;
+    memcpy(&v, p, sizeof(T));
+    p += sizeof(T);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct YoloLayer {
+    int class_count = 80, n_kpt = 17;
+    float kpt_conf = 0.f;
+    int thread_count = 256, net_w = 640, net_h = 640, max_out = 1000;
+    std::vector<int> strides;
+    bool seg = false, pose = false, obb = false;
+    int max_batch = 1;
+
+    std::vector<uint8_t> blob() const {  // yololayer.cu:75-101
+        std::vector<uint8_t> b;
+        put(b, class_count);
+        put(b, n_kpt);
+        put(b, kpt_conf);
+        put(b, thread_count);
+        put(b, net_w);
+        put(b, net_h);
+        put(b, max_out);
+        put(b, (int)strides.size());
+        for (int s : strides) put(b, s);
+        put(b, seg);
+        put(b, pose);
+        put(b, obb);
+        return b;
+    }
+    static YoloLayer* from_blob(const void* data, size_t len) {  // yololayer.cu:53-73
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        const uint8_t* end = p + len;
+        auto* y = new YoloLayer();
+        int ns = 0;
+        bool ok = get(p, end, y->class_count) && get(p, end, y->n_kpt) && get(p, end, y->kpt_conf) &&
+                  get(p, end, y->thread_count) && get(p, end, y->net_w) && get(p, end, y->net_h) &&
+                  get(p, end, y->max_out) && get(p, end, ns) && ns >= 0 && ns <= 8;
+        for (int i = 0; ok && i < ns; ++i) {
+            int s = 0;
+            ok = get(p, end, s);
+            y->strides.push_back(s);
+        }
+        ok = ok && get(p, end, y->seg) && get(p, end, y->pose) && get(p, end, y->obb) && p == end;
+        if (!ok) {
+            delete y;
+            return nullptr;
+        }
+        return y;
+    }
+};
+
+void yolo_fill(trtx_plugin_vtbl* v, YoloLayer* y);
+
+int32_t yolo_nb_outputs(void*) { return 1; }
+int32_t yolo_output_dims(void* s, int32_t, const trtx_dims*, int32_t, trtx_dims* out) {
+    auto* y = static_cast<YoloLayer*>(s);
+    out->nb = 3;  // Dims3(total_size + 1, 1, 1), yololayer.cu:107-111
+    out->d[0] = (int64_t)y->max_out * kYoloDetFloats + 1;
+    out->d[1] = 1;
+    out->d[2] = 1;
+    return 0;
+}
+int32_t yolo_configure(void* s, const trtx_dims* in, int32_t nb_in, const trtx_dims*, int32_t, int32_t max_batch) {
+    auto* y = static_cast<YoloLayer*>(s);
+    y->max_batch = max_batch;
+    if (nb_in != (int)y->strides.size()) return 1;
+    for (int i = 0; i < nb_in; ++i) {
+        const int64_t cells = (int64_t)(y->net_h / y->strides[i]) * (y->net_w / y->strides[i]);
+        int64_t vol = 1;
+        for (int k = 0; k < in[i].nb; ++k) vol *= in[i].d[k];
+        if (vol != cells * (4 + y->class_count)) return 1;  // det only: [4+classes, cells]
+    }
+    return 0;
+}
+int32_t yolo_initialize(void* s) {
+    auto* y = static_cast<YoloLayer*>(s);
+    return (y->seg || y->pose || y->obb) ? 1 : 0;  // only the det branch is implemented
+}
+void yolo_terminate(void*) {}
+size_t yolo_workspace(void* s, int32_t max_batch) {
+    auto* y = static_cast<YoloLayer*>(s);
+    return trtx_yolo_decode_workspace(max_batch, y->net_h, y->net_w, y->strides.data(), (int)y->strides.size());
+}
+int32_t yolo_enqueue(void* s, int32_t batch, const void* const* inputs, void* const* outputs, void* ws,
+                     trtx_stream_t stream) {
+    auto* y = static_cast<YoloLayer*>(s);
+    const size_t ws_bytes =
+            trtx_yolo_decode_workspace(batch, y->net_h, y->net_w, y->strides.data(), (int)y->strides.size());
+    return trtx_yolo_decode(reinterpret_cast<const float* const*>(inputs), (int)y->strides.size(), batch,
+                            y->class_count, y->net_h, y->net_w, y->strides.data(), y->max_out,
+                            static_cast<float*>(outputs[0]), ws, ws_bytes, stream);
+}
+size_t yolo_ser_size(void* s) { return static_cast<YoloLayer*>(s)->blob().size(); }
+void yolo_serialize(void* s, void* buf) {
+    const auto b = static_cast<YoloLayer*>(s)->blob();
+    memcpy(buf, b.data(), b.size());
+}
+const char* yolo_type(void*) { return "YoloLayer_TRT"; }
+const char* yolo_version(void*) { return "1"; }
+int32_t yolo_clone(void* s, trtx_plugin_vtbl* out) {
+    yolo_fill(out, new YoloLayer(*static_cast<YoloLayer*>(s)));
+    return 0;
+}
+void yolo_destroy(void* s) { delete static_cast<YoloLayer*>(s); }
+
+void yolo_fill(trtx_plugin_vtbl* v, YoloLayer* y) {
+    v->self = y;
+    v->get_nb_outputs = yolo_nb_outputs;
+    v->get_output_dims = yolo_output_dims;
+    v->configure = yolo_configure;
+    v->initialize = yolo_initialize;
+    v->terminate = yolo_terminate;
+    v->workspace_size = yolo_workspace;
+    v->enqueue = yolo_enqueue;
+    v->serialization_size = yolo_ser_size;
+    v->serialize = yolo_serialize;
+    v->plugin_type = yolo_type;
+    v->plugin_version = yolo_version;
+    v->clone = yolo_clone;
+    v->destroy = yolo_destroy;
+}
+
+// creator: one field "combinedInfo" = int32[9 + nStrides] (yolov8/src/block.cpp:267-293, yololayer.cu:339-360)
+int32_t yolo_create(void*, const char*, const trtx_plugin_field* f, int32_t nb, trtx_plugin_vtbl* out) {
+    if (nb != 1 || !f || !f[0].name || strcmp(f[0].name, "combinedInfo") != 0 || f[0].length < 10) return 1;
+    const int* ci = static_cast<const int*>(f[0].data);
+    auto* y = new YoloLayer();
+    y->class_count = ci[0];
+    y->n_kpt = ci[1];
+    y->kpt_conf = (float)ci[2];
+    y->net_w = ci[3];
+    y->net_h = ci[4];
+    y->max_out = ci[5];
+    y->seg = ci[6] != 0;
+    y->pose = ci[7] != 0;
+    y->obb = ci[8] != 0;
+    y->strides.assign(ci + 9, ci + f[0].length);
+    yolo_fill(out, y);
+    return 0;
+}
+int32_t yolo_deserialize(void*, const char*, const void* data, size_t len, trtx_plugin_vtbl* out) {
+    YoloLayer* y = YoloLayer::from_blob(data, len);
+    if (!y) return 1;
+    yolo_fill(out, y);
+    return 0;
+}
+const char* yolo_creator_name(void*) { return "YoloLayer_TRT"; }
+const char* yolo_creator_version(void*) { return "1"; }
+
+}  // namespace
+
+void register_builtin_plugins(PluginRegistry& r) {
+    trtx_creator_vtbl c{};
+    c.plugin_name = yolo_creator_name;
+    c.plugin_version = yolo_creator_version;
+    c.create = yolo_create;
+    c.deserialize = yolo_deserialize;
+    r.add(c);
+}
+
+}  // namespace trtx

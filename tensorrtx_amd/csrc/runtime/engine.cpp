@@ -1,0 +1,419 @@
+#include "engine.h"
+
+#include <string.h>
+
+#include <sstream>
+
+#include "../common.h"
+
+using namespace trtx;
+
+trtx_engine::~trtx_engine() {
+    if (plugins_initialized)
+        for (auto& op : plan.ops)
+            if (op.kind == OP_PLUGIN && op.plugin->v.terminate) op.plugin->v.terminate(op.plugin->v.self);
+    if (d_weights) (void)hipFree(d_weights);
+}
+
+trtx_context::~trtx_context() {
+    if (d_arena) (void)hipFree(d_arena);
+}
+
+namespace trtx {
+
+namespace {
+
+struct Resolver {
+    const Plan& plan;
+    char* arena;
+    char* weights;
+    void* const* bindings;
+    char* base(const PTensor& t) const {
+        const Storage& s = plan.storages[t.storage];
+        switch (s.kind) {
+            case ST_ARENA: return arena + s.offset;
+            case ST_WEIGHTS: return weights + s.offset;
+            default: return static_cast<char*>(bindings[s.binding]);
+        }
+    }
+    void* ptr(int tid) const {
+        const PTensor& t = plan.tensors[tid];
+        const size_t es = t.dtype == DT_F16 ? 2 : 4;
+        return base(t) + (t.layout == LAY_NHWC ? (size_t)t.rcoff : (size_t)t.reoff) * es;
+    }
+};
+
+// add the runtime batch as outermost dimension of a per-sample strided view
+StridedView batch_view(const StridedView& v, int batch, long bs_in, long bs_in2) {
+    StridedView o{};
+    o.rank = v.rank + 1;
+    o.shape[0] = batch;
+    o.stride_in[0] = bs_in;
+    o.stride_in2[0] = bs_in2;
+    for (int d = 0; d < v.rank; ++d) {
+        o.shape[d + 1] = v.shape[d];
+        o.stride_in[d + 1] = v.stride_in[d];
+        o.stride_in2[d + 1] = v.stride_in2[d];
+    }
+    return o;
+}
+
+}  // namespace
+
+int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStream_t stream,
+                     std::vector<OpTiming>* prof) {
+    trtx_engine* e = c->engine;
+    const Plan& plan = e->plan;
+    if (batch < 1 || batch > plan.max_batch) {
+        fprintf(stderr, "[trtx_hip] enqueue: batch %d outside [1, %d]\n", batch, plan.max_batch);
+        return TRTX_ERR_INVALID;
+    }
+    for (size_t b = 0; b < plan.binding_tensor.size(); ++b)
+        if (!bindings[b]) {
+            fprintf(stderr, "[trtx_hip] enqueue: binding %zu is null\n", b);
+            return TRTX_ERR_INVALID;
+        }
+    Resolver R{plan, static_cast<char*>(c->d_arena), static_cast<char*>(e->d_weights), bindings};
+    char* W = static_cast<char*>(e->d_weights);
+    std::vector<hipEvent_t> evs;
+    if (prof) {
+        evs.resize(plan.ops.size() + 1);
+        for (auto& ev : evs) TRTX_HIP_TRY(hipEventCreate(&ev));
+        TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
+    }
+    for (size_t k = 0; k < plan.ops.size(); ++k) {
+        const POp& op = plan.ops[k];
+        const PTensor& t0 = plan.tensors[op.in.empty() ? op.out[0] : op.in[0]];
+        const PTensor& to = plan.tensors[op.out[0]];
+        auto nb = [&](const PTensor& t) { return t.nfix ? t.nfix : batch; };
+        int32_t st = TRTX_OK;
+        switch (op.kind) {
+            case OP_CONV:
+            case OP_DECONV: {
+                ConvArgs a = op.conv;
+                a.in = R.ptr(op.in[0]);
+                a.out = R.ptr(op.out[0]);
+                a.residual = op.in.size() > 1 ? R.ptr(op.in[1]) : nullptr;
+                a.wgt = W + op.w_off;
+                a.bias = reinterpret_cast<const float*>(W + op.b_off);
+                a.N = nb(t0);
+                a.M = a.N * a.Ho * a.Wo;
+                if (op.kind == OP_DECONV)
+                    st = deconv_direct(a, op.dtype, stream);
+                else if (op.igemm)
+                    st = conv_igemm_f16(a, stream);
+                else
+                    st = conv_direct(a, op.dtype, stream);
+                break;
+            }
+            case OP_POOL:
+                st = nhwc_pool(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, op.i[0], nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
+                               to.W, to.ld, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], stream);
+                break;
+            case OP_RESIZE:
+                st = nhwc_resize_nearest(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
+                                         to.W, to.ld, stream);
+                break;
+            case OP_EW_NHWC: {
+                const PTensor& t1 = plan.tensors[op.in[1]];
+                st = nhwc_elementwise(R.ptr(op.in[0]), R.ptr(op.in[1]), R.ptr(op.out[0]), op.dtype, op.i[0],
+                                      (long)nb(t0) * t0.H * t0.W, t0.C, t0.ld, t1.ld, to.ld, stream);
+                break;
+            }
+            case OP_ACT_NHWC:
+                st = nhwc_activation(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, op.i[0], op.f[0],
+                                     (long)nb(t0) * t0.H * t0.W, t0.C, t0.ld, to.ld, stream);
+                break;
+            case OP_SCALE_NHWC:
+                st = nhwc_scale(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, reinterpret_cast<const float*>(W + op.s_off),
+                                reinterpret_cast<const float*>(W + op.b_off), (long)nb(t0) * t0.H * t0.W, t0.C, t0.ld,
+                                to.ld, stream);
+                break;
+            case OP_COPY_NHWC:
+                st = nhwc_copy(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, (long)nb(t0) * t0.H * t0.W, t0.C, t0.ld, to.ld,
+                               stream);
+                break;
+            case OP_REDUCE_HW:
+                st = nhwc_reduce_hw_avg(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, nb(t0), t0.H * t0.W, t0.C, t0.ld, to.ld,
+                                        stream);
+                break;
+            case OP_TO_NHWC:
+                st = nchw_f32_to_nhwc(static_cast<const float*>(R.ptr(op.in[0])), R.ptr(op.out[0]), to.dtype, nb(to), to.C,
+                                      to.H, to.W, to.Calloc ? to.Calloc : to.C, to.ld, stream);
+                break;
+            case OP_TO_LINEAR:
+                st = nhwc_to_nchw_f32(R.ptr(op.in[0]), t0.dtype, static_cast<float*>(R.ptr(op.out[0])), nb(t0), t0.C, t0.H,
+                                      t0.W, t0.ld, stream);
+                break;
+            case OP_GATHER: {
+                const float* src = static_cast<const float*>(R.ptr(op.in[0])) + op.off0;
+                const StridedView v = to.batched ? batch_view(op.view, batch, t0.batched ? t0.dims.volume() : 0, 0) : op.view;
+                st = lin_gather(src, static_cast<float*>(R.ptr(op.out[0])), v, stream);
+                break;
+            }
+            case OP_SCATTER: {
+                float* dst = static_cast<float*>(R.ptr(op.out[0])) + op.off0;
+                // dense source per sample; destination strided with the output's sample stride
+                StridedView v = op.view;
+                if (to.batched) {
+                    if (!t0.batched) {
+                        // broadcast an unbatched source into every sample: one launch per sample
+                        for (int b = 0; b < batch && st == TRTX_OK; ++b)
+                            st = lin_scatter(static_cast<const float*>(R.ptr(op.in[0])), dst + (long)b * to.dims.volume(), v,
+                                             stream);
+                        break;
+                    }
+                    v = batch_view(op.view, batch, to.dims.volume(), 0);
+                }
+                st = lin_scatter(static_cast<const float*>(R.ptr(op.in[0])), dst, v, stream);
+                break;
+            }
+            case OP_EW_LIN: {
+                const PTensor& t1 = plan.tensors[op.in[1]];
+                const StridedView v = to.batched ? batch_view(op.view, batch, t0.batched ? t0.dims.volume() : 0,
+                                                              t1.batched ? t1.dims.volume() : 0)
+                                                 : op.view;
+                st = lin_elementwise(static_cast<const float*>(R.ptr(op.in[0])), static_cast<const float*>(R.ptr(op.in[1])),
+                                     static_cast<float*>(R.ptr(op.out[0])), op.i[0], v, stream);
+                break;
+            }
+            case OP_ACT_LIN:
+                st = lin_activation(static_cast<const float*>(R.ptr(op.in[0])), static_cast<float*>(R.ptr(op.out[0])), op.i[0],
+                                    op.f[0], (long)(to.batched ? batch : 1) * to.dims.volume(), stream);
+                break;
+            case OP_SCALE_LIN: {
+                const long bmul = to.batched ? batch : 1;
+                st = lin_scale(static_cast<const float*>(R.ptr(op.in[0])), static_cast<float*>(R.ptr(op.out[0])),
+                               reinterpret_cast<const float*>(W + op.s_off), reinterpret_cast<const float*>(W + op.b_off),
+                               reinterpret_cast<const float*>(W + op.w_off), op.i[0], bmul * op.i[1], op.i[2], op.i[3],
+                               stream);
+                break;
+            }
+            case OP_SOFTMAX:
+                st = lin_softmax(static_cast<const float*>(R.ptr(op.in[0])), static_cast<float*>(R.ptr(op.out[0])),
+                                 (long)(to.batched ? batch : 1) * op.i[0], op.i[1], op.i[2], stream);
+                break;
+            case OP_MATMUL: {
+                const PTensor& t1 = plan.tensors[op.in[1]];
+                st = lin_matmul(static_cast<const float*>(R.ptr(op.in[0])), static_cast<const float*>(R.ptr(op.in[1])),
+                                static_cast<float*>(R.ptr(op.out[0])), to.batched ? batch : 1, op.i[0], op.i[1], op.i[2],
+                                op.i[3], op.i[4], t0.batched ? t0.dims.volume() : 0, t1.batched ? t1.dims.volume() : 0,
+                                stream);
+                break;
+            }
+            case OP_REDUCE_LIN:
+                st = lin_reduce(static_cast<const float*>(R.ptr(op.in[0])), static_cast<float*>(R.ptr(op.out[0])), op.i[0],
+                                (long)(to.batched ? batch : 1) * op.i[1], op.i[2], op.i[3], stream);
+                break;
+            case OP_PLUGIN: {
+                std::vector<const void*> ins;
+                std::vector<void*> outs;
+                for (int t : op.in) ins.push_back(R.ptr(t));
+                for (int t : op.out) outs.push_back(R.ptr(t));
+                void* ws = op.ws_bytes ? static_cast<char*>(c->d_arena) + op.ws_off : nullptr;
+                const int rc = op.plugin->v.enqueue(op.plugin->v.self, batch, ins.data(), outs.data(), ws, stream);
+                if (rc != 0) {
+                    fprintf(stderr, "[trtx_hip] plugin %s enqueue returned %d\n", op.name.c_str(), rc);
+                    st = TRTX_ERR_HIP;
+                }
+                break;
+            }
+            case OP_COPY_LIN: {
+                const size_t bytes = (size_t)(to.batched ? batch : 1) * to.dims.volume() * 4;
+                if (hipMemcpyAsync(R.ptr(op.out[0]), R.ptr(op.in[0]), bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                    st = TRTX_ERR_HIP;
+                break;
+            }
+            default:
+                st = TRTX_ERR_UNSUPPORTED;
+        }
+        if (st != TRTX_OK) {
+            fprintf(stderr, "[trtx_hip] op %zu (%s, %s) failed: %s\n", k, op_kind_name(op.kind), op.name.c_str(),
+                    trtx_status_string(st));
+            return st;
+        }
+        if (prof) TRTX_HIP_TRY(hipEventRecord(evs[k + 1], stream));
+    }
+    if (prof) {
+        TRTX_HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evs[k], evs[k + 1]);
+            prof->push_back({plan.ops[k].name, op_kind_name(plan.ops[k].kind), ms});
+        }
+        for (auto& ev : evs) (void)hipEventDestroy(ev);
+    }
+    return TRTX_OK;
+}
+
+}  // namespace trtx
+
+// ---------------------------------------------------------------------------------------------------------
+struct trtx_hostmem {
+    std::vector<uint8_t> data;
+};
+
+extern "C" const void* trtx_hostmem_data(const trtx_hostmem* m) { return m ? m->data.data() : nullptr; }
+extern "C" size_t trtx_hostmem_size(const trtx_hostmem* m) { return m ? m->data.size() : 0; }
+extern "C" void trtx_hostmem_destroy(trtx_hostmem* m) { delete m; }
+trtx_hostmem* trtx_hostmem_from(std::vector<uint8_t>&& v) {
+    auto* m = new trtx_hostmem();
+    m->data = std::move(v);
+    return m;
+}
+
+extern "C" void trtx_string_free(char* s) { free(s); }
+
+extern "C" int32_t trtx_plan_describe(const void* plan_data, size_t size, int32_t lowered, char** json_out) {
+    if (!plan_data || !json_out) return TRTX_ERR_INVALID;
+    std::string err;
+    auto net = Network::deserialize(static_cast<const uint8_t*>(plan_data), size, &err);
+    if (!net) {
+        fprintf(stderr, "[trtx_hip] trtx_plan_describe: %s\n", err.c_str());
+        return TRTX_ERR_IO;
+    }
+    std::string js;
+    if (!lowered) {
+        js = net->describe_json();
+    } else {
+        Plan plan;
+        if (!lower_network(*net, &plan)) {
+            fprintf(stderr, "[trtx_hip] lowering failed: %s\n", plan.error.c_str());
+            return TRTX_ERR_UNSUPPORTED;
+        }
+        pack_weights(*net, &plan);
+        js = plan.describe_json();
+    }
+    *json_out = strdup(js.c_str());
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, trtx_engine** out) {
+    if (!plan_data || !out) return TRTX_ERR_INVALID;
+    if (trtx_device_count() < 1) {
+        fprintf(stderr, "[trtx_hip] no HIP device: engines only run on the GPU (there is no CPU fallback)\n");
+        return TRTX_ERR_NO_DEVICE;
+    }
+    std::string err;
+    std::unique_ptr<trtx_engine> e(new trtx_engine());
+    e->net = Network::deserialize(static_cast<const uint8_t*>(plan_data), size, &err);
+    if (!e->net) {
+        fprintf(stderr, "[trtx_hip] deserializeCudaEngine: %s\n", err.c_str());
+        return TRTX_ERR_IO;
+    }
+    e->blob.assign(static_cast<const uint8_t*>(plan_data), static_cast<const uint8_t*>(plan_data) + size);
+    if (!lower_network(*e->net, &e->plan)) {
+        fprintf(stderr, "[trtx_hip] lowering failed: %s\n", e->plan.error.c_str());
+        return TRTX_ERR_UNSUPPORTED;
+    }
+    pack_weights(*e->net, &e->plan);
+    if (e->plan.weight_bytes) {
+        TRTX_HIP_TRY(hipMalloc(&e->d_weights, e->plan.weight_bytes));
+        TRTX_HIP_TRY(hipMemcpy(e->d_weights, e->plan.weight_blob.data(), e->plan.weight_bytes, hipMemcpyHostToDevice));
+    }
+    e->plan.weight_blob.clear();
+    e->plan.weight_blob.shrink_to_fit();
+    for (auto& op : e->plan.ops)
+        if (op.kind == OP_PLUGIN && op.plugin->v.initialize && op.plugin->v.initialize(op.plugin->v.self) != 0) {
+            fprintf(stderr, "[trtx_hip] plugin %s: initialize() failed\n", op.name.c_str());
+            return TRTX_ERR_UNSUPPORTED;
+        }
+    e->plugins_initialized = true;
+    *out = e.release();
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_engine_serialize(const trtx_engine* e, trtx_hostmem** out) {
+    if (!e || !out) return TRTX_ERR_INVALID;
+    std::vector<uint8_t> copy = e->blob;
+    *out = trtx_hostmem_from(std::move(copy));
+    return TRTX_OK;
+}
+
+extern "C" void trtx_engine_destroy(trtx_engine* e) { delete e; }
+
+extern "C" int32_t trtx_engine_nb_bindings(const trtx_engine* e) { return e ? (int32_t)e->plan.binding_tensor.size() : 0; }
+
+extern "C" const char* trtx_engine_binding_name(const trtx_engine* e, int32_t i) {
+    if (!e || i < 0 || i >= (int32_t)e->plan.binding_tensor.size()) return nullptr;
+    return e->net->tensors[e->plan.binding_tensor[i]].name.c_str();
+}
+
+extern "C" int32_t trtx_engine_binding_index(const trtx_engine* e, const char* name) {
+    if (!e || !name) return -1;
+    for (size_t i = 0; i < e->plan.binding_tensor.size(); ++i)
+        if (e->net->tensors[e->plan.binding_tensor[i]].name == name) return (int32_t)i;
+    return -1;
+}
+
+extern "C" int32_t trtx_engine_binding_is_input(const trtx_engine* e, int32_t i) {
+    if (!e || i < 0 || i >= (int32_t)e->plan.binding_tensor.size()) return 0;
+    return e->plan.binding_is_input[i] ? 1 : 0;
+}
+
+extern "C" int32_t trtx_engine_binding_dims(const trtx_engine* e, int32_t i, trtx_dims* out) {
+    if (!e || !out || i < 0 || i >= (int32_t)e->plan.binding_tensor.size()) return TRTX_ERR_INVALID;
+    *out = to_c(e->net->tensors[e->plan.binding_tensor[i]].dims);
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_engine_binding_dtype(const trtx_engine*, int32_t) { return TRTX_DTYPE_FLOAT; }
+
+extern "C" int32_t trtx_engine_max_batch(const trtx_engine* e) { return e ? e->plan.max_batch : 0; }
+
+extern "C" size_t trtx_engine_device_memory(const trtx_engine* e) {
+    return e ? e->plan.arena_bytes + e->plan.weight_bytes : 0;
+}
+
+extern "C" int32_t trtx_context_create(trtx_engine* e, trtx_context** out) {
+    if (!e || !out) return TRTX_ERR_INVALID;
+    std::unique_ptr<trtx_context> c(new trtx_context());
+    c->engine = e;
+    c->addr.assign(e->plan.binding_tensor.size(), nullptr);
+    if (e->plan.arena_bytes) {
+        TRTX_HIP_TRY(hipMalloc(&c->d_arena, e->plan.arena_bytes));
+        TRTX_HIP_TRY(hipMemset(c->d_arena, 0, e->plan.arena_bytes));
+    }
+    *out = c.release();
+    return TRTX_OK;
+}
+
+extern "C" void trtx_context_destroy(trtx_context* c) { delete c; }
+
+extern "C" int32_t trtx_context_enqueue(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream) {
+    if (!c || !bindings) return TRTX_ERR_INVALID;
+    return execute_plan(c, c->engine->plan.explicit_batch ? 1 : batch, bindings, stream, nullptr);
+}
+
+extern "C" int32_t trtx_context_set_tensor_address(trtx_context* c, const char* name, void* ptr) {
+    if (!c || !name) return TRTX_ERR_INVALID;
+    const int i = trtx_engine_binding_index(c->engine, name);
+    if (i < 0) return TRTX_ERR_INVALID;
+    c->addr[i] = ptr;
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_context_enqueue_v3(trtx_context* c, trtx_stream_t stream) {
+    if (!c) return TRTX_ERR_INVALID;
+    for (void* p : c->addr)
+        if (!p) return TRTX_ERR_STATE;
+    return execute_plan(c, c->engine->plan.explicit_batch ? 1 : c->engine->plan.max_batch, c->addr.data(), stream, nullptr);
+}
+
+extern "C" int32_t trtx_context_profile(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream,
+                                        char** json_out) {
+    if (!c || !bindings || !json_out) return TRTX_ERR_INVALID;
+    std::vector<OpTiming> prof;
+    const int32_t st = execute_plan(c, c->engine->plan.explicit_batch ? 1 : batch, bindings, stream, &prof);
+    if (st != TRTX_OK) return st;
+    std::ostringstream o;
+    o << "[";
+    for (size_t k = 0; k < prof.size(); ++k) {
+        o << (k ? "," : "") << "{\"name\":\"";
+        for (char ch : prof[k].name) o << ((ch == '"' || ch == '\\' || (unsigned char)ch < 0x20) ? ' ' : ch);
+        o << "\",\"kind\":\"" << prof[k].kind << "\",\"ms\":" << prof[k].ms << "}";
+    }
+    o << "]";
+    *json_out = strdup(o.str().c_str());
+    return TRTX_OK;
+}

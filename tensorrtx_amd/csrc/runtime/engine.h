@@ -1,0 +1,35 @@
+// Engine (device-resident packed weights + lowered plan) and execution context (activation arena +
+// stream executor).  IRuntime::deserializeCudaEngine / ICudaEngine / IExecutionContext of the reference
+// (yolov8/yolov8_det.cpp:42-66,98; lenet/lenet.cpp:187-243).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "plan.h"
+
+struct trtx_engine {
+    std::unique_ptr<trtx::Network> net;
+    trtx::Plan plan;
+    std::vector<uint8_t> blob;  // the serialized plan this engine was created from
+    void* d_weights = nullptr;
+    bool plugins_initialized = false;
+    ~trtx_engine();
+};
+
+struct trtx_context {
+    trtx_engine* engine = nullptr;
+    void* d_arena = nullptr;
+    std::vector<void*> addr;  // setTensorAddress slots, one per binding
+    ~trtx_context();
+};
+
+namespace trtx {
+// runs every op of the plan on `stream`; with `prof` != nullptr brackets each op with hipEvents
+struct OpTiming {
+    std::string name, kind;
+    float ms;
+};
+int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStream_t stream,
+                     std::vector<OpTiming>* prof);
+}  // namespace trtx

@@ -1,0 +1,1061 @@
+// Network -> Plan lowering.  See plan.h for what this stands in for.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <sstream>
+
+#include "pack.h"
+#include "plan.h"
+
+namespace trtx {
+
+const char* op_kind_name(int k) {
+    static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
+                              "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
+                              "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin"};
+    return (k >= 0 && k <= OP_COPY_LIN) ? n[k] : "?";
+}
+
+namespace {
+
+int act_code(int trt_type) {
+    switch (trt_type) {
+        case TRTX_ACTIVATION_RELU: return ACT_RELU;
+        case TRTX_ACTIVATION_SIGMOID: return ACT_SIGMOID;
+        case TRTX_ACTIVATION_TANH: return ACT_TANH;
+        case TRTX_ACTIVATION_LEAKY_RELU: return ACT_LEAKY;
+        default: return -1;
+    }
+}
+
+int ew_code(int trt_op) {
+    switch (trt_op) {
+        case TRTX_ELEMENTWISE_SUM: return EW_SUM;
+        case TRTX_ELEMENTWISE_PROD: return EW_PROD;
+        case TRTX_ELEMENTWISE_MAX: return EW_MAX;
+        case TRTX_ELEMENTWISE_MIN: return EW_MIN;
+        case TRTX_ELEMENTWISE_SUB: return EW_SUB;
+        case TRTX_ELEMENTWISE_DIV: return EW_DIV;
+        case TRTX_ELEMENTWISE_POW: return EW_POW;
+        default: return -1;
+    }
+}
+
+struct FusedConv {
+    int conv_layer = -1;
+    int scale_layer = -1;
+    int act1 = ACT_NONE;
+    float alpha1 = 0.f;
+    int residual = -1;  // network tensor id
+    int act2 = ACT_NONE;
+    float alpha2 = 0.f;
+    int out_tensor = -1;  // network tensor the fused op produces
+    int emit_at = -1;     // layer index at which the fused op is scheduled
+};
+
+struct Lowerer {
+    const Network& net;
+    Plan& plan;
+    int dt;  // dtype of NHWC tensors
+    std::vector<std::vector<int>> consumers;
+    std::vector<int> pt_of, pt_lin, pt_nhwc;
+    std::vector<bool> absorbed;
+    std::vector<int> group_at;
+    std::vector<FusedConv> groups;
+    std::string err;
+
+    Lowerer(const Network& n, Plan& p) : net(n), plan(p) {
+        dt = n.fp16 ? DT_F16 : DT_F32;
+        consumers.resize(n.tensors.size());
+        for (size_t li = 0; li < n.layers.size(); ++li)
+            for (int t : n.layers[li].inputs) consumers[t].push_back((int)li);
+        pt_of.assign(n.tensors.size(), -1);
+        pt_lin.assign(n.tensors.size(), -1);
+        pt_nhwc.assign(n.tensors.size(), -1);
+        absorbed.assign(n.layers.size(), false);
+        group_at.assign(n.layers.size(), -1);
+    }
+
+    bool fail(const std::string& m) {
+        if (err.empty()) err = m;
+        return false;
+    }
+
+    bool spatial(const Dims& d) const { return net.explicit_batch ? d.nb == 4 : d.nb == 3; }
+
+    // ---- tensors ---------------------------------------------------------------------------------
+    int new_tensor(int net_t, const Dims& d, int layout, bool batched) {
+        PTensor t;
+        t.id = (int)plan.tensors.size();
+        t.net_tensor = net_t;
+        t.name = net_t >= 0 ? net.tensors[net_t].name : "";
+        t.dims = d;
+        t.layout = layout;
+        t.batched = batched;
+        if (layout == LAY_NHWC) {
+            t.dtype = dt;
+            if (net.explicit_batch) {
+                t.nfix = (int)d.d[0];
+                t.C = (int)d.d[1];
+                t.H = (int)d.d[2];
+                t.W = (int)d.d[3];
+                t.batched = false;
+            } else {
+                t.C = (int)d.d[0];
+                t.H = (int)d.d[1];
+                t.W = (int)d.d[2];
+            }
+            t.Calloc = dt == DT_F16 ? (t.C + 7) / 8 * 8 : t.C;
+        } else {
+            t.dtype = DT_F32;
+            if (net.explicit_batch) t.batched = false;
+        }
+        plan.tensors.push_back(t);
+        return t.id;
+    }
+    int new_view_nhwc(int parent, int coff, int C, int net_t) {
+        PTensor t = plan.tensors[parent];
+        t.id = (int)plan.tensors.size();
+        t.net_tensor = net_t;
+        t.name = net_t >= 0 ? net.tensors[net_t].name : "";
+        t.parent = parent;
+        t.coff = coff;
+        t.C = C;
+        t.Calloc = 0;
+        t.pad_zeroed = false;
+        if (net.explicit_batch)
+            t.dims.d[1] = C;
+        else
+            t.dims.d[0] = C;
+        plan.tensors.push_back(t);
+        return t.id;
+    }
+    int new_view_lin(int parent, const Dims& d, int net_t) {
+        PTensor t = plan.tensors[parent];
+        t.id = (int)plan.tensors.size();
+        t.net_tensor = net_t;
+        t.name = net_t >= 0 ? net.tensors[net_t].name : "";
+        t.parent = parent;
+        t.eoff = 0;
+        t.dims = d;
+        plan.tensors.push_back(t);
+        return t.id;
+    }
+
+    POp& add_op(int kind, const std::string& name, std::vector<int> in, std::vector<int> out) {
+        POp op;
+        op.kind = kind;
+        op.name = name;
+        op.in = std::move(in);
+        op.out = std::move(out);
+        op.dtype = dt;
+        plan.ops.push_back(std::move(op));
+        return plan.ops.back();
+    }
+
+    int need_nhwc(int net_t) {
+        const int p = pt_of[net_t];
+        if (plan.tensors[p].layout == LAY_NHWC) return p;
+        if (pt_nhwc[net_t] >= 0) return pt_nhwc[net_t];
+        const int q = new_tensor(net_t, plan.tensors[p].dims, LAY_NHWC, plan.tensors[p].batched);
+        plan.tensors[q].pad_zeroed = true;
+        POp& op = add_op(OP_TO_NHWC, "to_nhwc:" + net.tensors[net_t].name, {p}, {q});
+        op.bytes = (double)plan.tensors[p].dims.volume() * (4 + (dt == DT_F16 ? 2 : 4));
+        return pt_nhwc[net_t] = q;
+    }
+    int need_lin(int net_t) {
+        const int p = pt_of[net_t];
+        if (plan.tensors[p].layout == LAY_LINEAR) return p;
+        if (pt_lin[net_t] >= 0) return pt_lin[net_t];
+        const int q = new_tensor(net_t, plan.tensors[p].dims, LAY_LINEAR, plan.tensors[p].batched || plan.tensors[p].nfix == 0);
+        POp& op = add_op(OP_TO_LINEAR, "to_linear:" + net.tensors[net_t].name, {p}, {q});
+        op.bytes = (double)plan.tensors[p].dims.volume() * (4 + (dt == DT_F16 ? 2 : 4));
+        return pt_lin[net_t] = q;
+    }
+
+    // top owner of an NHWC tensor and accumulated channel offset
+    int owner_of(int p, int* off) const {
+        int o = 0;
+        while (plan.tensors[p].parent >= 0) {
+            o += plan.tensors[p].coff;
+            p = plan.tensors[p].parent;
+        }
+        if (off) *off = o;
+        return p;
+    }
+    bool is_binding_tensor(int p) const {
+        for (int b : plan.binding_ptensor)
+            if (b == p) return true;
+        return false;
+    }
+    // try to make tensor `child` live inside `parent` at channel `coff`
+    bool try_place(int child, int parent, int coff) {
+        int off = 0;
+        const int top = owner_of(child, &off);
+        PTensor& t = plan.tensors[top];
+        const PTensor& c = plan.tensors[child];
+        if (t.layout != LAY_NHWC) return false;
+        // only a whole, un-padded, freely placeable owner may move (a padded owner would spill into its neighbour)
+        if (off != 0 || c.C != t.C || t.C != t.Calloc || t.pad_zeroed || is_binding_tensor(top)) return false;
+        if (owner_of(parent, nullptr) == top) return false;  // would create a cycle
+        t.parent = parent;
+        t.coff = coff;
+        return true;
+    }
+
+    // ---- fusion analysis ----------------------------------------------------------------------------
+    bool sole_consumer(int tensor, int* layer) const {
+        if (consumers[tensor].size() != 1 || net.tensors[tensor].is_output) return false;
+        *layer = consumers[tensor][0];
+        return true;
+    }
+
+    void analyse_fusion() {
+        for (size_t li = 0; li < net.layers.size(); ++li) {
+            const LayerDef& l = net.layers[li];
+            if (l.kind != L_CONV && l.kind != L_FULLY_CONNECTED) continue;
+            if (!spatial(net.tensors[l.inputs[0]].dims)) continue;
+            FusedConv g;
+            g.conv_layer = (int)li;
+            int t = l.outputs[0];
+            int last = (int)li;
+            int nx;
+            // Conv -> Scale (BatchNorm folded by the host code, block.cpp:45-77)
+            if (sole_consumer(t, &nx) && !absorbed[nx] && net.layers[nx].kind == L_SCALE && net.layers[nx].op != TRTX_SCALE_ELEMENTWISE) {
+                const LayerDef& s = net.layers[nx];
+                bool pow1 = true;
+                for (float p : s.w2) pow1 = pow1 && p == 1.0f;
+                if (pow1) {
+                    g.scale_layer = nx;
+                    absorbed[nx] = true;
+                    t = s.outputs[0];
+                    last = std::max(last, nx);
+                }
+            }
+            // SiLU spelled as Sigmoid + Prod (block.cpp:91-94), or a plain activation
+            if (!net.tensors[t].is_output && consumers[t].size() == 2) {
+                int a = consumers[t][0], b = consumers[t][1];
+                if (net.layers[a].kind != L_ACTIVATION) std::swap(a, b);
+                const LayerDef &la = net.layers[a], &lb = net.layers[b];
+                if (la.kind == L_ACTIVATION && la.op == TRTX_ACTIVATION_SIGMOID && lb.kind == L_ELEMENTWISE &&
+                    lb.op == TRTX_ELEMENTWISE_PROD && a != b && !absorbed[a] && !absorbed[b]) {
+                    const int so = la.outputs[0];
+                    const bool uses = (lb.inputs[0] == t && lb.inputs[1] == so) || (lb.inputs[1] == t && lb.inputs[0] == so);
+                    int only;
+                    if (uses && sole_consumer(so, &only) && only == b) {
+                        g.act1 = ACT_SILU;
+                        absorbed[a] = absorbed[b] = true;
+                        t = lb.outputs[0];
+                        last = std::max(last, std::max(a, b));
+                    }
+                }
+            } else if (sole_consumer(t, &nx) && !absorbed[nx] && net.layers[nx].kind == L_ACTIVATION && act_code(net.layers[nx].op) >= 0) {
+                g.act1 = act_code(net.layers[nx].op);
+                g.alpha1 = net.layers[nx].alpha;
+                absorbed[nx] = true;
+                t = net.layers[nx].outputs[0];
+                last = std::max(last, nx);
+            }
+            // + residual (block.cpp:104-108 ; resnet50.cpp:146), then an optional trailing activation
+            if (sole_consumer(t, &nx) && !absorbed[nx] && net.layers[nx].kind == L_ELEMENTWISE && net.layers[nx].op == TRTX_ELEMENTWISE_SUM) {
+                const LayerDef& e = net.layers[nx];
+                const int other = e.inputs[0] == t ? e.inputs[1] : e.inputs[0];
+                if (other != t && net.tensors[other].dims == net.tensors[t].dims) {
+                    g.residual = other;
+                    absorbed[nx] = true;
+                    t = e.outputs[0];
+                    last = std::max(last, nx);
+                    int n2;
+                    if (sole_consumer(t, &n2) && !absorbed[n2] && net.layers[n2].kind == L_ACTIVATION && act_code(net.layers[n2].op) >= 0) {
+                        g.act2 = act_code(net.layers[n2].op);
+                        g.alpha2 = net.layers[n2].alpha;
+                        absorbed[n2] = true;
+                        t = net.layers[n2].outputs[0];
+                        last = std::max(last, n2);
+                    }
+                }
+            }
+            g.out_tensor = t;
+            g.emit_at = last;
+            absorbed[li] = true;
+            group_at[last] = (int)groups.size();
+            groups.push_back(g);
+        }
+    }
+
+    // ---- per-kind emission ----------------------------------------------------------------------------
+    bool emit_conv(const FusedConv& g) {
+        const LayerDef& l = net.layers[g.conv_layer];
+        const int in = need_nhwc(l.inputs[0]);
+        const PTensor ti = plan.tensors[in];
+        const int out = new_tensor(g.out_tensor, net.tensors[g.out_tensor].dims, LAY_NHWC, true);
+        int res = -1;
+        if (g.residual >= 0) res = need_nhwc(g.residual);
+        std::vector<int> ins = {in};
+        if (res >= 0) ins.push_back(res);
+        POp& op = add_op(OP_CONV, l.name, ins, {out});
+        op.src_layer = g.conv_layer;
+        op.scale_layer = g.scale_layer;
+        ConvArgs& a = op.conv;
+        const PTensor& to = plan.tensors[out];
+        a.H = ti.H;
+        a.W = ti.W;
+        a.Cin = ti.C;
+        a.Ho = to.H;
+        a.Wo = to.W;
+        a.Cout = to.C;
+        if (l.kind == L_FULLY_CONNECTED) {
+            a.kh = ti.H;
+            a.kw = ti.W;
+            a.stride_h = a.stride_w = 1;
+            a.pad_h = a.pad_w = 0;
+            a.dil_h = a.dil_w = 1;
+            a.groups = 1;
+        } else {
+            a.kh = l.kernel[0];
+            a.kw = l.kernel[1];
+            a.stride_h = l.stride[0];
+            a.stride_w = l.stride[1];
+            a.pad_h = l.padding[0];
+            a.pad_w = l.padding[1];
+            a.dil_h = l.dilation[0];
+            a.dil_w = l.dilation[1];
+            a.groups = l.groups;
+        }
+        a.act1 = g.act1;
+        a.alpha1 = g.alpha1;
+        a.act2 = g.act2;
+        a.alpha2 = g.alpha2;
+        op.flops = 2.0 * a.Ho * a.Wo * a.Cout * (double)a.kh * a.kw * (a.Cin / a.groups);
+        pt_of[g.out_tensor] = out;
+        return true;
+    }
+
+    bool emit_layer(int li) {
+        const LayerDef& l = net.layers[li];
+        auto out_dims = [&](int s = 0) -> const Dims& { return net.tensors[l.outputs[s]].dims; };
+        switch (l.kind) {
+            case L_CONV:
+            case L_FULLY_CONNECTED:
+                return fail(l.name + ": convolution on a non-image tensor is not supported");
+            case L_DECONV: {
+                const int in = need_nhwc(l.inputs[0]);
+                const PTensor ti = plan.tensors[in];
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                POp& op = add_op(OP_DECONV, l.name, {in}, {out});
+                op.src_layer = li;
+                ConvArgs& a = op.conv;
+                const PTensor& to = plan.tensors[out];
+                a.H = ti.H; a.W = ti.W; a.Cin = ti.C; a.Ho = to.H; a.Wo = to.W; a.Cout = to.C;
+                a.kh = l.kernel[0]; a.kw = l.kernel[1]; a.stride_h = l.stride[0]; a.stride_w = l.stride[1];
+                a.pad_h = l.padding[0]; a.pad_w = l.padding[1]; a.dil_h = l.dilation[0]; a.dil_w = l.dilation[1];
+                a.groups = l.groups;
+                op.flops = 2.0 * ti.H * ti.W * a.Cin * (double)a.kh * a.kw * (a.Cout / a.groups);
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_POOLING: {
+                const int in = need_nhwc(l.inputs[0]);
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                POp& op = add_op(OP_POOL, l.name, {in}, {out});
+                op.i[0] = l.op == TRTX_POOLING_MAX ? POOL_MAX : POOL_AVG;
+                op.i[1] = l.kernel[0]; op.i[2] = l.kernel[1]; op.i[3] = l.stride[0]; op.i[4] = l.stride[1];
+                op.i[5] = l.padding[0]; op.i[6] = l.padding[1]; op.i[7] = l.avg_exclusive;
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_RESIZE: {
+                if (l.op != TRTX_RESIZE_NEAREST) return fail(l.name + ": only nearest resize is implemented");
+                const Dims& di = net.tensors[l.inputs[0]].dims;
+                const Dims& dout = out_dims();
+                if (!spatial(di) || dout.d[di.nb - 3] != di.d[di.nb - 3]) return fail(l.name + ": resize must keep channels");
+                const int in = need_nhwc(l.inputs[0]);
+                const int out = new_tensor(l.outputs[0], dout, LAY_NHWC, true);
+                add_op(OP_RESIZE, l.name, {in}, {out});
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_ACTIVATION: {
+                const int code = act_code(l.op);
+                if (code < 0) return fail(l.name + ": unsupported activation type");
+                const int p = pt_of[l.inputs[0]];
+                const bool nhwc = plan.tensors[p].layout == LAY_NHWC;
+                const int out = new_tensor(l.outputs[0], out_dims(), nhwc ? LAY_NHWC : LAY_LINEAR, plan.tensors[p].batched);
+                POp& op = add_op(nhwc ? OP_ACT_NHWC : OP_ACT_LIN, l.name, {p}, {out});
+                op.i[0] = code;
+                op.f[0] = l.alpha;
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_SCALE: {
+                bool pow1 = true;
+                for (float p : l.w2) pow1 = pow1 && p == 1.0f;
+                const Dims& di = net.tensors[l.inputs[0]].dims;
+                if (spatial(di) && pow1 && l.op != TRTX_SCALE_ELEMENTWISE) {
+                    const int in = need_nhwc(l.inputs[0]);
+                    const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                    POp& op = add_op(OP_SCALE_NHWC, l.name, {in}, {out});
+                    op.src_layer = li;
+                    pt_of[l.outputs[0]] = out;
+                    return true;
+                }
+                if (l.op == TRTX_SCALE_ELEMENTWISE) return fail(l.name + ": elementwise scale is not implemented");
+                const int in = need_lin(l.inputs[0]);
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_LINEAR, plan.tensors[in].batched);
+                POp& op = add_op(OP_SCALE_LIN, l.name, {in}, {out});
+                op.src_layer = li;
+                op.i[0] = l.op == TRTX_SCALE_CHANNEL ? 1 : 0;
+                const int ca = (net.explicit_batch && di.nb >= 4) ? 1 : (di.nb >= 3 ? di.nb - 3 : 0);
+                long outer = 1, inner = 1;
+                for (int k = 0; k < ca; ++k) outer *= di.d[k];
+                for (int k = ca + 1; k < di.nb; ++k) inner *= di.d[k];
+                op.i[1] = (int)outer; op.i[2] = (int)di.d[ca]; op.i[3] = (int)inner;
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_ELEMENTWISE: {
+                const int code = ew_code(l.op);
+                if (code < 0) return fail(l.name + ": unsupported elementwise op");
+                const Dims &da = net.tensors[l.inputs[0]].dims, &db = net.tensors[l.inputs[1]].dims;
+                const int pa = pt_of[l.inputs[0]], pb = pt_of[l.inputs[1]];
+                const bool any_nhwc = plan.tensors[pa].layout == LAY_NHWC || plan.tensors[pb].layout == LAY_NHWC;
+                if (spatial(da) && da == db && any_nhwc) {
+                    const int a = need_nhwc(l.inputs[0]), b = need_nhwc(l.inputs[1]);
+                    const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                    POp& op = add_op(OP_EW_NHWC, l.name, {a, b}, {out});
+                    op.i[0] = code;
+                    pt_of[l.outputs[0]] = out;
+                    return true;
+                }
+                const int a = need_lin(l.inputs[0]), b = need_lin(l.inputs[1]);
+                const Dims& dout = out_dims();
+                const bool batched = plan.tensors[a].batched || plan.tensors[b].batched;
+                const int out = new_tensor(l.outputs[0], dout, LAY_LINEAR, batched);
+                POp& op = add_op(OP_EW_LIN, l.name, {a, b}, {out});
+                op.i[0] = code;
+                op.view.rank = dout.nb;
+                long sa = 1, sb = 1;
+                for (int k = dout.nb - 1; k >= 0; --k) {
+                    op.view.shape[k] = dout.d[k];
+                    op.view.stride_in[k] = (da.d[k] == 1 && dout.d[k] > 1) ? 0 : sa;
+                    op.view.stride_in2[k] = (db.d[k] == 1 && dout.d[k] > 1) ? 0 : sb;
+                    sa *= da.d[k];
+                    sb *= db.d[k];
+                }
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_CONCAT: return emit_concat(li);
+            case L_SLICE: return emit_slice(li);
+            case L_SHUFFLE: return emit_shuffle(li);
+            case L_SOFTMAX: {
+                const Dims& di = net.tensors[l.inputs[0]].dims;
+                int ax;
+                if (l.axis < 0) {
+                    ax = std::max(0, di.nb - 3);
+                } else {
+                    ax = -1;
+                    for (int k = 0; k < di.nb; ++k)
+                        if ((l.axis >> k) & 1) {
+                            if (ax >= 0) return fail(l.name + ": softmax over several axes");
+                            ax = k;
+                        }
+                    if (ax < 0) return fail(l.name + ": softmax without axis");
+                }
+                const int in = need_lin(l.inputs[0]);
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_LINEAR, plan.tensors[in].batched);
+                POp& op = add_op(OP_SOFTMAX, l.name, {in}, {out});
+                long outer = 1, inner = 1;
+                for (int k = 0; k < ax; ++k) outer *= di.d[k];
+                for (int k = ax + 1; k < di.nb; ++k) inner *= di.d[k];
+                op.i[0] = (int)outer; op.i[1] = (int)di.d[ax]; op.i[2] = (int)inner;
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_MATMUL: {
+                const Dims &da = net.tensors[l.inputs[0]].dims, &db = net.tensors[l.inputs[1]].dims;
+                for (int k = 0; k < da.nb - 2; ++k)
+                    if (da.d[k] != 1 || db.d[k] != 1) return fail(l.name + ": matmul with leading dims > 1 is not implemented");
+                if (l.mm_op[0] == TRTX_MATMUL_VECTOR || l.mm_op[1] == TRTX_MATMUL_VECTOR) return fail(l.name + ": kVECTOR matmul");
+                const int a = need_lin(l.inputs[0]), b = need_lin(l.inputs[1]);
+                const Dims& dout = out_dims();
+                const int out = new_tensor(l.outputs[0], dout, LAY_LINEAR, plan.tensors[a].batched || plan.tensors[b].batched);
+                POp& op = add_op(OP_MATMUL, l.name, {a, b}, {out});
+                const int n = da.nb;
+                const bool ta = l.mm_op[0] == TRTX_MATMUL_TRANSPOSE, tb = l.mm_op[1] == TRTX_MATMUL_TRANSPOSE;
+                op.i[0] = (int)dout.d[n - 2]; op.i[1] = (int)dout.d[n - 1];
+                op.i[2] = (int)(ta ? da.d[n - 2] : da.d[n - 1]); op.i[3] = ta; op.i[4] = tb;
+                op.flops = 2.0 * op.i[0] * op.i[1] * op.i[2];
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_CONSTANT: {
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_LINEAR, false);
+                plan.tensors[out].batched = false;
+                Storage s;
+                s.kind = ST_WEIGHTS;
+                s.bytes = (size_t)out_dims().volume() * 4;
+                plan.tensors[out].storage = (int)plan.storages.size();
+                plan.storages.push_back(s);
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_REDUCE: {
+                const Dims& di = net.tensors[l.inputs[0]].dims;
+                const int p = pt_of[l.inputs[0]];
+                const int hw_mask = net.explicit_batch ? 0b1100 : 0b110;
+                if (spatial(di) && plan.tensors[p].layout == LAY_NHWC && l.op == TRTX_REDUCE_AVG && l.axis == hw_mask && l.keep_dims) {
+                    const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                    add_op(OP_REDUCE_HW, l.name, {p}, {out});
+                    pt_of[l.outputs[0]] = out;
+                    return true;
+                }
+                // contiguous run of reduced axes in LINEAR layout
+                int first = -1, last = -1;
+                for (int k = 0; k < di.nb; ++k)
+                    if ((l.axis >> k) & 1) {
+                        if (first < 0) first = k;
+                        if (last >= 0 && k != last + 1) return fail(l.name + ": non-contiguous reduce axes");
+                        last = k;
+                    }
+                if (first < 0) return fail(l.name + ": reduce without axes");
+                int rop;
+                switch (l.op) {
+                    case TRTX_REDUCE_SUM: rop = 0; break;
+                    case TRTX_REDUCE_AVG: rop = 1; break;
+                    case TRTX_REDUCE_MAX: rop = 2; break;
+                    default: return fail(l.name + ": unsupported reduce op");
+                }
+                const int in = need_lin(l.inputs[0]);
+                const int out = new_tensor(l.outputs[0], out_dims(), LAY_LINEAR, plan.tensors[in].batched);
+                POp& op = add_op(OP_REDUCE_LIN, l.name, {in}, {out});
+                long outer = 1, axis = 1, inner = 1;
+                for (int k = 0; k < first; ++k) outer *= di.d[k];
+                for (int k = first; k <= last; ++k) axis *= di.d[k];
+                for (int k = last + 1; k < di.nb; ++k) inner *= di.d[k];
+                op.i[0] = rop; op.i[1] = (int)outer; op.i[2] = (int)axis; op.i[3] = (int)inner;
+                pt_of[l.outputs[0]] = out;
+                return true;
+            }
+            case L_PLUGIN: {
+                std::vector<int> ins, outs;
+                for (int t : l.inputs) ins.push_back(need_lin(t));
+                for (size_t s = 0; s < l.outputs.size(); ++s) {
+                    const int o = new_tensor(l.outputs[s], net.tensors[l.outputs[s]].dims, LAY_LINEAR, true);
+                    outs.push_back(o);
+                    pt_of[l.outputs[s]] = o;
+                }
+                POp& op = add_op(OP_PLUGIN, l.name, ins, outs);
+                op.plugin = l.plugin;
+                return true;
+            }
+            case L_IDENTITY: {
+                const int p = pt_of[l.inputs[0]];
+                pt_of[l.outputs[0]] = plan.tensors[p].layout == LAY_NHWC
+                                              ? new_view_nhwc(p, 0, plan.tensors[p].C, l.outputs[0])
+                                              : new_view_lin(p, out_dims(), l.outputs[0]);
+                return true;
+            }
+            default: return fail(l.name + ": unknown layer kind");
+        }
+    }
+
+    bool emit_concat(int li) {
+        const LayerDef& l = net.layers[li];
+        const Dims& dout = net.tensors[l.outputs[0]].dims;
+        const int cax = net.explicit_batch ? 1 : 0;
+        bool all_nhwc = spatial(dout) && l.axis == cax;
+        for (int t : l.inputs) all_nhwc = all_nhwc && plan.tensors[pt_of[t]].layout == LAY_NHWC;
+        if (all_nhwc) {
+            std::vector<int> ins;
+            for (int t : l.inputs) ins.push_back(pt_of[t]);
+            // concat of consecutive channel views of one tensor == a view of that tensor (C2F, block.cpp:134-141)
+            bool consecutive = plan.tensors[ins[0]].parent >= 0;
+            for (size_t k = 1; consecutive && k < ins.size(); ++k) {
+                const PTensor &a = plan.tensors[ins[k - 1]], &b = plan.tensors[ins[k]];
+                consecutive = b.parent == a.parent && b.coff == a.coff + a.C;
+            }
+            if (consecutive) {
+                pt_of[l.outputs[0]] = new_view_nhwc(plan.tensors[ins[0]].parent, plan.tensors[ins[0]].coff,
+                                                    (int)dout.d[cax], l.outputs[0]);
+                return true;
+            }
+            const int out = new_tensor(l.outputs[0], dout, LAY_NHWC, true);
+            int off = 0;
+            for (size_t k = 0; k < ins.size(); ++k) {
+                const int c = plan.tensors[ins[k]].C;
+                if (!try_place(ins[k], out, off)) {
+                    const int v = new_view_nhwc(out, off, c, -1);
+                    add_op(OP_COPY_NHWC, l.name + ":copy" + std::to_string(k), {ins[k]}, {v});
+                }
+                off += c;
+            }
+            pt_of[l.outputs[0]] = out;
+            return true;
+        }
+        // LINEAR: scatter every input into the dense output
+        std::vector<int> ins;
+        bool batched = false;
+        for (int t : l.inputs) {
+            ins.push_back(need_lin(t));
+            batched = batched || plan.tensors[ins.back()].batched;
+        }
+        const int out = new_tensor(l.outputs[0], dout, LAY_LINEAR, batched);
+        long ostride[8];
+        long s = 1;
+        for (int k = dout.nb - 1; k >= 0; --k) {
+            ostride[k] = s;
+            s *= dout.d[k];
+        }
+        long pos = 0;
+        for (size_t k = 0; k < ins.size(); ++k) {
+            const Dims& di = net.tensors[l.inputs[k]].dims;
+            POp& op = add_op(OP_SCATTER, l.name + ":in" + std::to_string(k), {ins[k]}, {out});
+            op.view.rank = di.nb;
+            for (int d = 0; d < di.nb; ++d) {
+                op.view.shape[d] = di.d[d];
+                op.view.stride_in[d] = ostride[d];
+            }
+            op.off0 = pos * ostride[l.axis];
+            pos += di.d[l.axis];
+        }
+        pt_of[l.outputs[0]] = out;
+        return true;
+    }
+
+    bool emit_slice(int li) {
+        const LayerDef& l = net.layers[li];
+        const Dims& di = net.tensors[l.inputs[0]].dims;
+        const int p = pt_of[l.inputs[0]];
+        const int cax = net.explicit_batch ? 1 : 0;
+        if (spatial(di) && plan.tensors[p].layout == LAY_NHWC) {
+            bool chan_only = l.step.d[cax] == 1;
+            for (int k = 0; k < di.nb; ++k)
+                if (k != cax) chan_only = chan_only && l.start.d[k] == 0 && l.size.d[k] == di.d[k] && l.step.d[k] == 1;
+            if (chan_only) {
+                pt_of[l.outputs[0]] = new_view_nhwc(p, (int)l.start.d[cax], (int)l.size.d[cax], l.outputs[0]);
+                return true;
+            }
+        }
+        const int in = need_lin(l.inputs[0]);
+        const int out = new_tensor(l.outputs[0], l.size, LAY_LINEAR, plan.tensors[in].batched);
+        POp& op = add_op(OP_GATHER, l.name, {in}, {out});
+        op.view.rank = di.nb;
+        long s = 1, off = 0;
+        for (int k = di.nb - 1; k >= 0; --k) {
+            op.view.shape[k] = l.size.d[k];
+            op.view.stride_in[k] = s * l.step.d[k];
+            off += l.start.d[k] * s;
+            s *= di.d[k];
+        }
+        op.off0 = off;
+        pt_of[l.outputs[0]] = out;
+        return true;
+    }
+
+    bool emit_shuffle(int li) {
+        const LayerDef& l = net.layers[li];
+        const Dims& di = net.tensors[l.inputs[0]].dims;
+        const Dims& dout = net.tensors[l.outputs[0]].dims;
+        auto identity = [](const int32_t* p, int n) {
+            for (int k = 0; k < n; ++k)
+                if (p[k] != k) return false;
+            return true;
+        };
+        int cur = need_lin(l.inputs[0]);
+        Dims dcur = di;
+        if (!identity(l.perm1, di.nb)) {
+            Dims t = di;
+            for (int k = 0; k < di.nb; ++k) t.d[k] = di.d[l.perm1[k]];
+            const int q = new_tensor(-1, t, LAY_LINEAR, plan.tensors[cur].batched);
+            POp& op = add_op(OP_GATHER, l.name + ":t1", {cur}, {q});
+            long st[8], s = 1;
+            for (int k = di.nb - 1; k >= 0; --k) {
+                st[k] = s;
+                s *= di.d[k];
+            }
+            op.view.rank = di.nb;
+            for (int k = 0; k < di.nb; ++k) {
+                op.view.shape[k] = t.d[k];
+                op.view.stride_in[k] = st[l.perm1[k]];
+            }
+            cur = q;
+            dcur = t;
+        }
+        // reshape: a view
+        Dims r = dcur;
+        if (l.reshape.nb > 0) {
+            // the network already validated/inferred the reshape; recover it from the output dims
+            r.nb = dout.nb;
+            for (int k = 0; k < dout.nb; ++k) r.d[k] = 0;
+            // invert perm2: out[k] = r[perm2[k]]
+            for (int k = 0; k < dout.nb; ++k) r.d[l.perm2[k]] = dout.d[k];
+        }
+        if (identity(l.perm2, r.nb)) {
+            pt_of[l.outputs[0]] = new_view_lin(cur, dout, l.outputs[0]);
+            return true;
+        }
+        const int rv = new_view_lin(cur, r, -1);
+        const int out = new_tensor(l.outputs[0], dout, LAY_LINEAR, plan.tensors[cur].batched);
+        POp& op = add_op(OP_GATHER, l.name + ":t2", {rv}, {out});
+        long st[8], s = 1;
+        for (int k = r.nb - 1; k >= 0; --k) {
+            st[k] = s;
+            s *= r.d[k];
+        }
+        op.view.rank = r.nb;
+        for (int k = 0; k < r.nb; ++k) {
+            op.view.shape[k] = dout.d[k];
+            op.view.stride_in[k] = st[l.perm2[k]];
+        }
+        pt_of[l.outputs[0]] = out;
+        return true;
+    }
+
+    // ---- driver ----------------------------------------------------------------------------------------
+    bool run() {
+        plan.explicit_batch = net.explicit_batch;
+        plan.fp16 = net.fp16;
+        plan.max_batch = net.explicit_batch ? 1 : net.max_batch;
+        // input bindings
+        for (int t : net.input_ids()) {
+            const int p = new_tensor(t, net.tensors[t].dims, LAY_LINEAR, true);
+            Storage s;
+            s.kind = ST_BINDING;
+            s.binding = (int)plan.binding_tensor.size();
+            plan.tensors[p].storage = (int)plan.storages.size();
+            plan.storages.push_back(s);
+            plan.binding_tensor.push_back(t);
+            plan.binding_ptensor.push_back(p);
+            plan.binding_is_input.push_back(true);
+            pt_of[t] = p;
+        }
+        analyse_fusion();
+        for (size_t li = 0; li < net.layers.size(); ++li) {
+            if (group_at[li] >= 0) {
+                if (!emit_conv(groups[group_at[li]])) return false;
+                continue;
+            }
+            if (absorbed[li]) continue;
+            if (!emit_layer((int)li)) return false;
+        }
+        // output bindings: LINEAR fp32
+        for (int t : net.output_ids()) {
+            if (pt_of[t] < 0) return fail("output tensor " + net.tensors[t].name + " is never produced");
+            int p = need_lin(t);
+            PTensor& pt = plan.tensors[p];
+            const bool own = pt.parent < 0 && pt.storage < 0 && !is_binding_tensor(p);
+            if (!own) {
+                const int q = new_tensor(t, pt.dims, LAY_LINEAR, pt.batched);
+                POp& op = add_op(OP_COPY_LIN, "output:" + net.tensors[t].name, {p}, {q});
+                op.i[0] = 0;
+                p = q;
+            }
+            Storage s;
+            s.kind = ST_BINDING;
+            s.binding = (int)plan.binding_tensor.size();
+            plan.tensors[p].storage = (int)plan.storages.size();
+            plan.storages.push_back(s);
+            plan.binding_tensor.push_back(t);
+            plan.binding_ptensor.push_back(p);
+            plan.binding_is_input.push_back(false);
+        }
+        return finalize();
+    }
+
+    size_t tensor_bytes(const PTensor& t) const {
+        const size_t es = t.dtype == DT_F16 ? 2 : 4;
+        if (t.layout == LAY_NHWC) {
+            const size_t n = t.nfix ? (size_t)t.nfix : (size_t)plan.max_batch;
+            return n * t.H * t.W * (size_t)t.Calloc * es;
+        }
+        return (t.batched ? (size_t)plan.max_batch : 1) * (size_t)t.dims.volume() * es;
+    }
+
+    bool finalize() {
+        // 1. storages for owners
+        for (auto& t : plan.tensors) {
+            if (t.parent >= 0 || t.storage >= 0) continue;
+            Storage s;
+            s.kind = ST_ARENA;
+            s.bytes = tensor_bytes(t);
+            t.storage = (int)plan.storages.size();
+            plan.storages.push_back(s);
+        }
+        // 2. resolve views
+        for (auto& t : plan.tensors) {
+            int p = t.id, coff = 0;
+            long eoff = 0;
+            while (plan.tensors[p].parent >= 0) {
+                coff += plan.tensors[p].coff;
+                eoff += plan.tensors[p].eoff;
+                p = plan.tensors[p].parent;
+            }
+            t.storage = plan.tensors[p].storage;
+            t.rcoff = coff;
+            t.reoff = eoff;
+            t.ld = plan.tensors[p].layout == LAY_NHWC ? plan.tensors[p].Calloc : 0;
+        }
+        // binding storages take their size from the bound tensor
+        for (size_t b = 0; b < plan.binding_ptensor.size(); ++b) {
+            const PTensor& t = plan.tensors[plan.binding_ptensor[b]];
+            plan.storages[t.storage].bytes = tensor_bytes(t);
+        }
+        // 3. convolution kernel selection now that strides/offsets are known
+        for (auto& op : plan.ops) {
+            if (op.kind != OP_CONV && op.kind != OP_DECONV) continue;
+            ConvArgs& a = op.conv;
+            const PTensor& ti = plan.tensors[op.in[0]];
+            const PTensor& to = plan.tensors[op.out[0]];
+            a.ld_in = ti.ld;
+            a.ld_out = to.ld;
+            a.ld_res = op.in.size() > 1 ? plan.tensors[op.in[1]].ld : 0;
+            a.K = a.kh * a.kw * (a.Cin / a.groups);
+            a.Cout_pad = a.Cout;
+            a.Kpad = a.K;
+            op.igemm = false;
+            if (op.kind == OP_CONV && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.Cout % 8 == 0 &&
+                a.Cout >= 16) {
+                int cin_eff = a.Cin;
+                bool ok = true;
+                if (cin_eff % 8) {
+                    // padded channels are zero only for a freshly converted, un-aliased tensor
+                    const PTensor& own = plan.tensors[ti.parent >= 0 ? ti.parent : ti.id];
+                    ok = ti.parent < 0 && own.pad_zeroed;
+                    cin_eff = (a.Cin + 7) / 8 * 8;
+                }
+                ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
+                if (op.in.size() > 1) {
+                    const PTensor& tr = plan.tensors[op.in[1]];
+                    ok = ok && tr.rcoff % 8 == 0 && tr.ld % 8 == 0;
+                }
+                if (ok) {
+                    op.igemm = true;
+                    a.Cin = cin_eff;
+                    a.K = a.kh * a.kw * a.Cin;
+                    a.Kpad = (a.K + 31) / 32 * 32;
+                    a.bn = conv_igemm_pick_bn(a.Cout);
+                    a.Cout_pad = (a.Cout + a.bn - 1) / a.bn * a.bn;
+                }
+            }
+            const double es = dt == DT_F16 ? 2 : 4;
+            op.bytes = es * ((double)a.H * a.W * ti.C + (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
+        }
+        // 4. plugins: configure + workspace
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            POp& op = plan.ops[k];
+            if (op.kind != OP_PLUGIN) continue;
+            std::vector<trtx_dims> din, dout;
+            for (int t : op.in) din.push_back(to_c(plan.tensors[t].dims));
+            for (int t : op.out) dout.push_back(to_c(plan.tensors[t].dims));
+            if (op.plugin->v.configure &&
+                op.plugin->v.configure(op.plugin->v.self, din.data(), (int)din.size(), dout.data(), (int)dout.size(),
+                                       plan.max_batch) != 0)
+                return fail(op.name + ": plugin configurePlugin rejected the tensor shapes");
+            op.ws_bytes = op.plugin->v.workspace_size ? op.plugin->v.workspace_size(op.plugin->v.self, plan.max_batch) : 0;
+            for (int t : op.in) op.bytes += 4.0 * plan.tensors[t].dims.volume();
+            for (int t : op.out) op.bytes += 4.0 * plan.tensors[t].dims.volume();
+        }
+        // 5. liveness
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            const POp& op = plan.ops[k];
+            auto touch = [&](int t) {
+                Storage& s = plan.storages[plan.tensors[t].storage];
+                s.first_use = std::min(s.first_use, (int)k);
+                s.last_use = std::max(s.last_use, (int)k);
+            };
+            for (int t : op.in) touch(t);
+            for (int t : op.out) touch(t);
+        }
+        // plugin workspaces are short-lived arena blocks
+        std::vector<std::pair<int, int>> ws_storage;  // (op, storage)
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            if (plan.ops[k].kind != OP_PLUGIN || plan.ops[k].ws_bytes == 0) continue;
+            Storage s;
+            s.kind = ST_ARENA;
+            s.bytes = plan.ops[k].ws_bytes;
+            s.first_use = s.last_use = (int)k;
+            ws_storage.push_back({(int)k, (int)plan.storages.size()});
+            plan.storages.push_back(s);
+        }
+        // 6. arena offsets: first-fit over storages ordered by first use (closed live intervals)
+        std::vector<int> order;
+        for (size_t s = 0; s < plan.storages.size(); ++s)
+            if (plan.storages[s].kind == ST_ARENA && plan.storages[s].last_use >= 0) order.push_back((int)s);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int a, int b) { return plan.storages[a].first_use < plan.storages[b].first_use; });
+        std::vector<int> placed;
+        size_t arena = 0;
+        for (int si : order) {
+            Storage& s = plan.storages[si];
+            const size_t need = align_up256(s.bytes);
+            std::vector<std::pair<size_t, size_t>> busy;
+            for (int pj : placed) {
+                const Storage& o = plan.storages[pj];
+                if (o.last_use < s.first_use || o.first_use > s.last_use) continue;
+                busy.push_back({o.offset, o.offset + align_up256(o.bytes)});
+            }
+            std::sort(busy.begin(), busy.end());
+            size_t off = 0;
+            for (auto& b : busy) {
+                if (off + need <= b.first) break;
+                off = std::max(off, b.second);
+            }
+            s.offset = off;
+            arena = std::max(arena, off + need);
+            placed.push_back(si);
+        }
+        plan.arena_bytes = arena;
+        for (auto& w : ws_storage) plan.ops[w.first].ws_off = plan.storages[w.second].offset;
+        return true;
+    }
+    static size_t align_up256(size_t v) { return (v + 255) / 256 * 256; }
+};
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+bool lower_network(const Network& net, Plan* plan) {
+    *plan = Plan();
+    Lowerer L(net, *plan);
+    const bool ok = L.run();
+    if (!ok) plan->error = L.err.empty() ? "lowering failed" : L.err;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+bool pack_weights(const Network& net, Plan* plan) {
+    std::vector<uint8_t>& blob = plan->weight_blob;
+    blob.clear();
+    auto reserve = [&](size_t bytes) {
+        const size_t off = align256(blob.size());
+        blob.resize(off + bytes, 0);
+        return off;
+    };
+    // constants
+    for (auto& t : plan->tensors) {
+        if (t.storage < 0 || plan->storages[t.storage].kind != ST_WEIGHTS || t.parent >= 0) continue;
+        const TensorDef& nt = net.tensors[t.net_tensor];
+        const LayerDef& l = net.layers[nt.producer];
+        const size_t off = reserve(l.w0.size() * 4);
+        memcpy(blob.data() + off, l.w0.data(), l.w0.size() * 4);
+        plan->storages[t.storage].offset = off;
+    }
+    for (auto& op : plan->ops) {
+        if (op.kind == OP_CONV || op.kind == OP_DECONV) {
+            const LayerDef& l = net.layers[op.src_layer];
+            const ConvArgs& a = op.conv;
+            const int cout = a.Cout;
+            // folded per-channel scale / shift
+            std::vector<float> sc(cout, 1.f), bias(std::max(a.Cout_pad, cout), 0.f);
+            for (int c = 0; c < cout && c < (int)l.w1.size(); ++c) bias[c] = l.w1[c];
+            if (op.scale_layer >= 0) {
+                const LayerDef& s = net.layers[op.scale_layer];
+                for (int c = 0; c < cout; ++c) {
+                    const float scale = s.w1.empty() ? 1.f : (s.w1.size() == 1 ? s.w1[0] : s.w1[c]);
+                    const float shift = s.w0.empty() ? 0.f : (s.w0.size() == 1 ? s.w0[0] : s.w0[c]);
+                    sc[c] = scale;
+                    bias[c] = bias[c] * scale + shift;
+                }
+            }
+            const TensorDef& tin = net.tensors[l.inputs[0]];
+            const int cin_logical = (int)tin.dims.d[tin.dims.nb - 3];
+            if (op.kind == OP_DECONV) {
+                op.w_off = reserve((size_t)cout * a.kh * a.kw * (cin_logical / a.groups) * 4);
+                pack_deconv_weights_f32(l.w0.data(), cin_logical, cout, a.groups, a.kh, a.kw,
+                                        reinterpret_cast<float*>(blob.data() + op.w_off));
+            } else if (op.igemm) {
+                op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
+                pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.Cin, sc.data(),
+                                      reinterpret_cast<uint16_t*>(blob.data() + op.w_off));
+            } else {
+                op.w_off = reserve((size_t)cout * a.kh * a.kw * (cin_logical / a.groups) * 4);
+                pack_conv_weights_f32(l.w0.data(), cout, cin_logical / a.groups, a.kh, a.kw, sc.data(),
+                                      reinterpret_cast<float*>(blob.data() + op.w_off));
+            }
+            op.b_off = reserve(bias.size() * 4);
+            memcpy(blob.data() + op.b_off, bias.data(), bias.size() * 4);
+            op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * 2 : (size_t)cout * a.K * 4);
+        } else if (op.kind == OP_SCALE_NHWC || op.kind == OP_SCALE_LIN) {
+            const LayerDef& l = net.layers[op.src_layer];
+            const int C = op.kind == OP_SCALE_NHWC ? plan->tensors[op.in[0]].C : (op.i[0] == 1 ? op.i[2] : 1);
+            auto expand = [&](const std::vector<float>& w, float dflt) {
+                std::vector<float> v(C, dflt);
+                for (int c = 0; c < C; ++c)
+                    if (!w.empty()) v[c] = w.size() == 1 ? w[0] : w[c];
+                return v;
+            };
+            const auto shift = expand(l.w0, 0.f), scale = expand(l.w1, 1.f), power = expand(l.w2, 1.f);
+            op.s_off = reserve(C * 4);
+            memcpy(blob.data() + op.s_off, scale.data(), C * 4);
+            op.b_off = reserve(C * 4);
+            memcpy(blob.data() + op.b_off, shift.data(), C * 4);
+            op.w_off = reserve(C * 4);
+            memcpy(blob.data() + op.w_off, power.data(), C * 4);
+        }
+    }
+    plan->weight_bytes = align256(blob.size());
+    blob.resize(plan->weight_bytes, 0);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+std::string Plan::describe_json() const {
+    std::ostringstream o;
+    double flops = 0, bytes = 0;
+    int n_conv = 0, n_igemm = 0;
+    for (const auto& op : ops) {
+        flops += op.flops;
+        bytes += op.bytes;
+        if (op.kind == OP_CONV) {
+            ++n_conv;
+            n_igemm += op.igemm ? 1 : 0;
+        }
+    }
+    o << "{\"fp16\":" << (fp16 ? "true" : "false") << ",\"max_batch\":" << max_batch << ",\"arena_bytes\":" << arena_bytes
+      << ",\"weight_bytes\":" << weight_bytes << ",\"n_ops\":" << ops.size() << ",\"n_conv\":" << n_conv
+      << ",\"n_igemm\":" << n_igemm << ",\"flops_per_sample\":" << flops << ",\"bytes_per_sample\":" << bytes
+      << ",\"ops\":[";
+    for (size_t k = 0; k < ops.size(); ++k) {
+        const POp& op = ops[k];
+        o << (k ? "," : "") << "{\"kind\":\"" << op_kind_name(op.kind) << "\",\"name\":\"";
+        for (char c : op.name) o << ((c == '"' || c == '\\' || (unsigned char)c < 0x20) ? ' ' : c);
+        o << "\",\"flops\":" << op.flops << ",\"bytes\":" << op.bytes;
+        if (op.kind == OP_CONV || op.kind == OP_DECONV) {
+            const ConvArgs& a = op.conv;
+            o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout
+              << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
+              << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
+              << ",\"act2\":" << a.act2 << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
+              << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
+              << ",\"ld_out\":" << a.ld_out;
+        }
+        o << ",\"in\":[";
+        for (size_t j = 0; j < op.in.size(); ++j) o << (j ? "," : "") << op.in[j];
+        o << "],\"out\":[";
+        for (size_t j = 0; j < op.out.size(); ++j) o << (j ? "," : "") << op.out[j];
+        o << "]}";
+    }
+    o << "],\"tensors\":[";
+    for (size_t k = 0; k < tensors.size(); ++k) {
+        const PTensor& t = tensors[k];
+        o << (k ? "," : "") << "{\"id\":" << t.id << ",\"net\":" << t.net_tensor << ",\"layout\":\""
+          << (t.layout == LAY_NHWC ? "nhwc" : "linear") << "\",\"dims\":[";
+        for (int d = 0; d < t.dims.nb; ++d) o << (d ? "," : "") << t.dims.d[d];
+        o << "],\"storage\":" << t.storage << ",\"coff\":" << t.rcoff << ",\"ld\":" << t.ld << ",\"view\":"
+          << (t.parent >= 0 ? "true" : "false") << "}";
+    }
+    o << "],\"storages\":[";
+    for (size_t k = 0; k < storages.size(); ++k) {
+        const Storage& s = storages[k];
+        o << (k ? "," : "") << "{\"kind\":" << s.kind << ",\"bytes\":" << s.bytes << ",\"offset\":" << s.offset
+          << ",\"first\":" << s.first_use << ",\"last\":" << s.last_use << "}";
+    }
+    o << "]}";
+    return o.str();
+}
+
+}  // namespace trtx

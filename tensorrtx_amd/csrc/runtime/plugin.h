@@ -1,0 +1,77 @@
+// Runtime-side owner of one plugin instance (driven through the C v-table of include/trtx_hip.h) and the
+// process-wide creator registry (getPluginRegistry() of the reference: yolov8/src/block.cpp:263).
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "graph.h"
+#include "trtx_hip.h"
+
+namespace trtx {
+
+inline trtx_dims to_c(const Dims& d) {
+    trtx_dims o{};
+    o.nb = d.nb;
+    for (int i = 0; i < 8; ++i) o.d[i] = d.d[i];
+    return o;
+}
+inline Dims from_c(const trtx_dims& d) {
+    Dims o;
+    o.nb = d.nb < 0 ? 0 : (d.nb > 8 ? 8 : d.nb);
+    for (int i = 0; i < 8; ++i) o.d[i] = d.d[i];
+    return o;
+}
+
+struct PluginHolder {
+    trtx_plugin_vtbl v{};
+    explicit PluginHolder(const trtx_plugin_vtbl& vt) : v(vt) {}
+    ~PluginHolder() {
+        if (v.destroy) v.destroy(v.self);
+    }
+    PluginHolder(const PluginHolder&) = delete;
+    PluginHolder& operator=(const PluginHolder&) = delete;
+
+    int nb_outputs() const { return v.get_nb_outputs(v.self); }
+    bool output_dims(int idx, const std::vector<Dims>& ins, Dims* out) const {
+        std::vector<trtx_dims> ci;
+        for (const auto& d : ins) ci.push_back(to_c(d));
+        trtx_dims o{};
+        if (v.get_output_dims(v.self, idx, ci.data(), (int)ci.size(), &o) != 0) return false;
+        *out = from_c(o);
+        return true;
+    }
+    std::string type() const { return v.plugin_type(v.self); }
+    std::string version() const { return v.plugin_version(v.self); }
+    std::vector<uint8_t> serialize() const {
+        std::vector<uint8_t> b(v.serialization_size(v.self));
+        if (!b.empty()) v.serialize(v.self, b.data());
+        return b;
+    }
+    std::shared_ptr<PluginHolder> clone() const {
+        trtx_plugin_vtbl c{};
+        if (!v.clone || v.clone(v.self, &c) != 0) return nullptr;
+        return std::make_shared<PluginHolder>(c);
+    }
+};
+
+class PluginRegistry {
+   public:
+    static PluginRegistry& instance();
+    int32_t add(const trtx_creator_vtbl& c);
+    bool get(const std::string& name, const std::string& version, trtx_creator_vtbl* out);
+    std::shared_ptr<PluginHolder> deserialize(const std::string& type, const std::string& version, const void* data,
+                                              size_t len);
+
+   private:
+    PluginRegistry();
+    std::mutex mu_;
+    std::map<std::string, trtx_creator_vtbl> creators_;
+};
+
+// built-in HIP plugins (plugins/builtin_plugins.cpp)
+void register_builtin_plugins(PluginRegistry& r);
+
+}  // namespace trtx

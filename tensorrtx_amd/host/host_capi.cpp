@@ -1,0 +1,62 @@
+// extern "C" doorway so tests/bench (ctypes) can drive the C++ host builders.  `options` is a flat
+// "key=value;key=value" string.  Returns a malloc'd copy of the serialized plan.
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+
+#include "common.h"
+#include "models.h"
+
+using namespace nvinfer1;
+
+static std::map<std::string, std::string> parse_opts(const char* s) {
+    std::map<std::string, std::string> m;
+    std::stringstream ss(s ? s : "");
+    std::string kv;
+    while (std::getline(ss, kv, ';')) {
+        const auto eq = kv.find('=');
+        if (eq != std::string::npos) m[kv.substr(0, eq)] = kv.substr(eq + 1);
+    }
+    return m;
+}
+static int geti(const std::map<std::string, std::string>& m, const char* k, int d) {
+    auto it = m.find(k);
+    return it == m.end() ? d : std::atoi(it->second.c_str());
+}
+
+extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, const char* options, void** blob, size_t* size) {
+    if (!model || !wts_path || !blob || !size) return TRTX_ERR_INVALID;
+    const auto o = parse_opts(options);
+    trtx_host::Logger logger;
+    std::unique_ptr<IBuilder> builder(createInferBuilder(logger));
+    std::unique_ptr<IBuilderConfig> config(builder->createBuilderConfig());
+    std::unique_ptr<IHostMemory> plan;
+    const std::string m(model);
+    if (m == "lenet") {
+        plan.reset(trtx_host::buildLenet(builder.get(), config.get(), wts_path, geti(o, "batch", 1)));
+    } else if (m == "resnet50") {
+        plan.reset(trtx_host::buildResnet50(builder.get(), config.get(), wts_path, geti(o, "batch", 1), geti(o, "fp16", 1) != 0,
+                                            geti(o, "h", 224), geti(o, "w", 224)));
+    } else if (m == "yolov8n") {
+        trtx_host::Yolov8Config cfg;
+        cfg.max_batch = geti(o, "batch", 1);
+        cfg.fp16 = geti(o, "fp16", 1) != 0;
+        cfg.input_h = geti(o, "h", 640);
+        cfg.input_w = geti(o, "w", 640);
+        cfg.num_class = geti(o, "classes", 80);
+        cfg.max_out_bbox = geti(o, "max_out", 1000);
+        cfg.mark_heads = geti(o, "mark_heads", 0) != 0;
+        plan.reset(trtx_host::buildEngineYolov8Det(builder.get(), config.get(), wts_path, cfg));
+    } else {
+        return TRTX_ERR_INVALID;
+    }
+    if (!plan) return TRTX_ERR_UNSUPPORTED;
+    *size = plan->size();
+    *blob = std::malloc(*size);
+    std::memcpy(*blob, plan->data(), *size);
+    return TRTX_OK;
+}
+
+extern "C" void trtx_host_free(void* blob) { std::free(blob); }

@@ -42,3 +42,18 @@ def yolo_head_tensors(batch, classes=80, net_h=640, net_w=640, strides=(8, 16, 3
                 outs[l][b, 3, e] = y2 / s - (r + 0.5) + jit[3]
                 outs[l][b, 4 + cls, e] = rng.uniform(0.5, 8.0)
     return outs
+
+
+def images(batch, h=640, w=640, seed=0, n_rect=(8, 30)):
+    """Synthetic RGB images in [0, 1], [B, 3, H, W] fp32: dark noisy background with random bright
+    rectangles, so that a randomly initialised detector sees spatially varying features
+    (uniform noise alone averages out to a constant feature map)."""
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(0.0, 0.15, size=(batch, 3, h, w)).astype(np.float32)
+    for b in range(batch):
+        for _ in range(int(rng.integers(n_rect[0], n_rect[1] + 1))):
+            rw, rh = int(rng.integers(w // 40, w // 4)), int(rng.integers(h // 40, h // 4))
+            x0, y0 = int(rng.integers(0, w - rw)), int(rng.integers(0, h - rh))
+            col = rng.uniform(0.2, 1.0, size=(3, 1, 1)).astype(np.float32)
+            img[b, :, y0:y0 + rh, x0:x0 + rw] = col + rng.normal(0, 0.03, size=(3, rh, rw)).astype(np.float32)
+    return np.clip(img, 0.0, 1.0)

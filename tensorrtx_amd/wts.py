@@ -1,0 +1,26 @@
+"""`.wts` writer — host-side mirror of the reference's gen_wts.py exporters
+(lenet/gen_wts.py:83-92, yolov8/gen_wts.py:50-58; format: tutorials/getting_started.md:107-132).
+
+    <number of blobs>\n
+    <name> <count> <hex> <hex> ...\n        each <hex> = struct.pack('>f', v).hex()  (big-endian IEEE-754 bits)
+
+Two dialects exist upstream (single space everywhere, or a double space after the count); both are
+produced here so the loader's whitespace handling can be tested.
+"""
+import numpy as np
+
+
+def write_wts(path, tensors, dialect="single"):
+    """tensors: ordered mapping name -> array-like (any shape, flattened row-major as fp32)."""
+    sep_after_count = " " if dialect == "single" else "  "
+    with open(path, "w") as f:
+        f.write(f"{len(tensors)}\n")
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32).reshape(-1))
+            # big-endian bytes -> one long hex string -> 8-character tokens joined by spaces (vectorised)
+            hx = a.astype(">f4").tobytes().hex().encode()
+            hexes = b" ".join(np.frombuffer(hx, dtype="S8")).decode()
+            if a.size:
+                f.write(f"{name} {a.size}{sep_after_count}{hexes}\n")
+            else:
+                f.write(f"{name} 0\n")

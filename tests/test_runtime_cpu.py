@@ -1,0 +1,159 @@
+"""CPU tests of the host side: .wts loader, C++ builders through the nvinfer1 shim, network serialisation,
+graph lowering (fusion / concat elimination / FLOP count) and the graph-interpreter oracle against the
+PyTorch restatements.  No compute kernel runs here (no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph_interp as gi
+from oracle import models_torch as mt
+from oracle import wts as owts
+from oracle import yolo_post as yp
+from tensorrtx_amd import capi, engine, synth
+from tensorrtx_amd import wts as wts_writer
+from util import synth_wts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    names = set()
+    for h in ("trtx_hip.h",):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        names |= set(re.findall(r"\b(trtx_[a-z0-9_]+)\s*\(", src))
+    names -= {"trtx_plugin_vtbl", "trtx_creator_vtbl"}
+    assert len(names) > 60
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.trtx_abi_version() == 1
+    assert L.trtx_device_count() >= 0
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("GPU present")
+    path, _ = synth_wts("lenet")
+    plan = engine.build_plan("lenet", path, batch=1)  # building is host-only work
+    with pytest.raises(capi.TrtxError) as e:
+        engine.Engine(plan)
+    assert e.value.status == 5  # TRTX_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("dialect", ["single", "double"])
+def test_wts_loader_matches_python_restatement(tmp_path, dialect):
+    rng = np.random.default_rng(0)
+    tensors = {"a.weight": rng.normal(size=(3, 4)).astype(np.float32), "b.bias": np.array([1.5, -0.0, np.inf, 1e-40], np.float32),
+               "empty": np.zeros((0,), np.float32), "c.num_batches_tracked": np.array([7.0], np.float32)}
+    p = str(tmp_path / "t.wts")
+    wts_writer.write_wts(p, tensors, dialect=dialect)
+    ref = owts.load_wts(p)
+    L = capi.lib()
+    w = ctypes.c_void_p()
+    assert L.trtx_wts_load(p.encode(), ctypes.byref(w)) == 0
+    assert L.trtx_wts_count(w) == len(tensors)
+    for i, (name, arr) in enumerate(tensors.items()):
+        n, v, c = ctypes.c_char_p(), ctypes.POINTER(ctypes.c_float)(), ctypes.c_int64()
+        assert L.trtx_wts_entry(w, i, ctypes.byref(n), ctypes.byref(v), ctypes.byref(c)) == 0
+        assert n.value.decode() == name and c.value == arr.size
+        got = np.ctypeslib.as_array(v, shape=(c.value,)) if c.value else np.zeros((0,), np.float32)
+        assert got.tobytes() == arr.reshape(-1).tobytes() == ref[name].tobytes()  # bit exact incl. -0.0, inf, denormal
+    L.trtx_wts_free(w)
+    assert L.trtx_wts_load(str(tmp_path / "missing.wts").encode(), ctypes.byref(w)) == 6  # TRTX_ERR_IO
+
+
+def test_lenet_builder_matches_pytorch_twin():
+    path, _ = synth_wts("lenet")
+    plan = engine.build_plan("lenet", path, batch=1)
+    desc = engine.describe_plan(plan)
+    x = torch.randn(1, 1, 32, 32, generator=torch.Generator().manual_seed(3))
+    out = gi.run(desc, plan, {"data": x.numpy()})["prob"].reshape(-1)
+    ref = mt.lenet(mt.Params(owts.load_wts(path)), x).reshape(-1)
+    assert torch.allclose(out, ref, atol=1e-6)
+    low = engine.describe_plan(plan, lowered=True)
+    kinds = [o["kind"] for o in low["ops"]]
+    assert kinds.count("conv") == 2 and "act_nhwc" not in kinds  # ReLU fused into both convolutions
+    assert kinds.count("matmul") == 3
+
+
+def test_resnet50_builder_matches_pytorch_restatement():
+    path, _ = synth_wts("resnet50")
+    plan = engine.build_plan("resnet50", path, batch=2, fp16=0, h=64, w=64)
+    desc = engine.describe_plan(plan)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    out = gi.run(desc, plan, {"data": x.numpy()})["prob"].reshape(2, 1000)
+    with torch.inference_mode():
+        ref = mt.resnet50(mt.Params(owts.load_wts(path)), x)
+    assert (out - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_resnet50_lowering_fuses_bn_relu_and_residual():
+    path, _ = synth_wts("resnet50")
+    plan = engine.build_plan("resnet50", path, batch=32, fp16=1, h=224, w=224)
+    low = engine.describe_plan(plan, lowered=True)
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert len(convs) == 54 and all(o["igemm"] for o in convs)  # 53 convs + FC, all on the MFMA kernel
+    assert sum(o["residual"] for o in convs) == 16 and all(o["bn_folded"] for o in convs[:-1])
+    kinds = {o["kind"] for o in low["ops"]}
+    assert kinds <= {"conv", "pool", "to_nhwc", "to_linear"}, kinds
+    assert abs(low["flops_per_sample"] / 1e9 - 8.178) < 0.06
+
+
+def test_yolov8n_builder_matches_pytorch_restatement():
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=2, h=128, w=128, fp16=1, mark_heads=1)
+    desc = engine.describe_plan(plan)
+    x = torch.from_numpy(synth.images(2, 128, 128, seed=5))
+    out = gi.run(desc, plan, {"images": x.numpy()})
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), x)
+    assert strides == [8, 16, 32]
+    for i, h in enumerate(heads):
+        assert (out[f"head{i}"] - h).abs().max().item() < 2e-4
+    dec = yp.decode_c([h.numpy() for h in heads], 80, 128, 128, strides)
+    got = out["output"].reshape(2, -1).numpy()
+    assert np.array_equal(got[:, 0], dec[:, 0])
+
+
+def test_yolov8n_lowering_at_benchmark_size():
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=32, h=640, w=640, fp16=1)
+    low = engine.describe_plan(plan, lowered=True)
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert sum(o["igemm"] for o in convs) == 63  # Appendix C.1: 63 convolutions; the 3 DFL 1x1 run in fp32
+    assert abs(low["flops_per_sample"] / 1e9 - 8.743) < 0.01
+    kinds = [o["kind"] for o in low["ops"]]
+    assert "copy_nhwc" not in kinds and "ew_nhwc" not in kinds and "act_nhwc" not in kinds  # all fused / aliased
+    assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
+    assert sum(o["residual"] for o in convs) == 6  # bottleneck shortcuts of model.2/4/6/8
+    assert low["arena_bytes"] < 450e6
+
+
+def test_plan_roundtrip_is_byte_stable():
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=4, h=64, w=64)
+    again = engine.build_plan("yolov8n", path, batch=4, h=64, w=64)
+    assert plan == again
+    desc = engine.describe_plan(plan)
+    plug = [l for l in desc["layers"] if l["kind"] == 16][0]
+    blob = bytes.fromhex(plug["plugin_blob"])
+    # YoloLayer serialisation layout (yololayer.cu:75-101): 8 ints/float, 3 strides, 3 bools
+    assert len(blob) == 8 * 4 + 3 * 4 + 3
+    hdr = np.frombuffer(blob, dtype=np.int32, count=8)
+    assert hdr[0] == 80 and hdr[3] == 256 and hdr[4] == 64 and hdr[5] == 64 and hdr[6] == 1000 and hdr[7] == 3
+
+
+def test_invalid_network_fails_at_build_time(tmp_path):
+    # a .wts with a wrong-sized kernel must be rejected by build-time validation, not crash
+    path, tensors = synth_wts("lenet")
+    bad = {k: v.numpy() for k, v in tensors.items()}
+    bad["conv1.weight"] = bad["conv1.weight"].reshape(-1)[:-1]
+    p = str(tmp_path / "bad.wts")
+    wts_writer.write_wts(p, bad)
+    with pytest.raises(capi.TrtxError):
+        engine.build_plan("lenet", p, batch=1)

@@ -1,0 +1,29 @@
+"""Shared helpers for the tests: seeded synthetic .wts files (cached under /tmp) and plan building."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from oracle import models_torch as mt
+from tensorrtx_amd import wts as wts_writer
+
+CACHE = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
+
+
+def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
+    """Create (once) the seeded synthetic weights of `model`; returns (path, OrderedDict of tensors)."""
+    os.makedirs(CACHE, exist_ok=True)
+    tag = hashlib.sha1(repr((model, seed, dialect, sorted(kw.items()))).encode()).hexdigest()[:12]
+    path = os.path.join(CACHE, f"{model}_{tag}.wts")
+    fn, x = {
+        "lenet": (mt.lenet, torch.zeros(1, 1, 32, 32)),
+        "resnet50": (mt.resnet50, torch.zeros(1, 3, 64, 64)),
+        "yolov8n": (mt.yolov8_det, torch.zeros(1, 3, 64, 64)),
+    }[model]
+    tensors, _ = mt.make_weights(fn, x, seed=seed, **kw)
+    if not os.path.exists(path):
+        tmp = path + ".tmp"
+        wts_writer.write_wts(tmp, {k: v.numpy() for k, v in tensors.items()}, dialect=dialect)
+        os.replace(tmp, path)
+    return path, tensors
