@@ -61,6 +61,18 @@ int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, in
                          trtx_stream_t stream);
 
 /*
+ * Fused DFL + YOLOv8 decode on the detect head's own NHWC fp16 output (what the engine uses instead of the
+ * shuffle/slice/softmax/conv/concat chain of yolov8/src/block.cpp:239-257 + model.cpp:263-303 followed by
+ * YoloLayerPlugin::enqueue).  heads[l]: device fp16 [batch][cells_l][ld[l]], channels [0,64) = 4x16 DFL
+ * bins, [64, 64+classes) = class logits; dfl_weights: device fp32[16] (model.22.dfl.conv.weight).
+ * Output format and candidate order are those of trtx_yolo_decode.  classes % 8 == 0.
+ */
+size_t trtx_yolo_head_decode_workspace(int batch, int net_h, int net_w, const int* strides, int n_levels);
+int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const int* ld, int n_levels, int batch, int classes,
+                                   int net_h, int net_w, const int* strides, const float* dfl_weights, int max_out,
+                                   float* output, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+
+/*
  * Class-aware greedy NMS over the decode buffer.  Replaces host batch_nms()/nms()
  * (reference yolov8/src/postprocess.cpp:71-129; call site yolov8/yolov8_det.cpp:240).
  *   decode_out device, fp32 [batch][1 + max_out*90]  (output of trtx_yolo_decode)

@@ -34,6 +34,9 @@ struct ConvArgs {
 int conv_igemm_pick_bn(int cout);
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
+bool conv_stem_supported(const ConvArgs& a);
+int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);
 // generic direct convolution (any groups / dilation / channel count), T = activation dtype, fp32 weights
 int32_t conv_direct(const ConvArgs& a, int dtype, hipStream_t s);
 // generic transposed convolution, fp32 weights laid out [Cin][kh][kw][Cout/groups]

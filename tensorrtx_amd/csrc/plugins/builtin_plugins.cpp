@@ -173,6 +173,18 @@ const char* yolo_creator_version(void*) { return "1"; }
 
 }  // namespace
 
+bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
+    if (v.enqueue != yolo_enqueue || !v.self) return false;
+    const auto* y = static_cast<const YoloLayer*>(v.self);
+    out->classes = y->class_count;
+    out->net_w = y->net_w;
+    out->net_h = y->net_h;
+    out->max_out = y->max_out;
+    out->strides = y->strides;
+    out->det_only = !(y->seg || y->pose || y->obb);
+    return true;
+}
+
 void register_builtin_plugins(PluginRegistry& r) {
     trtx_creator_vtbl c{};
     c.plugin_name = yolo_creator_name;

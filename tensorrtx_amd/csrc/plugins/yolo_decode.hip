@@ -108,11 +108,13 @@ __global__ __launch_bounds__(kChunk / VEC) void yolo_score_kernel(LevelTable t, 
 }
 
 // Pass 2: ordered compaction.  One thread per cell, kChunk threads per workgroup.
+// `boxes` != nullptr: ltrb distances were already produced by the fused DFL pass ([batch][cells][4]).
 __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int classes, int total_cells,
                                                            const float* __restrict__ score,
                                                            const int* __restrict__ cls_in,
                                                            const int* __restrict__ chunk_cnt, int n_chunks,
-                                                           int max_out, int out_elem, float* __restrict__ output) {
+                                                           int max_out, int out_elem, float* __restrict__ output,
+                                                           const float4* __restrict__ boxes) {
     const int b = blockIdx.y;
     const int chunk = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -149,13 +151,19 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
         const int e = g - t.cell_off[l];
         const int gw = t.grid_w[l];
         const float stride = (float)t.stride[l];
-        const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e;
+        float4 d;
+        if (boxes) {
+            d = boxes[(size_t)b * total_cells + g];
+        } else {
+            const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e;
+            d = make_float4(cur[0], cur[(size_t)cells], cur[(size_t)2 * cells], cur[(size_t)3 * cells]);
+        }
         const int row = e / gw, col = e - row * gw;
         float* det = out + 1 + (size_t)slot * trtx::kYoloDetFloats;
-        det[0] = (col + 0.5f - cur[0]) * stride;
-        det[1] = (row + 0.5f - cur[(size_t)cells]) * stride;
-        det[2] = (col + 0.5f + cur[(size_t)2 * cells]) * stride;
-        det[3] = (row + 0.5f + cur[(size_t)3 * cells]) * stride;
+        det[0] = (col + 0.5f - d.x) * stride;
+        det[1] = (row + 0.5f - d.y) * stride;
+        det[2] = (col + 0.5f + d.z) * stride;
+        det[3] = (row + 0.5f + d.w) * stride;
         det[4] = sc;
         det[5] = (float)cls_in[(size_t)b * total_cells + g];
     }
@@ -163,6 +171,95 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
         int total = before + in_wave + (keep ? 1 : 0);  // last thread of the last chunk sees the full count
         out[0] = (float)(total < max_out ? total : max_out);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused detect-head tail: reads the NHWC fp16 output of the head convolutions directly
+// (channels [0,64) = 4 sides x 16 DFL bins, [64, 64+classes) = class logits) and performs, per cell,
+//   DFL: softmax over the 16 bins of each side, expectation with the 1x1 "dfl.conv" weights
+//        (yolov8/src/block.cpp:239-257 — shuffle/softmax/conv/shuffle collapsed into registers, fp32), and
+//   the CalDetection class scan (sigmoid, strict-'>' argmax, 0.1 threshold; yololayer.cu:195-204).
+// It replaces ~10 layout/shuffle/slice/softmax/concat launches per level of the un-fused graph.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+struct HeadTable {
+    const _Float16* in[kMaxLevels];
+    int ld[kMaxLevels];
+    int cell_off[kMaxLevels + 1];
+    int n_levels;
+};
+
+__global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int classes, int total_cells,
+                                                              const float* __restrict__ dfl_w,
+                                                              float* __restrict__ score, int* __restrict__ cls_out,
+                                                              float4* __restrict__ boxes,
+                                                              int* __restrict__ chunk_cnt, int n_chunks) {
+    const int b = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    int keep_i = 0;
+    if (g < total_cells) {
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < kMaxLevels; ++i)
+            if (i < t.n_levels && g >= t.cell_off[i]) l = i;
+        const int cells = t.cell_off[l + 1] - t.cell_off[l];
+        const int e = g - t.cell_off[l];
+        const _Float16* cell = t.in[l] + ((size_t)b * cells + e) * t.ld[l];
+        // ---- DFL: 4 sides x softmax(16) . w
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = dfl_w[i];
+        float side[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8_t lo = *reinterpret_cast<const half8_t*>(cell + s * 16);
+            const half8_t hi = *reinterpret_cast<const half8_t*>(cell + s * 16 + 8);
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                x[i] = (float)lo[i];
+                x[8 + i] = (float)hi[i];
+            }
+            float mx = x[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, x[i]);
+            float sum = 0.f, acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float ex = expf(x[i] - mx);
+                sum += ex;
+                acc = fmaf(ex, w[i], acc);
+            }
+            side[s] = acc / sum;
+        }
+        // ---- class scan (classes % 8 == 0 on this path)
+        float best = 0.0f;
+        int bcls = 0;
+        const _Float16* cl = cell + 64;
+        for (int c0 = 0; c0 < classes; c0 += 8) {
+            const half8_t v = *reinterpret_cast<const half8_t*>(cl + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pr = logist((float)v[i]);
+                if (pr > best) {
+                    best = pr;
+                    bcls = c0 + i;
+                }
+            }
+        }
+        const bool keep = !((double)best < 0.1);
+        const size_t o = (size_t)b * total_cells + g;
+        score[o] = keep ? best : -1.0f;
+        cls_out[o] = bcls;
+        boxes[o] = make_float4(side[0], side[1], side[2], side[3]);
+        keep_i = keep ? 1 : 0;
+    }
+    // per-kChunk candidate counts (two 256-thread workgroups feed one chunk counter)
+    int wsum = keep_i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
+    if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&chunk_cnt[b * n_chunks + (blockIdx.x * 256) / kChunk], wsum);
 }
 
 }  // namespace
@@ -214,6 +311,59 @@ extern "C" int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, in
         hipLaunchKernelGGL(yolo_score_kernel<1>, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
                            chunk_cnt, n_chunks);
     hipLaunchKernelGGL(yolo_emit_kernel, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
-                       chunk_cnt, n_chunks, max_out, out_elem, output);
+                       chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)nullptr);
     return trtx::check_launch("trtx_yolo_decode");
+}
+
+
+extern "C" size_t trtx_yolo_head_decode_workspace(int batch, int net_h, int net_w, const int* strides, int n_levels) {
+    size_t cells = 0;
+    for (int i = 0; i < n_levels; ++i) cells += (size_t)(net_h / strides[i]) * (net_w / strides[i]);
+    const size_t n_chunks = (cells + kChunk - 1) / kChunk;
+    return trtx::align_up((size_t)batch * cells * sizeof(float), 256) +
+           trtx::align_up((size_t)batch * cells * sizeof(int), 256) +
+           trtx::align_up((size_t)batch * cells * sizeof(float4), 256) +
+           trtx::align_up((size_t)batch * n_chunks * sizeof(int), 256);
+}
+
+extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const int* ld, int n_levels, int batch,
+                                              int classes, int net_h, int net_w, const int* strides,
+                                              const float* dfl_weights, int max_out, float* output, void* workspace,
+                                              size_t workspace_bytes, hipStream_t stream) {
+    if (n_levels < 1 || n_levels > kMaxLevels || batch < 1 || classes < 8 || classes % 8 || max_out < 1 || !heads ||
+        !ld || !dfl_weights || !output || !workspace)
+        return TRTX_ERR_INVALID;
+    if (workspace_bytes < trtx_yolo_head_decode_workspace(batch, net_h, net_w, strides, n_levels)) return TRTX_ERR_WORKSPACE;
+    HeadTable h{};
+    LevelTable t{};
+    h.n_levels = t.n_levels = n_levels;
+    int off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const int gh = net_h / strides[i], gw = net_w / strides[i];
+        if (ld[i] % 8 || (reinterpret_cast<uintptr_t>(heads[i]) & 15)) return TRTX_ERR_UNSUPPORTED;
+        h.in[i] = static_cast<const _Float16*>(heads[i]);
+        h.ld[i] = ld[i];
+        h.cell_off[i] = t.cell_off[i] = off;
+        t.grid_w[i] = gw;
+        t.stride[i] = strides[i];
+        off += gh * gw;
+    }
+    for (int i = n_levels; i <= kMaxLevels; ++i) h.cell_off[i] = t.cell_off[i] = off;
+    const int total_cells = off;
+    const int n_chunks = (total_cells + kChunk - 1) / kChunk;
+    char* ws = static_cast<char*>(workspace);
+    float* score = reinterpret_cast<float*>(ws);
+    ws += trtx::align_up((size_t)batch * total_cells * sizeof(float), 256);
+    int* cls = reinterpret_cast<int*>(ws);
+    ws += trtx::align_up((size_t)batch * total_cells * sizeof(int), 256);
+    float4* boxes = reinterpret_cast<float4*>(ws);
+    ws += trtx::align_up((size_t)batch * total_cells * sizeof(float4), 256);
+    int* chunk_cnt = reinterpret_cast<int*>(ws);
+    if (hipMemsetAsync(chunk_cnt, 0, (size_t)batch * n_chunks * sizeof(int), stream) != hipSuccess) return TRTX_ERR_HIP;
+    const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
+    hipLaunchKernelGGL(yolo_head_score_kernel, dim3((total_cells + 255) / 256, batch), dim3(256), 0, stream, h, classes,
+                       total_cells, dfl_weights, score, cls, boxes, chunk_cnt, n_chunks);
+    hipLaunchKernelGGL(yolo_emit_kernel, dim3(n_chunks, batch), dim3(kChunk), 0, stream, t, classes, total_cells, score,
+                       cls, chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)boxes);
+    return trtx::check_launch("trtx_yolo_head_decode_nhwc");
 }

@@ -96,10 +96,12 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 a.residual = op.in.size() > 1 ? R.ptr(op.in[1]) : nullptr;
                 a.wgt = W + op.w_off;
                 a.bias = reinterpret_cast<const float*>(W + op.b_off);
-                a.N = nb(t0);
+                a.N = op.stem ? batch : nb(t0);
                 a.M = a.N * a.Ho * a.Wo;
                 if (op.kind == OP_DECONV)
                     st = deconv_direct(a, op.dtype, stream);
+                else if (op.stem)
+                    st = conv_stem_nchw_f32(a, stream);
                 else if (op.igemm)
                     st = conv_igemm_f16(a, stream);
                 else
@@ -216,6 +218,20 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     fprintf(stderr, "[trtx_hip] plugin %s enqueue returned %d\n", op.name.c_str(), rc);
                     st = TRTX_ERR_HIP;
                 }
+                break;
+            }
+            case OP_YOLO_HEAD: {
+                const int nl = op.i[4];
+                const void* heads[8];
+                int lds[8];
+                for (int k = 0; k < nl; ++k) {
+                    heads[k] = R.ptr(op.in[k]);
+                    lds[k] = plan.tensors[op.in[k]].ld;
+                }
+                st = trtx_yolo_head_decode_nhwc(heads, lds, nl, batch, op.i[0], op.i[1], op.i[2], &op.i[5],
+                                                reinterpret_cast<const float*>(W + op.w_off), op.i[3],
+                                                static_cast<float*>(R.ptr(op.out[0])),
+                                                static_cast<char*>(c->d_arena) + op.ws_off, op.ws_bytes, stream);
                 break;
             }
             case OP_COPY_LIN: {

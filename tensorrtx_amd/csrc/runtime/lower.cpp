@@ -14,8 +14,8 @@ namespace trtx {
 const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
-                              "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin"};
-    return (k >= 0 && k <= OP_COPY_LIN) ? n[k] : "?";
+                              "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head"};
+    return (k >= 0 && k <= OP_YOLO_HEAD) ? n[k] : "?";
 }
 
 namespace {
@@ -55,6 +55,13 @@ struct FusedConv {
     int emit_at = -1;     // layer index at which the fused op is scheduled
 };
 
+struct YoloHeadFuse {
+    int plugin_layer = -1;
+    std::vector<int> head_tensor;  // network tensor per level: CHW (64 + classes, gh, gw)
+    int dfl_conv_layer = -1;
+    YoloLayerParams params;
+};
+
 struct Lowerer {
     const Network& net;
     Plan& plan;
@@ -64,6 +71,8 @@ struct Lowerer {
     std::vector<bool> absorbed;
     std::vector<int> group_at;
     std::vector<FusedConv> groups;
+    std::vector<YoloHeadFuse> yolo_heads;
+    std::vector<int> yolo_at;
     std::string err;
 
     Lowerer(const Network& n, Plan& p) : net(n), plan(p) {
@@ -76,6 +85,7 @@ struct Lowerer {
         pt_nhwc.assign(n.tensors.size(), -1);
         absorbed.assign(n.layers.size(), false);
         group_at.assign(n.layers.size(), -1);
+        yolo_at.assign(n.layers.size(), -1);
     }
 
     bool fail(const std::string& m) {
@@ -216,6 +226,7 @@ struct Lowerer {
         for (size_t li = 0; li < net.layers.size(); ++li) {
             const LayerDef& l = net.layers[li];
             if (l.kind != L_CONV && l.kind != L_FULLY_CONNECTED) continue;
+            if (absorbed[li]) continue;  // already claimed (fused YOLO head)
             if (!spatial(net.tensors[l.inputs[0]].dims)) continue;
             FusedConv g;
             g.conv_layer = (int)li;
@@ -285,11 +296,149 @@ struct Lowerer {
         }
     }
 
+    // ---- YOLOv8 detect tail: flatten -> slice -> DFL(shuffle, softmax, 1x1 conv, shuffle) -> concat -> YoloLayer_TRT
+    // (yolov8/src/model.cpp:263-303, block.cpp:239-257) collapses into one fused kernel when the plugin is the
+    // built-in one and every intermediate tensor has no other use.
+    int producer(int tensor) const { return net.tensors[tensor].producer; }
+    bool only_used_by(int tensor, std::initializer_list<int> layers) const {
+        if (net.tensors[tensor].is_output) return false;
+        std::vector<int> want(layers), have(consumers[tensor]);
+        std::sort(want.begin(), want.end());
+        std::sort(have.begin(), have.end());
+        return want == have;
+    }
+    static bool ident(const int32_t* p, int n) {
+        for (int k = 0; k < n; ++k)
+            if (p[k] != k) return false;
+        return true;
+    }
+    bool match_yolo_level(int plugin_layer, int t_in, int classes, int* head, int* conv_layer, std::vector<int>* used) {
+        const int lc = producer(t_in);
+        if (lc < 0 || net.layers[lc].kind != L_CONCAT || net.layers[lc].inputs.size() != 2 || net.layers[lc].axis != 0) return false;
+        if (!only_used_by(t_in, {plugin_layer})) return false;
+        const int ta = net.layers[lc].inputs[0], tb = net.layers[lc].inputs[1];
+        // box branch
+        const int lsh2 = producer(ta);
+        if (lsh2 < 0 || net.layers[lsh2].kind != L_SHUFFLE || !only_used_by(ta, {lc})) return false;
+        const LayerDef& sh2 = net.layers[lsh2];
+        const Dims& d2 = net.tensors[ta].dims;
+        if (d2.nb != 2 || d2.d[0] != 4 || !ident(sh2.perm1, 3) || !ident(sh2.perm2, 2)) return false;
+        const int64_t g = d2.d[1];
+        const int tconv = sh2.inputs[0];
+        const int lconv = producer(tconv);
+        if (lconv < 0 || net.layers[lconv].kind != L_CONV || !only_used_by(tconv, {lsh2})) return false;
+        const LayerDef& cv = net.layers[lconv];
+        if (cv.nb_out != 1 || cv.kernel[0] != 1 || cv.kernel[1] != 1 || cv.groups != 1 || cv.stride[0] != 1 || cv.stride[1] != 1 ||
+            cv.padding[0] != 0 || cv.padding[1] != 0 || cv.w0.size() != 16 || !cv.w1.empty())
+            return false;
+        const int tsm = cv.inputs[0];
+        const int lsm = producer(tsm);
+        if (lsm < 0 || net.layers[lsm].kind != L_SOFTMAX || !only_used_by(tsm, {lconv})) return false;
+        if (!(net.layers[lsm].axis < 0 || net.layers[lsm].axis == 1)) return false;
+        const int tsh1 = net.layers[lsm].inputs[0];
+        const int lsh1 = producer(tsh1);
+        if (lsh1 < 0 || net.layers[lsh1].kind != L_SHUFFLE || !only_used_by(tsh1, {lsm})) return false;
+        const LayerDef& sh1 = net.layers[lsh1];
+        const Dims& d1 = net.tensors[tsh1].dims;
+        if (d1.nb != 3 || d1.d[0] != 16 || d1.d[1] != 4 || d1.d[2] != g) return false;
+        if (!ident(sh1.perm1, 2) || sh1.reshape.nb != 3 || sh1.perm2[0] != 1 || sh1.perm2[1] != 0 || sh1.perm2[2] != 2) return false;
+        const int tsa = sh1.inputs[0];
+        const int lsa = producer(tsa);
+        if (lsa < 0 || net.layers[lsa].kind != L_SLICE || !only_used_by(tsa, {lsh1})) return false;
+        const LayerDef& sa = net.layers[lsa];
+        if (sa.start.nb != 2 || sa.start.d[0] != 0 || sa.start.d[1] != 0 || sa.size.d[0] != 64 || sa.size.d[1] != g ||
+            sa.step.d[0] != 1 || sa.step.d[1] != 1)
+            return false;
+        // class branch
+        const int lsb = producer(tb);
+        if (lsb < 0 || net.layers[lsb].kind != L_SLICE || !only_used_by(tb, {lc})) return false;
+        const LayerDef& sb = net.layers[lsb];
+        if (sb.start.nb != 2 || sb.start.d[0] != 64 || sb.start.d[1] != 0 || sb.size.d[0] != classes || sb.size.d[1] != g ||
+            sb.step.d[0] != 1 || sb.step.d[1] != 1 || sb.inputs[0] != sa.inputs[0])
+            return false;
+        const int tflat = sa.inputs[0];
+        const int lflat = producer(tflat);
+        if (lflat < 0 || net.layers[lflat].kind != L_SHUFFLE || !only_used_by(tflat, {lsa, lsb})) return false;
+        const LayerDef& fl = net.layers[lflat];
+        const Dims& dx = net.tensors[fl.inputs[0]].dims;
+        if (!ident(fl.perm1, 3) || !ident(fl.perm2, 2) || !spatial(dx) || dx.d[0] != 64 + classes || dx.d[1] * dx.d[2] != g) return false;
+        *head = fl.inputs[0];
+        *conv_layer = lconv;
+        for (int l : {lc, lsh2, lconv, lsm, lsh1, lsa, lsb, lflat}) used->push_back(l);
+        return true;
+    }
+    void analyse_yolo_head() {
+        if (dt != DT_F16 || net.explicit_batch) return;
+        for (size_t li = 0; li < net.layers.size(); ++li) {
+            const LayerDef& l = net.layers[li];
+            if (l.kind != L_PLUGIN || l.outputs.size() != 1) continue;
+            YoloHeadFuse f;
+            if (!builtin_yolo_params(l.plugin->v, &f.params)) continue;
+            if (!f.params.det_only || f.params.classes % 8 || f.params.strides.size() != l.inputs.size() || l.inputs.size() > 6) continue;
+            std::vector<int> used;
+            bool ok = true;
+            for (size_t k = 0; ok && k < l.inputs.size(); ++k) {
+                int head = -1, conv = -1;
+                ok = match_yolo_level((int)li, l.inputs[k], f.params.classes, &head, &conv, &used);
+                if (!ok) break;
+                const Dims& dh = net.tensors[head].dims;
+                ok = dh.d[1] == f.params.net_h / f.params.strides[k] && dh.d[2] == f.params.net_w / f.params.strides[k];
+                if (f.dfl_conv_layer >= 0 && net.layers[conv].w0 != net.layers[f.dfl_conv_layer].w0) ok = false;
+                f.dfl_conv_layer = conv;
+                f.head_tensor.push_back(head);
+            }
+            for (int u : used) ok = ok && !absorbed[u];
+            if (!ok) continue;
+            for (int u : used) absorbed[u] = true;
+            f.plugin_layer = (int)li;
+            absorbed[li] = true;
+            yolo_at[li] = (int)yolo_heads.size();
+            yolo_heads.push_back(f);
+        }
+    }
+    bool emit_yolo_head(const YoloHeadFuse& f) {
+        const LayerDef& l = net.layers[f.plugin_layer];
+        std::vector<int> ins;
+        for (int t : f.head_tensor) ins.push_back(need_nhwc(t));
+        const int out = new_tensor(l.outputs[0], net.tensors[l.outputs[0]].dims, LAY_LINEAR, true);
+        POp& op = add_op(OP_YOLO_HEAD, l.name + " [fused DFL+decode]", ins, {out});
+        op.src_layer = f.dfl_conv_layer;
+        op.i[0] = f.params.classes;
+        op.i[1] = f.params.net_h;
+        op.i[2] = f.params.net_w;
+        op.i[3] = f.params.max_out;
+        op.i[4] = (int)f.params.strides.size();
+        for (size_t k = 0; k < f.params.strides.size(); ++k) op.i[5 + k] = f.params.strides[k];
+        op.ws_bytes = trtx_yolo_head_decode_workspace(plan.max_batch, f.params.net_h, f.params.net_w, f.params.strides.data(),
+                                                      (int)f.params.strides.size());
+        for (int t : ins) op.bytes += 2.0 * plan.tensors[t].dims.volume();
+        op.bytes += 4.0 * net.tensors[l.outputs[0]].dims.volume();
+        pt_of[l.outputs[0]] = out;
+        return true;
+    }
+
     // ---- per-kind emission ----------------------------------------------------------------------------
     bool emit_conv(const FusedConv& g) {
         const LayerDef& l = net.layers[g.conv_layer];
-        const int in = need_nhwc(l.inputs[0]);
-        const PTensor ti = plan.tensors[in];
+        // stem: a few-channel fp32 LINEAR input (the image) feeds conv_stem directly, no layout pass
+        bool stem = false;
+        {
+            const PTensor& src = plan.tensors[pt_of[l.inputs[0]]];
+            const Dims& di = net.tensors[l.inputs[0]].dims;
+            const int cin = (int)di.d[di.nb - 3];
+            stem = dt == DT_F16 && l.kind == L_CONV && src.layout == LAY_LINEAR && pt_nhwc[l.inputs[0]] < 0 && cin <= 4 &&
+                   g.residual < 0 && g.act2 == ACT_NONE && l.groups == 1 && l.dilation[0] == 1 && l.dilation[1] == 1 &&
+                   (l.nb_out == 8 || l.nb_out == 16 || l.nb_out == 32 || l.nb_out == 64) &&
+                   (size_t)l.kernel[0] * l.kernel[1] * cin * l.nb_out * 4 <= 48 * 1024;
+        }
+        const int in = stem ? pt_of[l.inputs[0]] : need_nhwc(l.inputs[0]);
+        PTensor ti = plan.tensors[in];
+        if (stem) {  // geometry of the LINEAR tensor viewed as an image
+            const Dims& di = net.tensors[l.inputs[0]].dims;
+            ti.C = (int)di.d[di.nb - 3];
+            ti.H = (int)di.d[di.nb - 2];
+            ti.W = (int)di.d[di.nb - 1];
+        }
         const int out = new_tensor(g.out_tensor, net.tensors[g.out_tensor].dims, LAY_NHWC, true);
         int res = -1;
         if (g.residual >= 0) res = need_nhwc(g.residual);
@@ -298,6 +447,7 @@ struct Lowerer {
         POp& op = add_op(OP_CONV, l.name, ins, {out});
         op.src_layer = g.conv_layer;
         op.scale_layer = g.scale_layer;
+        op.stem = stem;
         ConvArgs& a = op.conv;
         const PTensor& to = plan.tensors[out];
         a.H = ti.H;
@@ -732,8 +882,13 @@ struct Lowerer {
             plan.binding_is_input.push_back(true);
             pt_of[t] = p;
         }
+        analyse_yolo_head();  // before conv fusion: it claims the DFL 1x1 convolutions
         analyse_fusion();
         for (size_t li = 0; li < net.layers.size(); ++li) {
+            if (yolo_at[li] >= 0) {
+                if (!emit_yolo_head(yolo_heads[yolo_at[li]])) return false;
+                continue;
+            }
             if (group_at[li] >= 0) {
                 if (!emit_conv(groups[group_at[li]])) return false;
                 continue;
@@ -811,12 +966,13 @@ struct Lowerer {
             const PTensor& to = plan.tensors[op.out[0]];
             a.ld_in = ti.ld;
             a.ld_out = to.ld;
+            if (op.stem && (to.ld % 8 || to.rcoff % 8)) return fail(op.name + ": stem convolution output is not 16-byte aligned");
             a.ld_res = op.in.size() > 1 ? plan.tensors[op.in[1]].ld : 0;
             a.K = a.kh * a.kw * (a.Cin / a.groups);
             a.Cout_pad = a.Cout;
             a.Kpad = a.K;
             op.igemm = false;
-            if (op.kind == OP_CONV && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.Cout % 8 == 0 &&
+            if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.Cout % 8 == 0 &&
                 a.Cout >= 16) {
                 int cin_eff = a.Cin;
                 bool ok = true;
@@ -841,7 +997,7 @@ struct Lowerer {
                 }
             }
             const double es = dt == DT_F16 ? 2 : 4;
-            op.bytes = es * ((double)a.H * a.W * ti.C + (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
+            op.bytes = (op.stem ? 4.0 : es) * (double)a.H * a.W * a.Cin + es * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1);
         }
         // 4. plugins: configure + workspace
         for (size_t k = 0; k < plan.ops.size(); ++k) {
@@ -872,7 +1028,7 @@ struct Lowerer {
         // plugin workspaces are short-lived arena blocks
         std::vector<std::pair<int, int>> ws_storage;  // (op, storage)
         for (size_t k = 0; k < plan.ops.size(); ++k) {
-            if (plan.ops[k].kind != OP_PLUGIN || plan.ops[k].ws_bytes == 0) continue;
+            if ((plan.ops[k].kind != OP_PLUGIN && plan.ops[k].kind != OP_YOLO_HEAD) || plan.ops[k].ws_bytes == 0) continue;
             Storage s;
             s.kind = ST_ARENA;
             s.bytes = plan.ops[k].ws_bytes;
@@ -967,6 +1123,13 @@ bool pack_weights(const Network& net, Plan* plan) {
                 op.w_off = reserve((size_t)cout * a.kh * a.kw * (cin_logical / a.groups) * 4);
                 pack_deconv_weights_f32(l.w0.data(), cin_logical, cout, a.groups, a.kh, a.kw,
                                         reinterpret_cast<float*>(blob.data() + op.w_off));
+            } else if (op.stem) {
+                // [tap = (c*kh + r)*kw + q][cout], BN scale folded
+                op.w_off = reserve((size_t)a.kh * a.kw * cin_logical * cout * 4);
+                float* dst = reinterpret_cast<float*>(blob.data() + op.w_off);
+                for (int co = 0; co < cout; ++co)
+                    for (int t = 0; t < cin_logical * a.kh * a.kw; ++t)
+                        dst[(size_t)t * cout + co] = l.w0[(size_t)co * cin_logical * a.kh * a.kw + t] * sc[co];
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
                 pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.Cin, sc.data(),
@@ -979,6 +1142,10 @@ bool pack_weights(const Network& net, Plan* plan) {
             op.b_off = reserve(bias.size() * 4);
             memcpy(blob.data() + op.b_off, bias.data(), bias.size() * 4);
             op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * 2 : (size_t)cout * a.K * 4);
+        } else if (op.kind == OP_YOLO_HEAD) {
+            const LayerDef& l = net.layers[op.src_layer];
+            op.w_off = reserve(16 * 4);
+            memcpy(blob.data() + op.w_off, l.w0.data(), 16 * 4);
         } else if (op.kind == OP_SCALE_NHWC || op.kind == OP_SCALE_LIN) {
             const LayerDef& l = net.layers[op.src_layer];
             const int C = op.kind == OP_SCALE_NHWC ? plan->tensors[op.in[0]].C : (op.i[0] == 1 ? op.i[2] : 1);
@@ -1026,7 +1193,7 @@ std::string Plan::describe_json() const {
         o << "\",\"flops\":" << op.flops << ",\"bytes\":" << op.bytes;
         if (op.kind == OP_CONV || op.kind == OP_DECONV) {
             const ConvArgs& a = op.conv;
-            o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout
+            o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout
               << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
               << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
               << ",\"act2\":" << a.act2 << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")

@@ -40,6 +40,7 @@ enum OpKind : int {
     OP_REDUCE_LIN,
     OP_PLUGIN,
     OP_COPY_LIN,      // dense copy (e.g. into an output binding)
+    OP_YOLO_HEAD,     // fused DFL + YoloLayer decode on the NHWC head tensors
 };
 const char* op_kind_name(int k);
 
@@ -82,6 +83,7 @@ struct POp {
     // conv / deconv
     ConvArgs conv{};
     bool igemm = false;
+    bool stem = false;         // conv_stem kernel: reads the LINEAR fp32 input directly
     int src_layer = -1;        // network layer holding the kernel weights
     int scale_layer = -1;      // folded IScaleLayer (BatchNorm) or -1
     size_t w_off = 0, b_off = 0, s_off = 0;  // byte offsets into the device weight blob

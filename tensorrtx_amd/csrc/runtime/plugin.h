@@ -73,5 +73,13 @@ class PluginRegistry {
 
 // built-in HIP plugins (plugins/builtin_plugins.cpp)
 void register_builtin_plugins(PluginRegistry& r);
+// parameters of a *built-in* YoloLayer_TRT instance (false for any other / user-provided plugin): lets the
+// lowering pass replace the DFL + plugin tail by the fused NHWC kernel
+struct YoloLayerParams {
+    int classes, net_w, net_h, max_out;
+    std::vector<int> strides;
+    bool det_only;
+};
+bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out);
 
 }  // namespace trtx

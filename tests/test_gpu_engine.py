@@ -162,6 +162,26 @@ def test_yolov8n_fp16_engine_640(gpu):
     assert st["min_iou"] > 0.98
 
 
+def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
+    """The production plan (no debug outputs): fp32-NCHW stem kernel + fused DFL/decode kernel instead of the
+    shuffle/softmax/concat chain.  Checked against the fp32 oracle's decode."""
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=4, h=640, w=640, fp16=1)
+    low = engine.describe_plan(plan, lowered=True)
+    assert [o["kind"] for o in low["ops"]].count("yolo_head") == 1
+    x = torch.from_numpy(synth.images(4, 640, 640, seed=1))
+    out = _run(plan, {"images": x.numpy()}, 4, gpu)
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), x)
+    dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
+    dec = out["output"].reshape(4, -1).numpy()
+    st = _match_detections(dec, dec_ref)
+    _metric("yolov8n_fp16_640_fused", counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
+    assert st["ref"] > 50 and st["matched"] >= 0.98 * st["ref"]
+    assert st["min_iou"] > 0.98
+    assert np.abs(dec[:, 0] - dec_ref[:, 0]).max() <= 0.02 * dec_ref[:, 0].max() + 3
+
+
 def test_engine_decode_then_nms_pipeline(gpu):
     """enqueue -> YoloLayer plugin output stays on the device -> trtx_yolo_nms; the kept boxes must be the
     oracle NMS of the engine's own decode buffer (bit-exact selection on identical inputs)."""
