@@ -89,7 +89,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    from tensorrtx_amd import capi, engine, synth
+    from tensorrtx_amd import capi, engine, replicas, synth
     from util import synth_wts
 
     path, _ = synth_wts("yolov8n")
@@ -125,10 +125,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = replicas.max_over_ranks(dt, dist, dev)
 
     # per-kernel timing with HIP events on the launch stream (IProfiler analogue): roofline of the dominant kernel
     prof_runs = 5
