@@ -86,6 +86,61 @@ int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float con
                       int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, trtx_stream_t stream);
 
 
+/* ---- RetinaFace ------------------------------------------------------------------------------- */
+/*
+ * DecodePlugin::enqueue (reference retinaface/decode.cu:110-191).  inputs[l] (l = stride 8/16/32): device fp32
+ * [batch][32][h_l*w_l] = bbox(2x4) | cls(2x2) | landmark(2x10) planes (retina_r50.cpp:197-202).
+ * output: [batch][1 + anchors*15]: count, then Detection{bbox[4] xyxy px, conf, landmark[10]} (decode.h:11-15)
+ * for every anchor with softmax conf > 0.02, in (level, cell, k) order.  The reference fixes INPUT_H/W at
+ * compile time (decode.h:16-17); here they are arguments.
+ */
+size_t trtx_retina_decode_output_floats(int net_h, int net_w);
+size_t trtx_retina_decode_workspace(int batch, int net_h, int net_w);
+int32_t trtx_retina_decode(const float* const* inputs, int batch, int net_h, int net_w, float* output, void* workspace,
+                           size_t workspace_bytes, trtx_stream_t stream);
+/*
+ * Host nms() of the reference (retinaface/common.hpp:91-130) on the device: conf > conf_thresh (0.1, compared in
+ * double), sort by conf descending, greedy suppression with iou(+1e-6) > nms_thresh.  keep_idx [batch][max_keep]
+ * = decode slots in emission order, keep_det (nullable) [batch][max_keep][15] the kept records.
+ */
+size_t trtx_retina_nms_workspace(int batch, int net_h, int net_w);
+int32_t trtx_retina_nms(const float* decode_out, int batch, int net_h, int net_w, double conf_thresh, float nms_thresh,
+                        int max_keep, int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace,
+                        size_t workspace_bytes, trtx_stream_t stream);
+
+/* ---- R-CNN (detectron2-style) plugin chain ------------------------------------------------------ */
+/* rpnDecode (rcnn/RpnDecode.cu:27-143): stable descending sort of the A*h*w logits, top_n, anchor delta decode
+ * + clip; empty boxes get score -FLT_MAX.  scores [batch][A*h*w], deltas [batch][A*4*h*w] (CHW planes),
+ * anchors_host: host fp32 [A*4] (GenerateAnchors, rcnn.cpp:62-77). */
+size_t trtx_rpn_decode_workspace(int batch, int num_anchors, int height, int width);
+int32_t trtx_rpn_decode(int batch, const float* scores, const float* deltas, int height, int width, int image_height,
+                        int image_width, float stride, const float* anchors_host, int num_anchors, int top_n,
+                        float* out_scores, float* out_boxes, void* workspace, size_t workspace_bytes,
+                        trtx_stream_t stream);
+/* rpnNms (rcnn/RpnNms.cu:59-121): sort, exact greedy NMS (the reference kernel races across blocks), stable
+ * re-sort, first post_nms_topk boxes.  scores [batch][pre], boxes [batch][pre][4] -> out_boxes [batch][post][4] */
+size_t trtx_sorted_nms_workspace(int batch, int n);
+int32_t trtx_rpn_nms(int batch, const float* scores, const float* boxes, int pre_nms_topk, int post_nms_topk,
+                     float nms_thresh, float* out_boxes, void* workspace, size_t workspace_bytes,
+                     trtx_stream_t stream);
+/* roiAlign (rcnn/RoiAlign.cu:83-182): detectron2 ROIAlign(aligned=True), adaptive sampling when ratio == 0.
+ * boxes [batch][P][4], features [batch][C][fh][fw] -> out [batch][P][C][res][res] */
+int32_t trtx_roi_align(int batch, const float* boxes, const float* features, int pooler_resolution, float spatial_scale,
+                       int sampling_ratio, int num_proposals, int channels, int feature_h, int feature_w, float* out,
+                       trtx_stream_t stream);
+/* predictorDecode (rcnn/PredictorDecode.cu:24-110): sort N*C scores, top N (n, cls) pairs, weighted delta decode.
+ * The reference clips y2 with image_width (line 99); kept for parity. */
+size_t trtx_predictor_decode_workspace(int batch, int num_boxes, int num_classes);
+int32_t trtx_predictor_decode(int batch, const float* scores, const float* deltas, const float* proposals, int num_boxes,
+                              int num_classes, int image_height, int image_width, const float* bbox_reg_weights_host,
+                              float* out_scores, float* out_boxes, float* out_classes, void* workspace,
+                              size_t workspace_bytes, trtx_stream_t stream);
+/* batchedNms (rcnn/BatchedNms.cu:28-162): class-aware; method 0 hard, 1 soft-NMS linear (reference default,
+ * rcnn.cpp:59), 2 soft-NMS gaussian; workspace: trtx_sorted_nms_workspace(batch, count) */
+int32_t trtx_batched_nms(int nms_method, int batch, const float* scores, const float* boxes, const float* classes,
+                         int count, int detections_per_im, float nms_thresh, float* out_scores, float* out_boxes,
+                         float* out_classes, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+
 /* ---- single-kernel entry points (parity tests / micro-benchmarks) ----------------------------- */
 /* activation codes for the fused conv epilogue */
 #define TRTX_ACT_NONE 0

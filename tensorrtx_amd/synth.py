@@ -57,3 +57,51 @@ def images(batch, h=640, w=640, seed=0, n_rect=(8, 30)):
             col = rng.uniform(0.2, 1.0, size=(3, 1, 1)).astype(np.float32)
             img[b, :, y0:y0 + rh, x0:x0 + rw] = col + rng.normal(0, 0.03, size=(3, rh, rw)).astype(np.float32)
     return np.clip(img, 0.0, 1.0)
+
+
+def retina_head_tensors(batch, net_h, net_w, faces=200, seed=0):
+    """RetinaFace plugin inputs: list of [B, 32, h*w] fp32 for stride 8/16/32 =
+    bbox(2x4) | cls(2x2) | landmark(2x10) planes; cls pair difference ~ N(-5, 2^2), deltas ~ N(0, 1),
+    ~`faces` planted high-confidence anchors per image with clustered neighbours."""
+    rng = np.random.default_rng(seed)
+    outs = []
+    for s in (8, 16, 32):
+        h, w = net_h // s, net_w // s
+        x = rng.normal(0.0, 1.0, size=(batch, 32, h * w)).astype(np.float32)
+        diff = rng.normal(-5.0, 2.0, size=(batch, 2, h * w)).astype(np.float32)
+        base = rng.normal(0.0, 1.0, size=(batch, 2, h * w)).astype(np.float32)
+        x[:, 8] = base[:, 0]; x[:, 9] = base[:, 0] + diff[:, 0]      # k = 0: (conf1, conf2)
+        x[:, 10] = base[:, 1]; x[:, 11] = base[:, 1] + diff[:, 1]    # k = 1
+        outs.append(x)
+    for b in range(batch):
+        for _ in range(faces):
+            l = int(rng.integers(0, 3))
+            h, w = net_h // (8 << l), net_w // (8 << l)
+            cy, cx, k = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 2))
+            for dy, dx in ((0, 0), (0, 1), (1, 0)):
+                y, x_ = min(cy + dy, h - 1), min(cx + dx, w - 1)
+                e = y * w + x_
+                outs[l][b, 8 + 2 * k + 1, e] = outs[l][b, 8 + 2 * k, e] + rng.uniform(1.0, 6.0)
+                outs[l][b, 4 * k:4 * k + 4, e] = rng.normal(0, 0.3, size=4)
+    return outs
+
+
+def rcnn_rpn_tensors(batch, anchors=15, h=50, w=84, seed=0):
+    """RPN head outputs (C5): logits ~ N(0, 2^2) [B, A, h, w], deltas ~ N(0, 0.5^2) [B, 4A, h, w]."""
+    rng = np.random.default_rng(seed)
+    return (rng.normal(0, 2.0, size=(batch, anchors, h, w)).astype(np.float32),
+            rng.normal(0, 0.5, size=(batch, anchors * 4, h, w)).astype(np.float32))
+
+
+def rcnn_box_head_tensors(batch, n=1000, classes=80, img_h=800, img_w=1333, seed=0):
+    """Box-head outputs (C5): softmax scores from logits ~ N(0, 3^2) over classes+1 (background dropped),
+    deltas ~ N(0, 1) [B, N, C, 4], proposals = random boxes inside the image."""
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(0, 3.0, size=(batch, n, classes + 1))
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    scores = (e / e.sum(-1, keepdims=True))[..., :classes].astype(np.float32)
+    deltas = rng.normal(0, 1.0, size=(batch, n, classes, 4)).astype(np.float32)
+    x1 = rng.uniform(0, img_w - 40, size=(batch, n)); y1 = rng.uniform(0, img_h - 40, size=(batch, n))
+    bw = rng.uniform(8, 300, size=(batch, n)); bh = rng.uniform(8, 300, size=(batch, n))
+    props = np.stack([x1, y1, np.minimum(x1 + bw, img_w), np.minimum(y1 + bh, img_h)], -1).astype(np.float32)
+    return scores, deltas, props
