@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import yolo_post
+from . import det_post, yolo_post
 
 (L_INPUT, L_CONV, L_DECONV, L_ACTIVATION, L_POOLING, L_SCALE, L_ELEMENTWISE, L_CONCAT, L_SLICE, L_SHUFFLE, L_RESIZE,
  L_SOFTMAX, L_FC, L_MATMUL, L_CONSTANT, L_REDUCE, L_PLUGIN, L_IDENTITY) = range(18)
@@ -169,5 +169,11 @@ def _plugin(l, ins, batch):
         strides = [int(v) for v in np.frombuffer(blob, dtype=np.int32, count=ns, offset=32)]
         arrs = [np.ascontiguousarray(t.numpy().reshape(batch, 4 + classes, -1)) for t in ins]
         out = yolo_post.decode_c(arrs, classes, net_h, net_w, strides, max_out)
+        return [torch.from_numpy(out).reshape(batch, -1, 1, 1)]
+    if l["plugin_type"] == "Decode_TRT":
+        # blob: int net_h, int net_w (our extension of the reference's empty blob, decode.cu:19-26)
+        net_h, net_w = (int(v) for v in np.frombuffer(blob, dtype=np.int32, count=2))
+        arrs = [np.ascontiguousarray(t.numpy().reshape(batch, 32, -1)) for t in ins]
+        out = det_post.retina_decode(arrs, net_h, net_w)
         return [torch.from_numpy(out).reshape(batch, -1, 1, 1)]
     raise NotImplementedError(l["plugin_type"])

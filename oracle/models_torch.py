@@ -51,8 +51,8 @@ class Params:
     def vec(self, name, n, init):
         return self._get(name, (n,), init)
 
-    def bn(self, prefix, c):
-        w = self.vec(prefix + ".weight", c, lambda: 0.9 + 0.2 * self.rand(c))
+    def bn(self, prefix, c, gamma_scale=1.0):
+        w = self.vec(prefix + ".weight", c, lambda: gamma_scale * (0.9 + 0.2 * self.rand(c)))
         b = self.vec(prefix + ".bias", c, lambda: 0.1 * self.randn(c))
         m = self.vec(prefix + ".running_mean", c, lambda: 0.1 * self.randn(c))
         v = self.vec(prefix + ".running_var", c, lambda: 0.8 + 0.4 * self.rand(c))
@@ -210,6 +210,65 @@ def yolov8_det(p: Params, x, num_class=80, gd=0.33, gw=0.25, max_channels=1024, 
         t = F.conv2d(F.softmax(t, dim=1), dfl_w).reshape(-1, 4, g)
         outs.append(torch.cat([t, clsp], 1).contiguous())
     return outs, strides
+
+
+# ---------------------------------------------------------------------------------------- RetinaFace-R50
+def retinaface_r50(p: Params, x, head_gain=0.5):
+    """retinaface/retina_r50.cpp:100-212.  Returns the three [B, 32, h, w] plugin inputs
+    (bbox 8 | class 4 | landmark 20) for stride 8/16/32."""
+    eps = 1e-5
+
+    def conv_bn(x, cname, bname, cout, k, s, pad):
+        y = F.conv2d(x, p.conv_w(cname + ".weight", cout, x.shape[1], k), None, stride=s, padding=pad)
+        # synthetic weights: a small gamma on the last BN of every residual branch keeps activations O(1-10)
+        # through 16 bottlenecks so that fp16 storage (and the exp() in the decode) stay in range
+        return _bn_eval(y, p.bn(bname, cout, 0.25 if bname.endswith("bn3") else 1.0), eps)
+
+    def bottleneck(x, inch, outch, stride, l):
+        a = F.relu(conv_bn(x, l + "conv1", l + "bn1", outch, 1, 1, 0))
+        b = F.relu(conv_bn(a, l + "conv2", l + "bn2", outch, 3, stride, 1))
+        c = conv_bn(b, l + "conv3", l + "bn3", outch * 4, 1, 1, 0)
+        sc = x
+        if stride != 1 or inch != outch * 4:
+            sc = conv_bn(x, l + "downsample.0", l + "downsample.1", outch * 4, 1, stride, 0)
+        return F.relu(sc + c)
+
+    def cbr(x, cout, k, pad, relu, name):  # conv_bn_relu :70-85
+        y = conv_bn(x, name + ".0", name + ".1", cout, k, 1, pad)
+        return F.relu(y) if relu else y
+
+    def ssh(x, l):  # :87-98
+        c3 = cbr(x, 128, 3, 1, False, l + ".conv3X3")
+        c5a = cbr(x, 64, 3, 1, True, l + ".conv5X5_1")
+        c5 = cbr(c5a, 64, 3, 1, False, l + ".conv5X5_2")
+        c7 = cbr(cbr(c5a, 64, 3, 1, True, l + ".conv7X7_2"), 64, 3, 1, False, l + ".conv7x7_3")
+        return F.relu(torch.cat([c3, c5, c7], 1))
+
+    y = F.relu(conv_bn(x, "body.conv1", "body.bn1", 64, 7, 2, 3))
+    y = F.max_pool2d(y, 3, 2, 1)
+    inch = 64
+    stages = []
+    for stage, nblk in enumerate((3, 4, 6, 3)):
+        width = 64 << stage
+        for b in range(nblk):
+            y = bottleneck(y, inch, width, 2 if (b == 0 and stage > 0) else 1, f"body.layer{stage + 1}.{b}.")
+            inch = width * 4
+        stages.append(y)
+    o1 = cbr(stages[1], 256, 1, 0, True, "fpn.output1")
+    o2 = cbr(stages[2], 256, 1, 0, True, "fpn.output2")
+    o3 = cbr(stages[3], 256, 1, 0, True, "fpn.output3")
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")  # grouped 2x2/2 deconv of ones, :157-166  # noqa: E731
+    o2 = cbr(o2 + up(o3), 256, 3, 1, True, "fpn.merge2")
+    o1 = cbr(o1 + up(o2), 256, 3, 1, True, "fpn.merge1")
+    outs = []
+    for l, f in enumerate((ssh(o1, "ssh1"), ssh(o2, "ssh2"), ssh(o3, "ssh3"))):
+        parts = []
+        for name, ch in (("BboxHead", 8), ("ClassHead", 4), ("LandmarkHead", 20)):
+            w = p.conv_w(f"{name}.{l}.conv1x1.weight", ch, 256, 1, gain=head_gain)
+            b = p.vec(f"{name}.{l}.conv1x1.bias", ch, lambda ch=ch: 0.1 * p.randn(ch))
+            parts.append(F.conv2d(f, w, b))
+        outs.append(torch.cat(parts, 1).contiguous())
+    return outs
 
 
 def make_weights(model_fn, example_input, seed=0, **kw):

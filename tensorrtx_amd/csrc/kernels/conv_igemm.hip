@@ -194,6 +194,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
     constexpr int CHUNKS_PER_ROW = BN / 8;
     constexpr int TOTAL_CHUNKS = BM * CHUNKS_PER_ROW;
+    if (p.scalar_out) {
+        // ragged channel counts / unaligned channel slices (e.g. 4-, 8-, 20-channel detection heads written
+        // side by side into one concat buffer): element-wise stores with bounds checks
+        for (int id = tid; id < BM * BN; id += 256) {
+            const int row = id / BN;
+            const int col = id - row * BN;
+            const int m = m0 + row;
+            const int co = n0 + col;
+            if (m < p.M && co < p.Cout) {
+                float v = (float)Cs[row * C_ROW + col];
+                if (res || p.act2 != ACT_NONE) {
+                    const float rv = res ? (float)res[(size_t)m * p.ld_res + co] : 0.f;
+                    v = apply_act(v + rv, p.act2, p.alpha2);
+                }
+                out[(size_t)m * p.ld_out + co] = (_Float16)v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int id = tid; id < TOTAL_CHUNKS; id += 256) {
         const int row = id / CHUNKS_PER_ROW;
@@ -234,8 +253,8 @@ int conv_igemm_pick_bn(int cout) {
 }
 
 bool conv_igemm_supported(const ConvArgs& a) {
-    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.ld_out % 8 == 0 && a.Cout % 8 == 0 && a.groups == 1 &&
-           a.Kpad % BK == 0 && (!a.residual || a.ld_res % 8 == 0);
+    const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
+    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.Kpad % BK == 0 && (out_vec || a.scalar_out);
 }
 
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s) {

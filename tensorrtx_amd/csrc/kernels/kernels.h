@@ -28,6 +28,7 @@ struct ConvArgs {
     int act1, act2;
     float alpha1, alpha2;
     int bn;  // igemm column-tile width (16/32/64/80/128)
+    int scalar_out;  // igemm: element-wise epilogue stores (Cout, channel stride or offset not a multiple of 8)
 };
 
 // --- conv -------------------------------------------------------------------------------------------

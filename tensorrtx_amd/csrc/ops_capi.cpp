@@ -78,6 +78,7 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.Kpad = (a.K + 31) / 32 * 32;
     a.M = N * a.Ho * a.Wo;
     a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
+    a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
     return conv_igemm_f16(a, stream);
 }
 

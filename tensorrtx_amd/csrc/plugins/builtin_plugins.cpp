@@ -171,6 +171,95 @@ int32_t yolo_deserialize(void*, const char*, const void* data, size_t len, trtx_
 const char* yolo_creator_name(void*) { return "YoloLayer_TRT"; }
 const char* yolo_creator_version(void*) { return "1"; }
 
+// ------------------------------------------------------------------------------------------------
+// "Decode_TRT"/"1" — retinaface/decode.{h,cu}.  The reference fixes INPUT_H/W at compile time and serializes
+// nothing (decode.cu:19-26); here the network size is learnt in configurePlugin from the stride-8 input
+// (32, H/8, W/8) and stored in the blob as two ints so 1280x1280 engines deserialize without recompiling
+// (SURVEY.md Appendix A.9).  An empty blob means the reference's 480x640.
+struct RetinaDecode {
+    int net_h = 480, net_w = 640;
+};
+void rdec_fill(trtx_plugin_vtbl* v, RetinaDecode* d);
+int32_t rdec_nb_outputs(void*) { return 1; }
+int32_t rdec_output_dims(void*, int32_t, const trtx_dims* in, int32_t nb, trtx_dims* out) {
+    if (nb != 3 || in[0].nb != 3) return 1;
+    const int64_t h = in[0].d[1] * 8, w = in[0].d[2] * 8;
+    out->nb = 3;  // Dims3(totalCount, 1, 1), decode.cu:33-42
+    out->d[0] = (int64_t)trtx_retina_decode_output_floats((int)h, (int)w);
+    out->d[1] = 1;
+    out->d[2] = 1;
+    return 0;
+}
+int32_t rdec_configure(void* s, const trtx_dims* in, int32_t nb_in, const trtx_dims*, int32_t, int32_t) {
+    auto* d = static_cast<RetinaDecode*>(s);
+    if (nb_in != 3) return 1;
+    d->net_h = (int)in[0].d[1] * 8;
+    d->net_w = (int)in[0].d[2] * 8;
+    for (int l = 0; l < 3; ++l)
+        if (in[l].nb != 3 || in[l].d[0] != 32 || in[l].d[1] != d->net_h / (8 << l) || in[l].d[2] != d->net_w / (8 << l)) return 1;
+    return 0;
+}
+int32_t rdec_initialize(void*) { return 0; }
+void rdec_terminate(void*) {}
+size_t rdec_workspace(void* s, int32_t max_batch) {
+    auto* d = static_cast<RetinaDecode*>(s);
+    return trtx_retina_decode_workspace(max_batch, d->net_h, d->net_w);
+}
+int32_t rdec_enqueue(void* s, int32_t batch, const void* const* inputs, void* const* outputs, void* ws, trtx_stream_t stream) {
+    auto* d = static_cast<RetinaDecode*>(s);
+    return trtx_retina_decode(reinterpret_cast<const float* const*>(inputs), batch, d->net_h, d->net_w,
+                              static_cast<float*>(outputs[0]), ws, trtx_retina_decode_workspace(batch, d->net_h, d->net_w), stream);
+}
+size_t rdec_ser_size(void*) { return 2 * sizeof(int); }
+void rdec_serialize(void* s, void* buf) {
+    auto* d = static_cast<RetinaDecode*>(s);
+    const int v[2] = {d->net_h, d->net_w};
+    memcpy(buf, v, sizeof v);
+}
+const char* rdec_type(void*) { return "Decode_TRT"; }
+const char* rdec_version(void*) { return "1"; }
+int32_t rdec_clone(void* s, trtx_plugin_vtbl* out) {
+    rdec_fill(out, new RetinaDecode(*static_cast<RetinaDecode*>(s)));
+    return 0;
+}
+void rdec_destroy(void* s) { delete static_cast<RetinaDecode*>(s); }
+void rdec_fill(trtx_plugin_vtbl* v, RetinaDecode* d) {
+    v->self = d;
+    v->get_nb_outputs = rdec_nb_outputs;
+    v->get_output_dims = rdec_output_dims;
+    v->configure = rdec_configure;
+    v->initialize = rdec_initialize;
+    v->terminate = rdec_terminate;
+    v->workspace_size = rdec_workspace;
+    v->enqueue = rdec_enqueue;
+    v->serialization_size = rdec_ser_size;
+    v->serialize = rdec_serialize;
+    v->plugin_type = rdec_type;
+    v->plugin_version = rdec_version;
+    v->clone = rdec_clone;
+    v->destroy = rdec_destroy;
+}
+int32_t rdec_create(void*, const char*, const trtx_plugin_field*, int32_t, trtx_plugin_vtbl* out) {  // empty field collection, retina_r50.cpp:204-206
+    rdec_fill(out, new RetinaDecode());
+    return 0;
+}
+int32_t rdec_deserialize(void*, const char*, const void* data, size_t len, trtx_plugin_vtbl* out) {
+    auto* d = new RetinaDecode();
+    if (len == 2 * sizeof(int)) {
+        int v[2];
+        memcpy(v, data, sizeof v);
+        d->net_h = v[0];
+        d->net_w = v[1];
+    } else if (len != 0) {
+        delete d;
+        return 1;
+    }
+    rdec_fill(out, d);
+    return 0;
+}
+const char* rdec_creator_name(void*) { return "Decode_TRT"; }
+const char* rdec_creator_version(void*) { return "1"; }
+
 }  // namespace
 
 bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
@@ -192,6 +281,12 @@ void register_builtin_plugins(PluginRegistry& r) {
     c.create = yolo_create;
     c.deserialize = yolo_deserialize;
     r.add(c);
+    trtx_creator_vtbl d{};
+    d.plugin_name = rdec_creator_name;
+    d.plugin_version = rdec_creator_version;
+    d.create = rdec_create;
+    d.deserialize = rdec_deserialize;
+    r.add(d);
 }
 
 }  // namespace trtx

@@ -109,7 +109,7 @@ bool Network::infer(int li) {
             const Dims& x = in(0);
             if (x.nb < 3) return fail(this, l.name + ": needs a CHW tensor");
             Dims o = x;
-            const int c = x.nb - 3, h = x.nb - 2, w = x.nb - 1;
+            const int c = x.nb - 3, h = x.nb - 2;
             for (int a = 0; a < 2; ++a) {
                 const int64_t sz = x.d[h + a];
                 int64_t r;

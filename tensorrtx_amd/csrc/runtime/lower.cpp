@@ -73,6 +73,7 @@ struct Lowerer {
     std::vector<FusedConv> groups;
     std::vector<YoloHeadFuse> yolo_heads;
     std::vector<int> yolo_at;
+    std::vector<std::pair<int, int>> aliases;  // (dst network tensor, src network tensor): dst is the same data as src
     std::string err;
 
     Lowerer(const Network& n, Plan& p) : net(n), plan(p) {
@@ -207,8 +208,9 @@ struct Lowerer {
         PTensor& t = plan.tensors[top];
         const PTensor& c = plan.tensors[child];
         if (t.layout != LAY_NHWC) return false;
-        // only a whole, un-padded, freely placeable owner may move (a padded owner would spill into its neighbour)
-        if (off != 0 || c.C != t.C || t.C != t.Calloc || t.pad_zeroed || is_binding_tensor(top)) return false;
+        // only a whole, freely placeable owner may move.  Every producer writes exactly C channels (ragged channel
+        // counts take the element-wise store paths), except the layout pass that zero-fills its padding.
+        if (off != 0 || c.C != t.C || t.pad_zeroed || is_binding_tensor(top)) return false;
         if (owner_of(parent, nullptr) == top) return false;  // would create a cycle
         t.parent = parent;
         t.coff = coff;
@@ -293,6 +295,35 @@ struct Lowerer {
             absorbed[li] = true;
             group_at[last] = (int)groups.size();
             groups.push_back(g);
+        }
+        // Activation applied to a concatenation of un-activated convolution outputs (RetinaFace SSH,
+        // retina_r50.cpp:87-98): relu(cat(a, b, c)) == cat(relu a, relu b, relu c), so the activation moves into
+        // the producers' epilogues and the concat output is used as is.
+        for (size_t li = 0; li < net.layers.size(); ++li) {
+            const LayerDef& l = net.layers[li];
+            if (l.kind != L_CONCAT || absorbed[li]) continue;
+            int nx;
+            if (!sole_consumer(l.outputs[0], &nx) || absorbed[nx] || net.layers[nx].kind != L_ACTIVATION) continue;
+            const int code = act_code(net.layers[nx].op);
+            if (code < 0) continue;
+            std::vector<int> gs;
+            bool ok = true;
+            for (int t : l.inputs) {
+                int gi = -1;
+                for (size_t k = 0; k < groups.size(); ++k)
+                    if (groups[k].out_tensor == t) gi = (int)k;
+                int only;
+                ok = ok && gi >= 0 && groups[gi].act1 == ACT_NONE && groups[gi].residual < 0 && groups[gi].act2 == ACT_NONE &&
+                     sole_consumer(t, &only) && only == (int)li;
+                gs.push_back(gi);
+            }
+            if (!ok) continue;
+            for (int gi : gs) {
+                groups[gi].act1 = code;
+                groups[gi].alpha1 = net.layers[nx].alpha;
+            }
+            absorbed[nx] = true;
+            aliases.push_back({net.layers[nx].outputs[0], l.outputs[0]});
         }
     }
 
@@ -864,6 +895,11 @@ struct Lowerer {
         return true;
     }
 
+    void apply_aliases() {
+        for (auto& a : aliases)
+            if (pt_of[a.first] < 0 && pt_of[a.second] >= 0) pt_of[a.first] = pt_of[a.second];
+    }
+
     // ---- driver ----------------------------------------------------------------------------------------
     bool run() {
         plan.explicit_batch = net.explicit_batch;
@@ -893,8 +929,12 @@ struct Lowerer {
                 if (!emit_conv(groups[group_at[li]])) return false;
                 continue;
             }
-            if (absorbed[li]) continue;
+            if (absorbed[li]) {
+                apply_aliases();
+                continue;
+            }
             if (!emit_layer((int)li)) return false;
+            apply_aliases();
         }
         // output bindings: LINEAR fp32
         for (int t : net.output_ids()) {
@@ -972,8 +1012,7 @@ struct Lowerer {
             a.Cout_pad = a.Cout;
             a.Kpad = a.K;
             op.igemm = false;
-            if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.Cout % 8 == 0 &&
-                a.Cout >= 16) {
+            if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
                 int cin_eff = a.Cin;
                 bool ok = true;
                 if (cin_eff % 8) {
@@ -982,13 +1021,18 @@ struct Lowerer {
                     ok = ti.parent < 0 && own.pad_zeroed;
                     cin_eff = (a.Cin + 7) / 8 * 8;
                 }
-                ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
+                ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0;
+                // output side: 16-byte stores when everything is a multiple of 8, element-wise stores otherwise
+                bool vec_out = a.Cout % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
                 if (op.in.size() > 1) {
                     const PTensor& tr = plan.tensors[op.in[1]];
-                    ok = ok && tr.rcoff % 8 == 0 && tr.ld % 8 == 0;
+                    vec_out = vec_out && tr.rcoff % 8 == 0 && tr.ld % 8 == 0;
                 }
+                // tiny reductions (K < 32, e.g. the DFL 1x1) stay on the direct kernel
+                ok = ok && a.kh * a.kw * cin_eff >= 32;
                 if (ok) {
                     op.igemm = true;
+                    a.scalar_out = vec_out ? 0 : 1;
                     a.Cin = cin_eff;
                     a.K = a.kh * a.kw * a.Cin;
                     a.Kpad = (a.K + 31) / 32 * 32;

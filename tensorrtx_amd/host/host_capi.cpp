@@ -39,6 +39,9 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
     } else if (m == "resnet50") {
         plan.reset(trtx_host::buildResnet50(builder.get(), config.get(), wts_path, geti(o, "batch", 1), geti(o, "fp16", 1) != 0,
                                             geti(o, "h", 224), geti(o, "w", 224)));
+    } else if (m == "retinaface_r50") {
+        plan.reset(trtx_host::buildRetinaFaceR50(builder.get(), config.get(), wts_path, geti(o, "batch", 1), geti(o, "fp16", 1) != 0,
+                                                 geti(o, "h", 480), geti(o, "w", 640)));
     } else if (m == "yolov8n") {
         trtx_host::Yolov8Config cfg;
         cfg.max_batch = geti(o, "batch", 1);

@@ -16,6 +16,10 @@ nvinfer1::IHostMemory* buildLenet(nvinfer1::IBuilder* builder, nvinfer1::IBuilde
 nvinfer1::IHostMemory* buildResnet50(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config, const std::string& wts,
                                      int maxBatch, bool fp16, int H = 224, int W = 224);
 
+// retinaface/retina_r50.cpp:100-242
+nvinfer1::IHostMemory* buildRetinaFaceR50(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config, const std::string& wts,
+                                          int maxBatch, bool fp16, int H = 480, int W = 640);
+
 struct Yolov8Config {
     int input_h = 640, input_w = 640;   // kInputH / kInputW
     int num_class = 80;                 // kNumClass

@@ -198,3 +198,57 @@ def test_engine_decode_then_nms_pipeline(gpu):
     for b in range(8):
         assert np.array_equal(ki[b, :rc[b]].cpu().numpy(), ri[b, :rc[b]])
     e.close()
+
+
+def _retina_match(dec, ref, conf_margin=0.01):
+    """Match decoded anchors between engine and oracle buffers (both in canonical anchor order): anchors whose
+    oracle confidence is not within `conf_margin` of the 0.02 cut must appear with nearly identical boxes."""
+    stats = dict(ref=0, matched=0, max_box_err=0.0, max_conf_err=0.0)
+    for b in range(ref.shape[0]):
+        nr, ng = int(ref[b, 0]), int(dec[b, 0])
+        R = ref[b, 1:1 + nr * 15].reshape(nr, 15)
+        G = dec[b, 1:1 + ng * 15].reshape(ng, 15)
+        j = 0
+        for r in R:
+            if abs(r[4] - 0.02) < conf_margin:
+                continue
+            stats["ref"] += 1
+            # both lists are ordered by anchor; advance until the landmark-0 x coordinate (an affine function of the
+            # anchor position) is close
+            best = None
+            for jj in range(j, min(j + 8, ng)):
+                if np.abs(G[jj, :4] - r[:4]).max() < 2.0:
+                    best = jj
+                    break
+            if best is None:
+                continue
+            j = best + 1
+            stats["matched"] += 1
+            stats["max_box_err"] = max(stats["max_box_err"], float(np.abs(G[best, :4] - r[:4]).max()))
+            stats["max_conf_err"] = max(stats["max_conf_err"], float(abs(G[best, 4] - r[4])))
+    return stats
+
+
+@pytest.mark.parametrize("hw,batch", [((256, 320), 2), ((1280, 1280), 1)])
+def test_retinaface_r50_fp16_engine(gpu, hw, batch):
+    """Config 4: R50 body + FPN (deconv-as-upsample) + SSH + heads + Decode_TRT plugin, fp16, vs the fp32 oracle."""
+    from oracle import det_post as dp
+    H, W = hw
+    path, _ = synth_wts("retinaface_r50")
+    plan = engine.build_plan("retinaface_r50", path, batch=batch, fp16=1, h=H, w=W)
+    x = (torch.from_numpy(synth.images(batch, H, W, seed=2)) * 255 - 110) / 64
+    out = _run(plan, {"data": x.numpy()}, batch, gpu)["prob"].reshape(batch, -1).numpy()
+    with torch.inference_mode():
+        heads = mt.retinaface_r50(mt.Params(owts.load_wts(path)), x)
+    ref = dp.retina_decode([h.reshape(batch, 32, -1).numpy() for h in heads], H, W)
+    st = _retina_match(out, ref)
+    _metric("retinaface_r50_fp16", hw=list(hw), counts=out[:, 0].tolist(), ref_counts=ref[:, 0].tolist(), **st)
+    assert st["ref"] > 100 and st["matched"] >= 0.97 * st["ref"]
+    assert st["max_box_err"] < 1.0 and st["max_conf_err"] < 0.05
+    # device NMS on the engine's own decode buffer == oracle NMS of the same buffer
+    from tensorrtx_amd import det_ops
+    gi_, gc_, _ = det_ops.retina_nms(torch.from_numpy(out).to(gpu), H, W)
+    ri_, rc_ = dp.retina_nms(out)
+    assert np.array_equal(gc_.cpu().numpy(), rc_)
+    for b in range(batch):
+        assert np.array_equal(gi_.cpu().numpy()[b, :rc_[b]], ri_[b, :rc_[b]])

@@ -161,3 +161,32 @@ def test_invalid_network_fails_at_build_time(tmp_path):
     wts_writer.write_wts(p, bad)
     with pytest.raises(capi.TrtxError):
         engine.build_plan("lenet", p, batch=1)
+
+
+def test_retinaface_builder_matches_pytorch_restatement():
+    from oracle import det_post as dp
+    path, _ = synth_wts("retinaface_r50")
+    plan = engine.build_plan("retinaface_r50", path, batch=2, fp16=1, h=128, w=160)
+    desc = engine.describe_plan(plan)
+    x = (torch.from_numpy(synth.images(2, 128, 160, seed=2)) * 255 - 110) / 64
+    out = gi.run(desc, plan, {"data": x.numpy()})["prob"].reshape(2, -1).numpy()
+    with torch.inference_mode():
+        heads = mt.retinaface_r50(mt.Params(owts.load_wts(path)), x)
+    dec = dp.retina_decode([h.reshape(2, 32, -1).numpy() for h in heads], 128, 160)
+    assert np.array_equal(out[:, 0], dec[:, 0]) and dec[:, 0].min() > 50
+    n = int(dec[0, 0])
+    assert np.allclose(out[0, 1:1 + n * 15], dec[0, 1:1 + n * 15], rtol=1e-3, atol=1e-2)
+
+
+def test_retinaface_lowering_at_config4_size():
+    path, _ = synth_wts("retinaface_r50")
+    plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280)
+    low = engine.describe_plan(plan, lowered=True)
+    kinds = [o["kind"] for o in low["ops"]]
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert len(convs) == 82 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 81
+    assert abs(low["flops_per_sample"] / 1e9 - 354.0) < 1.0          # 354 GFLOP @1280^2
+    assert "copy_nhwc" not in kinds and "act_nhwc" not in kinds      # SSH ReLU pushed into the conv epilogues, heads aliased
+    assert kinds.count("deconv") == 2 and kinds.count("plugin") == 1
+    plug = [l for l in engine.describe_plan(plan)["layers"] if l["kind"] == 16][0]
+    assert np.frombuffer(bytes.fromhex(plug["plugin_blob"]), dtype=np.int32).tolist() == [1280, 1280]

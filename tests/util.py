@@ -9,17 +9,19 @@ from oracle import models_torch as mt
 from tensorrtx_amd import wts as wts_writer
 
 CACHE = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
+WTS_VERSION = {"retinaface_r50": 2}  # bump when a model's synthetic initialisation changes (cache key)
 
 
 def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
     """Create (once) the seeded synthetic weights of `model`; returns (path, OrderedDict of tensors)."""
     os.makedirs(CACHE, exist_ok=True)
-    tag = hashlib.sha1(repr((model, seed, dialect, sorted(kw.items()))).encode()).hexdigest()[:12]
+    tag = hashlib.sha1(repr((model, seed, dialect, sorted(kw.items()), WTS_VERSION.get(model, 1))).encode()).hexdigest()[:12]
     path = os.path.join(CACHE, f"{model}_{tag}.wts")
     fn, x = {
         "lenet": (mt.lenet, torch.zeros(1, 1, 32, 32)),
         "resnet50": (mt.resnet50, torch.zeros(1, 3, 64, 64)),
         "yolov8n": (mt.yolov8_det, torch.zeros(1, 3, 64, 64)),
+        "retinaface_r50": (mt.retinaface_r50, torch.zeros(1, 3, 64, 64)),
     }[model]
     tensors, _ = mt.make_weights(fn, x, seed=seed, **kw)
     if not os.path.exists(path):
