@@ -13,7 +13,7 @@
 // Tile: 128 pixels x (16*NFRAG) channels x 32 k per step; 4 waves, wave w owns pixel rows
 // [32w, 32w+32) x all columns (2 x NFRAG accumulator fragments).  Global loads for step t+1 are
 // issued before the MFMAs of step t and written to the other LDS buffer afterwards (one barrier
-// per step).  LDS rows are 80 B (64 B of data + 16 B pad) to spread ds_read_b128 over the banks.
+// per step).  LDS rows are 64 B with an XOR chunk swizzle so fragment reads are bank-conflict free.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,13 +29,19 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDS_ROW = 40;  // halfs per LDS row (32 data + 8 pad)
+constexpr int LDS_ROW = 32;  // halfs per LDS row: 64 B, un-padded; the four 16-byte chunks of a row are XOR-swizzled
+
+// chunk permutation that makes ds_read_b128 of an MFMA fragment (16 rows x one chunk per 16-lane service group, see the
+// group table in MI355X_MICROARCH.md) hit 16 distinct 16-byte slots: physical chunk = logical chunk ^ P[(row >> 2) & 3]
+__device__ __forceinline__ int swz(int row) {
+    return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;  // P = {0, 2, 3, 1}
+}
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     switch (act) {
         case ACT_RELU: return v > 0.f ? v : 0.f;
-        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-        case ACT_SILU: return v / (1.0f + __expf(-v));
+        case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // v_exp + v_rcp (1 ulp), rounded to fp16 afterwards
         case ACT_LEAKY: return v > 0.f ? v : v * alpha;
         case ACT_TANH: return tanhf(v);
         default: return v;
@@ -47,10 +53,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
     constexpr int BN = 16 * NFRAG;
     constexpr int A_TILE = BM * LDS_ROW;  // halfs
     constexpr int B_TILE = BN * LDS_ROW;
-    constexpr int C_ROW = BN + 8;  // halfs per row of the epilogue staging tile
-    constexpr int MAIN_HALFS = 2 * (A_TILE + B_TILE);
-    constexpr int EPI_HALFS = BM * C_ROW;
-    constexpr int SMEM_HALFS = MAIN_HALFS > EPI_HALFS ? MAIN_HALFS : EPI_HALFS;
+    constexpr int SMEM_HALFS = 2 * (A_TILE + B_TILE);
     __shared__ __attribute__((aligned(16))) _Float16 smem[SMEM_HALFS];
     _Float16* As = smem;
     _Float16* Bs = smem + 2 * A_TILE;
@@ -64,9 +67,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
     const _Float16* __restrict__ wgt = static_cast<const _Float16*>(p.wgt);
 
     // ---- per-thread A-gather state: rows (tid>>2) and (tid>>2)+64, k-chunk (tid&3) --------------
+    // Address generation is kept off the vector ALU as far as possible (it, not the MFMA pipe, was the busiest
+    // unit of the first version): each thread precomputes one pointer per row; the filter tap (r, q) and the
+    // channel offset of a k-tile are wave-uniform, so their offset is a scalar added per step.
     const int kc = tid & 3;
     int a_hi0[2], a_wi0[2];
-    long a_base[2];
+    const _Float16* a_ptr[2];
     bool a_ok[2];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -80,9 +86,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
         const int wo = rem - ho * p.Wo;
         a_hi0[i] = ho * p.stride_h - p.pad_h;
         a_wi0[i] = wo * p.stride_w - p.pad_w;
-        a_base[i] = (long)n * p.H * p.W;
+        // pointer to (n, hi0, wi0, channel kc*8); may lie outside the tensor for border pixels, it is only
+        // dereferenced after the bounds test
+        a_ptr[i] = in + (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.ld_in + kc * 8;
     }
-    // (r, q, c) of this thread's chunk for the current k-tile
+    constexpr int B_PASSES = (BN + 63) / 64;
+    const _Float16* b_ptr = wgt + (size_t)(n0 + (tid >> 2)) * p.Kpad + kc * 8;  // pass j adds 64*j rows
+    const bool uniform_taps = (p.Cin % BK) == 0;  // every k-tile lies inside one filter tap
+    // wave-uniform position of the current k-tile: tap (ur, uq), first channel uc
+    int ur = 0, uq = 0, uc = 0;
+    // per-thread position (general path: Cin % 32 != 0, a k-tile may straddle taps)
     int kr, kq, kcin;
     {
         const int k = kc * 8;
@@ -91,50 +104,68 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
         kr = tap / p.kw;
         kq = tap - kr * p.kw;
     }
-    // B rows handled by this thread: (tid>>2) + 64*j
-    constexpr int B_PASSES = (BN + 63) / 64;
 
     uint4 a_reg[2];
     uint4 b_reg[B_PASSES];
     const int nk = p.Kpad / BK;
 
     auto load_tile = [&](int kt) {
+        if (uniform_taps) {
+            const int toff = (ur * p.dil_h * p.W + uq * p.dil_w) * p.ld_in + uc;  // scalar
+            const bool tap_ok = ur < p.kh;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int hi = a_hi0[i] + kr * p.dil_h;
-            const int wi = a_wi0[i] + kq * p.dil_w;
-            const bool ok = a_ok[i] && kr < p.kh && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = *reinterpret_cast<const uint4*>(in + ((a_base[i] + (long)hi * p.W + wi) * p.ld_in + kcin));
-            a_reg[i] = v;
+            for (int i = 0; i < 2; ++i) {
+                const int hi = a_hi0[i] + ur * p.dil_h;
+                const int wi = a_wi0[i] + uq * p.dil_w;
+                const bool ok = a_ok[i] && tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + toff);
+                a_reg[i] = v;
+            }
+            uc += BK;
+            if (uc >= p.Cin) {
+                uc = 0;
+                if (++uq == p.kw) {
+                    uq = 0;
+                    ++ur;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hi = a_hi0[i] + kr * p.dil_h;
+                const int wi = a_wi0[i] + kq * p.dil_w;
+                const bool ok = a_ok[i] && kr < p.kh && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + ((long)(kr * p.dil_h) * p.W + kq * p.dil_w) * p.ld_in + kcin - kc * 8);
+                a_reg[i] = v;
+            }
+            kcin += BK;
+            while (kcin >= p.Cin) {
+                kcin -= p.Cin;
+                if (++kq == p.kw) {
+                    kq = 0;
+                    ++kr;
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
-            const int row = (tid >> 2) + 64 * j;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row < BN) v = *reinterpret_cast<const uint4*>(wgt + (size_t)(n0 + row) * p.Kpad + kt * BK + kc * 8);
+            if ((tid >> 2) + 64 * j < BN) v = *reinterpret_cast<const uint4*>(b_ptr + (size_t)(64 * j) * p.Kpad + kt * BK);
             b_reg[j] = v;
-        }
-        // advance (r, q, c) to the next k-tile
-        kcin += BK;
-        while (kcin >= p.Cin) {
-            kcin -= p.Cin;
-            if (++kq == p.kw) {
-                kq = 0;
-                ++kr;
-            }
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (tid >> 2) + 64 * i;
-            *reinterpret_cast<uint4*>(As + buf * A_TILE + row * LDS_ROW + kc * 8) = a_reg[i];
+            *reinterpret_cast<uint4*>(As + buf * A_TILE + row * LDS_ROW + (kc ^ swz(row)) * 8) = a_reg[i];
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
             const int row = (tid >> 2) + 64 * j;
-            if (row < BN) *reinterpret_cast<uint4*>(Bs + buf * B_TILE + row * LDS_ROW + kc * 8) = b_reg[j];
+            if (row < BN) *reinterpret_cast<uint4*>(Bs + buf * B_TILE + row * LDS_ROW + (kc ^ swz(row)) * 8) = b_reg[j];
         }
     };
 
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
     __syncthreads();
 
     const int frag_row = lane & 15;
-    const int frag_k = (lane >> 4) * 8;
+    const int frag_k = ((lane >> 4) ^ swz(frag_row)) * 8;  // tile bases are multiples of 16 rows: swz depends on the lane only
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
@@ -162,72 +193,62 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
         for (int j = 0; j < NFRAG; ++j) {
             const half8 bf = *reinterpret_cast<const half8*>(Bb + j * 16 * LDS_ROW);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);  // D^T: rows = channels
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: bias + act1 -> fp16 staging tile in LDS (C/D map: col = lane&15, row = (lane>>4)*4 + r)
-    _Float16* Cs = smem;
-    {
-        const int col_in = lane & 15;
-        const int row_in = (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
-            const int col = j * 16 + col_in;
-            const float bias = p.bias ? p.bias[n0 + col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * 32 + i * 16 + row_in + r;
-                    const float v = apply_act(acc[i][j][r] + bias, p.act1, p.alpha1);
-                    Cs[row * C_ROW + col] = (_Float16)v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- coalesced 16-byte stores (+ residual, act2) ----------------------------------------------
+    // ---- epilogue --------------------------------------------------------------------------------------
+    // The MFMAs were issued with the operands swapped (D^T = W * A^T), so each lane holds, per fragment, FOUR
+    // CONSECUTIVE OUTPUT CHANNELS of ONE pixel: channel = n0 + 16j + 4*(lane>>4) + r, pixel = m0 + 32*wave + 16i +
+    // (lane&15).  They are finished in registers (bias, activation, residual, activation) and stored straight to
+    // NHWC global memory as 8-byte runs: no LDS staging, no barrier, 4x fewer store instructions than the first
+    // version (instruction issue, not bandwidth, bounds these layers).
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
-    constexpr int CHUNKS_PER_ROW = BN / 8;
-    constexpr int TOTAL_CHUNKS = BM * CHUNKS_PER_ROW;
-    if (p.scalar_out) {
-        // ragged channel counts / unaligned channel slices (e.g. 4-, 8-, 20-channel detection heads written
-        // side by side into one concat buffer): element-wise stores with bounds checks
-        for (int id = tid; id < BM * BN; id += 256) {
-            const int row = id / BN;
-            const int col = id - row * BN;
-            const int m = m0 + row;
-            const int co = n0 + col;
-            if (m < p.M && co < p.Cout) {
-                float v = (float)Cs[row * C_ROW + col];
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const int px_in = lane & 15;
+    const int ch_in = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wave * 32 + i * 16 + px_in;
+        if (m >= p.M) continue;
+        _Float16* orow = out + (size_t)m * p.ld_out;
+        const _Float16* rrow = res ? res + (size_t)m * p.ld_res : nullptr;
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) {
+            const int co = n0 + j * 16 + ch_in;
+            if (co >= p.Cout) continue;
+            float v[4];
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);  // bias is padded to Cout_pad
+            v[0] = apply_act(acc[i][j][0] + bv.x, p.act1, p.alpha1);
+            v[1] = apply_act(acc[i][j][1] + bv.y, p.act1, p.alpha1);
+            v[2] = apply_act(acc[i][j][2] + bv.z, p.act1, p.alpha1);
+            v[3] = apply_act(acc[i][j][3] + bv.w, p.act1, p.alpha1);
+            if (!p.scalar_out) {
                 if (res || p.act2 != ACT_NONE) {
-                    const float rv = res ? (float)res[(size_t)m * p.ld_res + co] : 0.f;
-                    v = apply_act(v + rv, p.act2, p.alpha2);
+                    half4 rv = half4{0, 0, 0, 0};
+                    if (res) rv = *reinterpret_cast<const half4*>(rrow + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act((float)(_Float16)v[e] + (float)rv[e], p.act2, p.alpha2);
                 }
-                out[(size_t)m * p.ld_out + co] = (_Float16)v;
-            }
-        }
-        return;
-    }
+                half4 o;
 #pragma unroll
-    for (int id = tid; id < TOTAL_CHUNKS; id += 256) {
-        const int row = id / CHUNKS_PER_ROW;
-        const int cc = id - row * CHUNKS_PER_ROW;
-        const int m = m0 + row;
-        const int co = n0 + cc * 8;
-        if (m < p.M && co < p.Cout) {
-            half8 v = *reinterpret_cast<const half8*>(Cs + row * C_ROW + cc * 8);
-            if (res || p.act2 != ACT_NONE) {
-                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                *reinterpret_cast<half4*>(orow + co) = o;
+            } else {
+                // ragged channel counts / unaligned channel slices: element-wise with bounds checks
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (_Float16)apply_act((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e < p.Cout) {
+                        float x = v[e];
+                        if (res || p.act2 != ACT_NONE) x = apply_act((float)(_Float16)x + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
+                        orow[co + e] = (_Float16)x;
+                    }
+                }
             }
-            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
         }
     }
 }

@@ -31,10 +31,23 @@ struct ConvArgs {
     int scalar_out;  // igemm: element-wise epilogue stores (Cout, channel stride or offset not a multiple of 8)
 };
 
+// geometry of the LDS-patch convolution kernel (conv_patch.hip), chosen per layer at plan time
+struct PatchGeom {
+    int th, tw;            // output tile (th*tw <= 128)
+    int ph, pw;            // input patch
+    int cc;                // input channels staged per chunk (32 or 64)
+    int tiles_h, tiles_w;  // tiles per image
+};
+
 // --- conv -------------------------------------------------------------------------------------------
 int conv_igemm_pick_bn(int cout);
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// LDS-patch implicit GEMM (k x k, stride 1/2): weights fp16 [Cout_pad][chunk][tap][cc_pad] (conv_patch_kpad per row)
+bool conv_patch_plan(const ConvArgs& a, PatchGeom* g);
+size_t conv_patch_lds_bytes(const ConvArgs& a, const PatchGeom& g);
+int conv_patch_kpad(int cin, int kh, int kw, int cc);
+int32_t conv_patch_f16(const ConvArgs& a, const PatchGeom& g, hipStream_t s);
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);

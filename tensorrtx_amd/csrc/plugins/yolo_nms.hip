@@ -48,7 +48,7 @@ __device__ __forceinline__ float iou_xyxy(const float4 l, const float4 r) {
 __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict__ decode, int out_elem,
                                                         int det_floats, int max_out, float conf_thresh,
                                                         float nms_thresh, int* __restrict__ keep_idx,
-                                                        int* __restrict__ keep_cnt, float* __restrict__ keep_det) {
+                                                        int* __restrict__ keep_cnt, float* __restrict__ keep_det, long long* __restrict__ dbg) {
     __shared__ uint64_t s_hi[kCap];
     __shared__ uint64_t s_lo[kCap];
     __shared__ float4 s_box[kCap];
@@ -66,6 +66,9 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
     count = count < max_out ? count : max_out;
     count = count < kCap ? count : kCap;
 
+    long long t0 = 0;
+    if (dbg) t0 = wall_clock64();
+#define TRTX_NMS_STAMP(i) if (dbg && tid == 0 && b == 0) dbg[i] = wall_clock64() - t0
     // ---- load + keys ------------------------------------------------------------------------
     uint64_t hi = ~0ull, lo = ~0ull;
     if (tid < count) {
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
         }
     }
 
+    TRTX_NMS_STAMP(0);
     // ---- bitonic sort, ascending, 1024 keys ---------------------------------------------------
     for (int k = 2; k <= kCap; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
     }
     __syncthreads();
 
+    TRTX_NMS_STAMP(1);
     // ---- gather the sorted records --------------------------------------------------------------
     const bool valid = !(hi == ~0ull && lo == ~0ull);
     const int orig = valid ? (int)(uint32_t)lo : 0;
@@ -131,18 +136,19 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
     s_cls[tid] = my_cls;
     __syncthreads();
 
+    TRTX_NMS_STAMP(2);
     // ---- blocked greedy suppression -------------------------------------------------------------
     bool rem = !valid;
     const int nblk = (n + 63) >> 6;
     for (int bi = 0; bi < nblk; ++bi) {
         if (wave == bi) {
+            // Keys are sorted by class first, so the boxes that can suppress this lane's box are the contiguous run of
+            // equal-class lanes right before it: walk that run only (typically a handful of boxes, not 63).
             uint64_t supby = 0;  // bit k: sorted box (64*bi + k), k < lane, would suppress this lane's box
-            for (int k = 0; k < 63; ++k) {
+            for (int k = lane - 1; k >= 0; --k) {
                 const int rk = (bi << 6) + k;
-                const float4 bk = s_box[rk];
-                const float ck = s_cls[rk];
-                const bool s = (k < lane) && (ck == my_cls) && (iou_xyxy(bk, my_box) > nms_thresh);
-                supby |= (uint64_t)(s ? 1 : 0) << k;
+                if (s_cls[rk] != my_cls) break;
+                if (iou_xyxy(s_box[rk], my_box) > nms_thresh) supby |= 1ull << k;
             }
             uint64_t dead = __ballot(rem);
             for (int k = 0; k < 64; ++k) {
@@ -152,13 +158,19 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
             if (lane == 0) s_kept[bi] = ~dead;
         }
         __syncthreads();
-        if (wave > bi && !rem) {
-            uint64_t kept = s_kept[bi];
+        // Later boxes have a class >= every class of block bi, so only the tail run of block bi with exactly this
+        // class can matter: find its start by binary search (classes are sorted) and test the KEPT boxes of that run.
+        if (wave > bi && !rem && s_cls[(bi << 6) + 63] == my_cls) {
+            int lo = 0, hi = 63;  // first index in the block whose class equals my_cls
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cls[(bi << 6) + mid] < my_cls) lo = mid + 1; else hi = mid;
+            }
+            uint64_t kept = s_kept[bi] & (~0ull << lo);
             while (kept) {
                 const int k = __ffsll((unsigned long long)kept) - 1;
                 kept &= kept - 1;
-                const int rk = (bi << 6) + k;
-                if (s_cls[rk] == my_cls && iou_xyxy(s_box[rk], my_box) > nms_thresh) {
+                if (iou_xyxy(s_box[(bi << 6) + k], my_box) > nms_thresh) {
                     rem = true;
                     break;
                 }
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
         }
     }
 
+    TRTX_NMS_STAMP(3);
     // ---- ordered compaction -----------------------------------------------------------------------
     const bool keep = valid && !rem;
     const unsigned long long km = __ballot(keep);
@@ -193,6 +206,8 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
         }
     }
     if (tid == 0) keep_cnt[b] = total;
+    TRTX_NMS_STAMP(4);
+    if (dbg && tid == 0 && b == 0) dbg[5] = n;
 }
 
 }  // namespace
@@ -204,6 +219,15 @@ extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out
     if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
     const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
     hipLaunchKernelGGL(yolo_nms_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem,
-                       trtx::kYoloDetFloats, max_out, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det);
+                       trtx::kYoloDetFloats, max_out, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, (long long*)nullptr);
     return trtx::check_launch("trtx_yolo_nms");
+}
+
+// development probe: same kernel with per-phase wall-clock stamps of image 0 (100 MHz ticks) in dbg[0..5]
+extern "C" int32_t trtx_yolo_nms_probe(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                       int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, long long* dbg, hipStream_t stream) {
+    const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
+    hipLaunchKernelGGL(yolo_nms_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, trtx::kYoloDetFloats, max_out,
+                       conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, dbg);
+    return trtx::check_launch("trtx_yolo_nms_probe");
 }

@@ -11,6 +11,11 @@ namespace trtx {
 void pack_conv_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
                            const float* ch_scale, uint16_t* packed);
 
+// conv_patch layout: fp16 [Cout_pad][Kpatch], a row = for each chunk of `cc` input channels, for each tap (r,q),
+// the chunk's channels padded to a multiple of 32 (zeros)
+void pack_conv_weights_patch_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_eff, int cc,
+                                 const float* ch_scale, uint16_t* packed);
+
 // fp32 [Cout][kh][kw][Cin/groups] for the generic direct kernel (KCRS source, Cin here = per group)
 void pack_conv_weights_f32(const float* w_kcrs, int cout, int cin_g, int kh, int kw, const float* ch_scale,
                            float* packed);
