@@ -21,6 +21,11 @@
 #include "../common.h"
 #include "kernels.h"
 
+// development hook: tools/hip/igemm_phase_probe.hip defines TRTX_STAMP to record shader-clock stamps of one k-step
+#ifndef TRTX_STAMP
+#define TRTX_STAMP(i, kt)
+#endif
+
 namespace trtx {
 namespace {
 
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
     const int frag_k = ((lane >> 4) ^ swz(frag_row)) * 8;  // tile bases are multiples of 16 rows: swz depends on the lane only
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+        TRTX_STAMP(0, kt);
         if (kt + 1 < nk) load_tile(kt + 1);
+        TRTX_STAMP(1, kt);
         const _Float16* Ab = As + buf * A_TILE + (wave * 32 + frag_row) * LDS_ROW + frag_k;
         const _Float16* Bb = Bs + buf * B_TILE + frag_row * LDS_ROW + frag_k;
         half8 af[2];
@@ -195,8 +202,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);  // D^T: rows = channels
         }
+        TRTX_STAMP(2, kt);
         if (kt + 1 < nk) store_tile(buf ^ 1);
+        TRTX_STAMP(3, kt);
         __syncthreads();
+        TRTX_STAMP(4, kt);
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------

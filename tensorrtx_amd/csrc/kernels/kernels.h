@@ -43,6 +43,9 @@ struct PatchGeom {
 int conv_igemm_pick_bn(int cout);
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// second generation: LDS-DMA operands, bounds-checked buffer loads, 3-stage pipeline (conv_igemm2.hip)
+bool conv_igemm2_supported(const ConvArgs& a);
+int32_t conv_igemm2_f16(const ConvArgs& a, hipStream_t s);
 // LDS-patch implicit GEMM (k x k, stride 1/2): weights fp16 [Cout_pad][chunk][tap][cc_pad] (conv_patch_kpad per row)
 bool conv_patch_plan(const ConvArgs& a, PatchGeom* g);
 size_t conv_patch_lds_bytes(const ConvArgs& a, const PatchGeom& g);

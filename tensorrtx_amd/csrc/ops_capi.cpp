@@ -1,6 +1,7 @@
 // extern "C" entry points that expose single kernels (for parity tests, micro-benchmarks and
 // reference-style plugin classes) plus the library-level queries.  See include/trtx_hip.h.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -79,6 +80,8 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.M = N * a.Ho * a.Wo;
     a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
     a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
+    static const bool force_v1 = getenv("TRTX_CONV_V1") != nullptr;  // A/B switch for the micro-benchmarks
+    if (!force_v1 && conv_igemm2_supported(a)) return conv_igemm2_f16(a, stream);
     return conv_igemm_f16(a, stream);
 }
 

@@ -103,7 +103,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 else if (op.stem)
                     st = conv_stem_nchw_f32(a, stream);
                 else if (op.igemm)
-                    st = conv_igemm_f16(a, stream);
+                    st = conv_igemm2_supported(a) ? conv_igemm2_f16(a, stream) : conv_igemm_f16(a, stream);
                 else
                     st = conv_direct(a, op.dtype, stream);
                 break;
