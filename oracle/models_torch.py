@@ -277,3 +277,100 @@ def make_weights(model_fn, example_input, seed=0, **kw):
     with torch.inference_mode():
         out = model_fn(p, example_input, **kw)
     return p.t, out
+
+
+# ---------------------------------------------------------------------------------------------------------
+RCNN_DEFAULTS = dict(num_classes=80, anchor_sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0), pre_nms_topk=6000,
+                     rpn_nms_thresh=0.7, post_nms_topk=1000, stride=16, sampling_ratio=0, pooler_resolution=14,
+                     nms_thresh_test=0.5, detections_per_image=100, bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), nms_method=1,
+                     pixel_mean=(103.53, 116.28, 123.675), pixel_std=(1.0, 1.0, 1.0))
+
+
+def rcnn_r50c4(p: Params, x_hwc, stage="all", given=None, **cfg):
+    """Faster R-CNN R50-C4, rcnn/rcnn.cpp:79-278 + rcnn/backbone.hpp:26-229 (detectron2 export after fuse-bn: every
+    conv has a bias, stride in the first 1x1).  x_hwc: [B, H, W, 3] fp32.  Returns a dict with every stage:
+    features, logits, deltas, rpn_scores, rpn_boxes, proposals, roi (RoiAlign out), cls_prob, box_deltas,
+    pred_{scores,boxes,classes}, scores, boxes, labels.  The plugin stages use the C restatements (det_post).
+
+    `given` lets a parity test restart the chain from tensors produced elsewhere (e.g. the GPU engine's own
+    features/proposals), so that discrete top-k / NMS decisions upstream do not mask a downstream comparison.
+    stage="init" touches every weight with a cheap forward (used to generate the synthetic .wts)."""
+    from . import det_post
+    c = dict(RCNN_DEFAULTS)
+    c.update(cfg)
+    given = given or {}
+    out = {}
+
+    def conv(x, name, cout, k, s, pad, relu, gain=2.0):
+        w = p.conv_w(name + ".weight", cout, x.shape[1], k, gain=gain)
+        b = p.vec(name + ".bias", cout, lambda: 0.05 * p.randn(cout))
+        y = F.conv2d(x, w, b, stride=s, padding=pad)
+        return F.relu(y) if relu else y
+
+    def block(x, inch, mid, outch, stride, l):  # backbone.hpp:104-169
+        a = conv(x, l + ".conv1", mid, 1, stride, 0, True)
+        b = conv(a, l + ".conv2", mid, 3, 1, 1, True)
+        d = conv(b, l + ".conv3", outch, 1, 1, 0, False, gain=0.125)  # synthetic: small residual branch, fp16-safe depth
+        sc = conv(x, l + ".shortcut", outch, 1, stride, 0, False, gain=1.0) if inch != outch else x
+        return F.relu(d + sc)
+
+    def stage_(x, n, inch, mid, outch, first_stride, l):
+        for i in range(n):
+            x = block(x, inch, mid, outch, first_stride if i == 0 else 1, f"{l}.{i}")
+            inch = outch
+        return x
+
+    B, H, W, _ = x_hwc.shape
+    A = len(c["anchor_sizes"]) * len(c["aspect_ratios"])
+    nc = c["num_classes"]
+    if "features" in given:
+        feats = torch.as_tensor(given["features"])
+    else:
+        x = x_hwc.permute(0, 3, 1, 2)
+        x = (x - torch.tensor(c["pixel_mean"]).view(1, 3, 1, 1)) / torch.tensor(c["pixel_std"]).view(1, 3, 1, 1)
+        # synthetic stem gain: the (x - mean) input is O(100); bring the stem output to O(1)
+        y = conv(x, "backbone.stem.conv1", 64, 7, 2, 3, True, gain=2.0 / 70.0 ** 2)
+        y = F.max_pool2d(y, 3, 2, 1)
+        inch, mid, outch = 64, 64, 256
+        for s, n in enumerate((3, 4, 6)):
+            y = stage_(y, n, inch, mid, outch, 1 if s == 0 else 2, f"backbone.res{s + 2}")
+            inch, mid, outch = outch, mid * 2, outch * 2
+        feats = y
+    out["features"] = feats
+    if stage == "backbone":
+        return out
+    fh, fw = feats.shape[-2:]
+    hid = conv(feats, "proposal_generator.rpn_head.conv", feats.shape[1], 3, 1, 1, True)
+    out["logits"] = conv(hid, "proposal_generator.rpn_head.objectness_logits", A, 1, 1, 0, False, gain=8.0)
+    out["deltas"] = conv(hid, "proposal_generator.rpn_head.anchor_deltas", 4 * A, 1, 1, 0, False, gain=0.05)
+    if stage == "init":
+        pre = post = 8
+    else:
+        pre, post = c["pre_nms_topk"], c["post_nms_topk"]
+    if "proposals" in given:
+        proposals = np.asarray(given["proposals"], np.float32)
+    else:
+        anchors = det_post.generate_anchors(c["anchor_sizes"], c["aspect_ratios"])
+        rs, rb = det_post.rpn_decode(out["logits"].numpy(), out["deltas"].numpy(), fh, fw, H, W, float(c["stride"]), anchors, pre)
+        out["rpn_scores"], out["rpn_boxes"] = rs, rb
+        proposals = det_post.rpn_nms(rs, rb, post, c["rpn_nms_thresh"])
+    out["proposals"] = proposals
+    P = proposals.shape[1]
+    roi = det_post.roi_align(proposals, feats.numpy(), c["pooler_resolution"], 1.0 / c["stride"], c["sampling_ratio"])
+    out["roi"] = roi
+    r = torch.from_numpy(roi).reshape(B * P, feats.shape[1], c["pooler_resolution"], c["pooler_resolution"])
+    r = stage_(r, 3, feats.shape[1], 512, 2048, 2, "roi_heads.res5")
+    pooled = r.mean((2, 3))
+    wc = p._get("roi_heads.box_predictor.cls_score.weight", (nc + 1, 2048), lambda: p.randn(nc + 1, 2048) * 0.06)
+    bc = p.vec("roi_heads.box_predictor.cls_score.bias", nc + 1, lambda: 0.1 * p.randn(nc + 1))
+    wb = p._get("roi_heads.box_predictor.bbox_pred.weight", (4 * nc, 2048), lambda: p.randn(4 * nc, 2048) * 0.01)
+    bb = p.vec("roi_heads.box_predictor.bbox_pred.bias", 4 * nc, lambda: 0.01 * p.randn(4 * nc))
+    prob = F.softmax(F.linear(pooled, wc, bc), dim=1)
+    out["cls_prob"] = prob.reshape(B, P, nc + 1)
+    out["box_deltas"] = F.linear(pooled, wb, bb).reshape(B, P, 4 * nc)
+    fg = out["cls_prob"][:, :, :nc].contiguous().numpy()
+    ps, pb, pc = det_post.predictor_decode(fg, out["box_deltas"].numpy(), proposals, H, W, c["bbox_reg_weights"])
+    out["pred_scores"], out["pred_boxes"], out["pred_classes"] = ps, pb, pc
+    dets = min(c["detections_per_image"], P)
+    out["scores"], out["boxes"], out["labels"] = det_post.batched_nms(c["nms_method"], ps, pb, pc, dets, c["nms_thresh_test"])
+    return out

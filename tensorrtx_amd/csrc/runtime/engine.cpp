@@ -85,7 +85,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         const POp& op = plan.ops[k];
         const PTensor& t0 = plan.tensors[op.in.empty() ? op.out[0] : op.in[0]];
         const PTensor& to = plan.tensors[op.out[0]];
-        auto nb = [&](const PTensor& t) { return t.nfix ? t.nfix : batch; };
+        auto nb = [&](const PTensor& t) { return (t.nfix ? t.nfix : batch) * t.nmul; };
         int32_t st = TRTX_OK;
         switch (op.kind) {
             case OP_CONV:

@@ -94,7 +94,9 @@ struct Lowerer {
         return false;
     }
 
-    bool spatial(const Dims& d) const { return net.explicit_batch ? d.nb == 4 : d.nb == 3; }
+    // image tensors: (C,H,W) per sample, or (P,C,H,W) per sample where the leading P folds into the image count
+    // (TensorRT applies conv/pool/FC to the last three dims; rcnn.cpp:154-160 runs res5 on a (1000,C,14,14) tensor)
+    bool spatial(const Dims& d) const { return net.explicit_batch ? d.nb == 4 : (d.nb == 3 || d.nb == 4); }
 
     // ---- tensors ---------------------------------------------------------------------------------
     int new_tensor(int net_t, const Dims& d, int layout, bool batched) {
@@ -114,9 +116,10 @@ struct Lowerer {
                 t.W = (int)d.d[3];
                 t.batched = false;
             } else {
-                t.C = (int)d.d[0];
-                t.H = (int)d.d[1];
-                t.W = (int)d.d[2];
+                t.C = (int)d.d[d.nb - 3];
+                t.H = (int)d.d[d.nb - 2];
+                t.W = (int)d.d[d.nb - 1];
+                if (d.nb == 4) t.nmul = (int)d.d[0];
             }
             t.Calloc = dt == DT_F16 ? (t.C + 7) / 8 * 8 : t.C;
         } else {
@@ -136,10 +139,7 @@ struct Lowerer {
         t.C = C;
         t.Calloc = 0;
         t.pad_zeroed = false;
-        if (net.explicit_batch)
-            t.dims.d[1] = C;
-        else
-            t.dims.d[0] = C;
+        t.dims.d[t.dims.nb - 3] = C;
         plan.tensors.push_back(t);
         return t.id;
     }
@@ -457,7 +457,7 @@ struct Lowerer {
             const PTensor& src = plan.tensors[pt_of[l.inputs[0]]];
             const Dims& di = net.tensors[l.inputs[0]].dims;
             const int cin = (int)di.d[di.nb - 3];
-            stem = dt == DT_F16 && l.kind == L_CONV && src.layout == LAY_LINEAR && pt_nhwc[l.inputs[0]] < 0 && cin <= 4 &&
+            stem = dt == DT_F16 && l.kind == L_CONV && di.nb == (net.explicit_batch ? 4 : 3) && src.layout == LAY_LINEAR && pt_nhwc[l.inputs[0]] < 0 && cin <= 4 &&
                    g.residual < 0 && g.act2 == ACT_NONE && l.groups == 1 && l.dilation[0] == 1 && l.dilation[1] == 1 &&
                    (l.nb_out == 8 || l.nb_out == 16 || l.nb_out == 32 || l.nb_out == 64) &&
                    (size_t)l.kernel[0] * l.kernel[1] * cin * l.nb_out * 4 <= 48 * 1024;
@@ -509,7 +509,7 @@ struct Lowerer {
         a.alpha1 = g.alpha1;
         a.act2 = g.act2;
         a.alpha2 = g.alpha2;
-        op.flops = 2.0 * a.Ho * a.Wo * a.Cout * (double)a.kh * a.kw * (a.Cin / a.groups);
+        op.flops = 2.0 * to.nmul * a.Ho * a.Wo * a.Cout * (double)a.kh * a.kw * (a.Cin / a.groups);
         pt_of[g.out_tensor] = out;
         return true;
     }
@@ -686,7 +686,7 @@ struct Lowerer {
             case L_REDUCE: {
                 const Dims& di = net.tensors[l.inputs[0]].dims;
                 const int p = pt_of[l.inputs[0]];
-                const int hw_mask = net.explicit_batch ? 0b1100 : 0b110;
+                const int hw_mask = 0b110 << (di.nb - 3);
                 if (spatial(di) && plan.tensors[p].layout == LAY_NHWC && l.op == TRTX_REDUCE_AVG && l.axis == hw_mask && l.keep_dims) {
                     const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
                     add_op(OP_REDUCE_HW, l.name, {p}, {out});
@@ -746,7 +746,7 @@ struct Lowerer {
     bool emit_concat(int li) {
         const LayerDef& l = net.layers[li];
         const Dims& dout = net.tensors[l.outputs[0]].dims;
-        const int cax = net.explicit_batch ? 1 : 0;
+        const int cax = dout.nb - 3;
         bool all_nhwc = spatial(dout) && l.axis == cax;
         for (int t : l.inputs) all_nhwc = all_nhwc && plan.tensors[pt_of[t]].layout == LAY_NHWC;
         if (all_nhwc) {
@@ -810,7 +810,7 @@ struct Lowerer {
         const LayerDef& l = net.layers[li];
         const Dims& di = net.tensors[l.inputs[0]].dims;
         const int p = pt_of[l.inputs[0]];
-        const int cax = net.explicit_batch ? 1 : 0;
+        const int cax = di.nb - 3;
         if (spatial(di) && plan.tensors[p].layout == LAY_NHWC) {
             bool chan_only = l.step.d[cax] == 1;
             for (int k = 0; k < di.nb; ++k)
@@ -963,7 +963,7 @@ struct Lowerer {
     size_t tensor_bytes(const PTensor& t) const {
         const size_t es = t.dtype == DT_F16 ? 2 : 4;
         if (t.layout == LAY_NHWC) {
-            const size_t n = t.nfix ? (size_t)t.nfix : (size_t)plan.max_batch;
+            const size_t n = (t.nfix ? (size_t)t.nfix : (size_t)plan.max_batch) * (size_t)t.nmul;
             return n * t.H * t.W * (size_t)t.Calloc * es;
         }
         return (t.batched ? (size_t)plan.max_batch : 1) * (size_t)t.dims.volume() * es;
@@ -1041,7 +1041,7 @@ struct Lowerer {
                 }
             }
             const double es = dt == DT_F16 ? 2 : 4;
-            op.bytes = (op.stem ? 4.0 : es) * (double)a.H * a.W * a.Cin + es * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1);
+            op.bytes = to.nmul * ((op.stem ? 4.0 : es) * (double)a.H * a.W * a.Cin + es * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
         }
         // 4. plugins: configure + workspace
         for (size_t k = 0; k < plan.ops.size(); ++k) {

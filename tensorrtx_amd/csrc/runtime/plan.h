@@ -53,6 +53,7 @@ struct PTensor {
     int layout = LAY_LINEAR;
     int dtype = DT_F32;
     int nfix = 0;        // NHWC with explicit batch: N taken from dims[0]; 0 = runtime batch
+    int nmul = 1;        // NHWC with a leading per-sample dim (P,C,H,W): image count = batch * nmul
     int C = 0, H = 0, W = 0;
     bool pad_zeroed = false;  // channels [C, ld) of an owning NHWC tensor are guaranteed zero
     // storage
@@ -64,7 +65,7 @@ struct PTensor {
     int rcoff = 0;       // resolved channel offset within the storage
     long reoff = 0;      // resolved element offset within the storage (LINEAR)
     int Calloc = 0;      // owning NHWC tensor: allocated channel count
-    long sample_elems() const { return layout == LAY_NHWC ? (long)H * W * ld : (long)dims.volume(); }
+    long sample_elems() const { return layout == LAY_NHWC ? (long)nmul * H * W * ld : (long)dims.volume(); }
 };
 
 struct Storage {

@@ -52,6 +52,19 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
         cfg.max_out_bbox = geti(o, "max_out", 1000);
         cfg.mark_heads = geti(o, "mark_heads", 0) != 0;
         plan.reset(trtx_host::buildEngineYolov8Det(builder.get(), config.get(), wts_path, cfg));
+    } else if (m == "rcnn_r50c4") {
+        trtx_host::RcnnConfig cfg;
+        cfg.max_batch = geti(o, "batch", 1);
+        cfg.fp16 = geti(o, "fp16", 1) != 0;
+        cfg.input_h = geti(o, "h", cfg.input_h);
+        cfg.input_w = geti(o, "w", cfg.input_w);
+        cfg.num_classes = geti(o, "classes", cfg.num_classes);
+        cfg.pre_nms_topk = geti(o, "pre_nms_topk", cfg.pre_nms_topk);
+        cfg.post_nms_topk = geti(o, "post_nms_topk", cfg.post_nms_topk);
+        cfg.detections_per_image = geti(o, "detections", cfg.detections_per_image);
+        cfg.nms_method = geti(o, "nms_method", cfg.nms_method);
+        cfg.mark_stages = geti(o, "mark_stages", 0) != 0;
+        plan.reset(trtx_host::buildRcnnR50C4(builder.get(), config.get(), wts_path, cfg));
     } else {
         return TRTX_ERR_INVALID;
     }

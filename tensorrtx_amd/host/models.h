@@ -4,6 +4,7 @@
 // 1280x1280, etc. (SURVEY.md §5 "Config / flags").
 #pragma once
 #include <string>
+#include <vector>
 
 #include "NvInfer.h"
 
@@ -33,5 +34,32 @@ struct Yolov8Config {
 // yolov8/src/model.cpp:98-336
 nvinfer1::IHostMemory* buildEngineYolov8Det(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config,
                                             const std::string& wts, const Yolov8Config& cfg);
+
+// The reference's file-scope constants (rcnn/rcnn.cpp:16-60) as run-time configuration.
+struct RcnnConfig {
+    int input_h = 800, input_w = 1067;      // INPUT_H / INPUT_W: 480x640 resized by calculateSize() (rcnn.cpp:349-366)
+    int max_batch = 1;                      // BATCH_SIZE
+    bool fp16 = true;
+    float pixel_mean[3] = {103.53f, 116.28f, 123.675f};
+    float pixel_std[3] = {1.0f, 1.0f, 1.0f};
+    int num_classes = 80;
+    int res2_out_channels = 256;            // R50
+    std::vector<float> anchor_sizes = {32, 64, 128, 256, 512};
+    std::vector<float> aspect_ratios = {0.5f, 1.0f, 2.0f};
+    int pre_nms_topk = 6000;                // PRE_NMS_TOP_K_TEST
+    float rpn_nms_thresh = 0.7f;
+    int post_nms_topk = 1000;
+    int stride = 16;                        // STRIDES
+    int sampling_ratio = 0;
+    int pooler_resolution = 14;
+    float nms_thresh_test = 0.5f;
+    int detections_per_image = 100;
+    float bbox_reg_weights[4] = {10.0f, 10.0f, 5.0f, 5.0f};
+    int nms_method = 1;                     // 0 hard, 1 soft-NMS linear (reference default), 2 soft-NMS gaussian
+    bool mark_stages = false;               // debugging: also expose "features" and "proposals"
+};
+// rcnn/rcnn.cpp:79-278 (box head; MASK_ON = false)
+nvinfer1::IHostMemory* buildRcnnR50C4(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config, const std::string& wts,
+                                      const RcnnConfig& cfg);
 
 }  // namespace trtx_host

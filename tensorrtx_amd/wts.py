@@ -13,14 +13,16 @@ import numpy as np
 def write_wts(path, tensors, dialect="single"):
     """tensors: ordered mapping name -> array-like (any shape, flattened row-major as fp32)."""
     sep_after_count = " " if dialect == "single" else "  "
-    with open(path, "w") as f:
-        f.write(f"{len(tensors)}\n")
+    with open(path, "wb") as f:
+        f.write(f"{len(tensors)}\n".encode())
         for name, arr in tensors.items():
             a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32).reshape(-1))
-            # big-endian bytes -> one long hex string -> 8-character tokens joined by spaces (vectorised)
-            hx = a.astype(">f4").tobytes().hex().encode()
-            hexes = b" ".join(np.frombuffer(hx, dtype="S8")).decode()
+            f.write(f"{name} {a.size}".encode())
             if a.size:
-                f.write(f"{name} {a.size}{sep_after_count}{hexes}\n")
-            else:
-                f.write(f"{name} 0\n")
+                # big-endian bytes -> hex digits -> rows of " xxxxxxxx" (fully vectorised: no per-value Python work)
+                digits = np.frombuffer(a.astype(">f4").tobytes().hex().encode(), dtype=np.uint8).reshape(-1, 8)
+                rows = np.full((a.size, 9), ord(" "), dtype=np.uint8)
+                rows[:, 1:] = digits
+                f.write(sep_after_count[1:].encode())  # the extra blank of the "double" dialect
+                f.write(rows.tobytes())
+            f.write(b"\n")

@@ -1,0 +1,105 @@
+"""GPU parity of the Faster R-CNN R50-C4 engine (BASELINE config 5) against the oracle.
+
+The detector is a chain of discrete decisions (top-k, two NMS passes), so fp16 noise upstream can legitimately flip a
+choice and change everything downstream.  fp32 is compared end to end; fp16 is compared stage by stage, restarting the
+oracle from the tensors the engine itself produced ("features", "proposals" taps) so each stage is judged on its own.
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_torch as mt
+from oracle import wts as owts
+from tensorrtx_amd import engine, synth
+from test_gpu_engine import _metric, _run
+from util import synth_wts
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(batch, H, W, seed):
+    return torch.from_numpy(synth.images(batch, H, W, seed=seed)).permute(0, 2, 3, 1).contiguous() * 255
+
+
+def _iou_matrix(a, b):
+    x0 = np.maximum(a[:, None, 0], b[None, :, 0])
+    y0 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x1 = np.minimum(a[:, None, 2], b[None, :, 2])
+    y1 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x1 - x0, 0, None) * np.clip(y1 - y0, 0, None)
+    ua = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter
+    return np.where(ua > 0, inter / np.maximum(ua, 1e-12), 0.0)
+
+
+def _matched_fraction(got, ref, thr=0.9):
+    """fraction of non-empty reference boxes that have a partner with IoU > thr among `got`"""
+    ref = ref[(ref[:, 2] > ref[:, 0]) & (ref[:, 3] > ref[:, 1])]
+    if len(ref) == 0:
+        return 1.0
+    return float((_iou_matrix(ref, got).max(1) > thr).mean())
+
+
+def test_rcnn_fp32_engine_end_to_end(gpu):
+    cfg = dict(pre_nms_topk=300, post_nms_topk=50, detections=20)
+    path, _ = synth_wts("rcnn_r50c4")
+    B, H, W = 2, 128, 160
+    plan = engine.build_plan("rcnn_r50c4", path, batch=B, fp16=0, h=H, w=W, mark_stages=1, **cfg)
+    x = _images(B, H, W, 7)
+    out = _run(plan, {"images": x.numpy()}, B, gpu)
+    with torch.inference_mode():
+        ref = mt.rcnn_r50c4(mt.Params(owts.load_wts(path)), x, pre_nms_topk=300, post_nms_topk=50, detections_per_image=20)
+    feats = out["features"].reshape(ref["features"].shape).numpy()
+    err = float(np.abs(feats - ref["features"].numpy()).max())
+    props = out["proposals"].reshape(B, 50, 4).numpy()
+    scores = out["scores"].reshape(B, 20).numpy()
+    boxes = out["boxes"].reshape(B, 20, 4).numpy()
+    labels = out["labels"].reshape(B, 20).numpy()
+    pm = min(_matched_fraction(props[b], ref["proposals"][b], 0.99) for b in range(B))
+    dm = min(_matched_fraction(boxes[b], ref["boxes"][b], 0.95) for b in range(B))
+    _metric("rcnn_fp32", feat_err=err, proposals_matched=pm, detections_matched=dm,
+            score_err=float(np.abs(scores - ref["scores"]).max()))
+    assert err < 1e-3
+    assert pm >= 0.95 and dm >= 0.9
+    assert np.abs(scores - ref["scores"]).max() < 1e-3 and np.array_equal(labels, ref["labels"])
+
+
+@pytest.mark.parametrize("hw,batch,cfg", [((320, 416), 2, dict(pre_nms_topk=2000, post_nms_topk=200, detections=50)),
+                                           ((800, 1067), 1, dict())])
+def test_rcnn_fp16_engine_stagewise(gpu, hw, batch, cfg):
+    H, W = hw
+    path, _ = synth_wts("rcnn_r50c4")
+    plan = engine.build_plan("rcnn_r50c4", path, batch=batch, fp16=1, h=H, w=W, mark_stages=1, **cfg)
+    x = _images(batch, H, W, 11)
+    out = _run(plan, {"images": x.numpy()}, batch, gpu)
+    ocfg = dict(pre_nms_topk=cfg.get("pre_nms_topk", 6000), post_nms_topk=cfg.get("post_nms_topk", 1000),
+                detections_per_image=cfg.get("detections", 100))
+    P, D = ocfg["post_nms_topk"], ocfg["detections_per_image"]
+    params = mt.Params(owts.load_wts(path))
+    fdim = lambda n: functools.reduce(lambda v, _: (v - 1) // 2 + 1, range(4), n)  # noqa: E731  four stride-2 stages
+    fh, fw = fdim(H), fdim(W)
+    feats = out["features"].reshape(batch, 1024, fh, fw)
+    props = out["proposals"].reshape(batch, P, 4).numpy()
+    with torch.inference_mode():
+        # stage 1: backbone, fp16 storage vs fp32
+        full = mt.rcnn_r50c4(params, x, stage="backbone", **ocfg)
+        rf = full["features"]
+        rel = float((feats - rf).abs().max() / rf.abs().max())
+        assert rel < 2e-2
+        feats4 = feats
+        # stage 2: RPN + decode + NMS restarted from the engine's own features
+        s2 = mt.rcnn_r50c4(params, x, given={"features": feats4}, **ocfg)
+        pm = min(_matched_fraction(props[b], s2["proposals"][b], 0.9) for b in range(batch))
+        # stage 3: RoIAlign + res5 + predictor + soft-NMS restarted from the engine's own features and proposals
+        s3 = mt.rcnn_r50c4(params, x, given={"features": feats4, "proposals": props}, **ocfg)
+    scores = out["scores"].reshape(batch, D).numpy()
+    boxes = out["boxes"].reshape(batch, D, 4).numpy()
+    labels = out["labels"].reshape(batch, D).numpy()
+    dm = min(_matched_fraction(boxes[b], s3["boxes"][b], 0.85) for b in range(batch))
+    top = float(np.abs(scores[:, 0] - s3["scores"][:, 0]).max())
+    _metric("rcnn_fp16", hw=list(hw), feat_rel_err=rel, proposals_matched=pm, detections_matched=dm, top_score_err=top,
+            labels_equal=float((labels == s3["labels"]).mean()))
+    assert np.isfinite(scores).all() and scores[:, 0].min() > 0.05
+    assert pm >= 0.85
+    assert dm >= 0.8 and top < 0.05

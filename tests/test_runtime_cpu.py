@@ -190,3 +190,39 @@ def test_retinaface_lowering_at_config4_size():
     assert kinds.count("deconv") == 2 and kinds.count("plugin") == 1
     plug = [l for l in engine.describe_plan(plan)["layers"] if l["kind"] == 16][0]
     assert np.frombuffer(bytes.fromhex(plug["plugin_blob"]), dtype=np.int32).tolist() == [1280, 1280]
+
+
+RCNN_SMALL = dict(pre_nms_topk=100, post_nms_topk=20, detections=10)
+
+
+def test_rcnn_builder_matches_pytorch_restatement():
+    """Config 5 graph (HWC preprocess, C4 backbone, RPN, the five user plugins through the IPluginV2 trampoline, res5 on
+    the (proposals, C, 14, 14) tensor, FC/softmax/slice) interpreted layer by layer == the PyTorch restatement."""
+    path, _ = synth_wts("rcnn_r50c4")
+    plan = engine.build_plan("rcnn_r50c4", path, batch=2, fp16=0, h=64, w=96, mark_stages=1, **RCNN_SMALL)
+    desc = engine.describe_plan(plan)
+    plugs = [l["plugin_type"] for l in desc["layers"] if l["kind"] == 16]
+    assert plugs == ["RpnDecode", "RpnNms", "RoiAlign", "PredictorDecode", "BatchedNms"]
+    x = torch.from_numpy(synth.images(2, 64, 96, seed=5)).permute(0, 2, 3, 1).contiguous() * 255
+    res = gi.run(desc, plan, {"images": x.numpy()})
+    with torch.inference_mode():
+        ref = mt.rcnn_r50c4(mt.Params(owts.load_wts(path)), x, pre_nms_topk=100, post_nms_topk=20, detections_per_image=10)
+    assert np.allclose(res["features"].numpy(), ref["features"].numpy(), atol=1e-4)
+    assert np.allclose(res["proposals"].numpy(), ref["proposals"], atol=1e-2)
+    assert np.allclose(res["scores"].numpy().reshape(2, -1), ref["scores"], atol=1e-5) and ref["scores"].max() > 0.3
+    assert np.allclose(res["boxes"].numpy(), ref["boxes"], atol=1e-2)
+    assert np.array_equal(res["labels"].numpy().reshape(2, -1), ref["labels"])
+
+
+def test_rcnn_lowering_at_reference_size():
+    path, _ = synth_wts("rcnn_r50c4")
+    plan = engine.build_plan("rcnn_r50c4", path, batch=1, fp16=1)  # 800x1067, 6000 -> 1000 proposals -> 100 detections
+    low = engine.describe_plan(plan, lowered=True)
+    kinds = [o["kind"] for o in low["ops"]]
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    # stem + 42 backbone + 3 RPN + 10 res5 + 2 FC, all but the stem on the MFMA implicit-GEMM kernel
+    assert len(convs) == 58 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 57
+    assert kinds.count("plugin") == 5 and "act_nhwc" not in kinds and "ew_nhwc" not in kinds
+    e = engine.describe_plan(plan)
+    out_dims = {t["name"]: t["dims"] for t in e["tensors"] if t["is_output"]}
+    assert out_dims == {"scores": [100, 1], "boxes": [100, 4], "labels": [100, 1]}

@@ -1,4 +1,5 @@
 """Shared helpers for the tests: seeded synthetic .wts files (cached under /tmp) and plan building."""
+import functools
 import hashlib
 import os
 
@@ -9,7 +10,7 @@ from oracle import models_torch as mt
 from tensorrtx_amd import wts as wts_writer
 
 CACHE = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
-WTS_VERSION = {"retinaface_r50": 2}  # bump when a model's synthetic initialisation changes (cache key)
+WTS_VERSION = {"retinaface_r50": 2, "rcnn_r50c4": 2}  # bump when a model's synthetic initialisation changes (cache key)
 
 
 def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
@@ -22,6 +23,7 @@ def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
         "resnet50": (mt.resnet50, torch.zeros(1, 3, 64, 64)),
         "yolov8n": (mt.yolov8_det, torch.zeros(1, 3, 64, 64)),
         "retinaface_r50": (mt.retinaface_r50, torch.zeros(1, 3, 64, 64)),
+        "rcnn_r50c4": (functools.partial(mt.rcnn_r50c4, stage="init"), torch.zeros(1, 64, 64, 3)),
     }[model]
     tensors, _ = mt.make_weights(fn, x, seed=seed, **kw)
     if not os.path.exists(path):
