@@ -105,11 +105,15 @@ def main():
     keep_det = torch.empty((BATCH, 1000, 6), dtype=torch.float32, device=dev)
     import ctypes
     stream = capi._stream()
+    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    nms_ws_bytes = L.trtx_yolo_nms_workspace(BATCH)
+    nms_ws = torch.empty((nms_ws_bytes,), dtype=torch.uint8, device=dev)
 
     def step():
         eng.enqueue(BATCH, bindings)
         capi.check(L.trtx_yolo_nms(capi._p(out), BATCH, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(keep_idx),
-                                   capi._p(keep_cnt), capi._p(keep_det), stream), "trtx_yolo_nms")
+                                   capi._p(keep_cnt), capi._p(keep_det), capi._p(nms_ws), ctypes.c_size_t(nms_ws_bytes), stream),
+                   "trtx_yolo_nms")
 
     for _ in range(args.warmup):
         step()

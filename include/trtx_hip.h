@@ -80,10 +80,14 @@ int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const int* ld, int 
  *              emission order (class ascending, conf descending, bbox[0] ascending)
  *   keep_cnt   device, int32 [batch]
  *   keep_det   device, fp32 [batch][max_out][6] = x1,y1,x2,y2,conf,class of the kept boxes; may be NULL
+ *   workspace  device, >= trtx_yolo_nms_workspace(batch) bytes, 16-byte aligned (sorted records + the 1024x1024-bit
+ *              suppression matrix per image)
  * max_out <= 1024.
  */
+size_t trtx_yolo_nms_workspace(int batch);
 int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
-                      int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, trtx_stream_t stream);
+                      int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes,
+                      trtx_stream_t stream);
 
 
 /* ---- RetinaFace ------------------------------------------------------------------------------- */

@@ -80,8 +80,12 @@ def yolo_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45, with_de
     keep_idx = torch.full((B, max_out), -1, dtype=torch.int32, device=dev)
     keep_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
     keep_det = torch.zeros((B, max_out, 6), dtype=torch.float32, device=dev) if with_dets else None
+    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    ws_bytes = L.trtx_yolo_nms_workspace(B)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     check(L.trtx_yolo_nms(_p(decode_out), B, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
-                          _p(keep_idx), _p(keep_cnt), _p(keep_det), _stream()), "trtx_yolo_nms")
+                          _p(keep_idx), _p(keep_cnt), _p(keep_det), _p(ws), ctypes.c_size_t(ws_bytes), _stream()),
+          "trtx_yolo_nms")
     return keep_idx, keep_cnt, keep_det
 
 

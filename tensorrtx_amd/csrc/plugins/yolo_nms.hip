@@ -1,4 +1,4 @@
-// Class-aware greedy NMS for the YOLOv8 decode buffer — one workgroup (16 waves) per image.
+// Class-aware greedy NMS for the YOLOv8 decode buffer.
 //
 // Replaces the reference's single-threaded host nms()/batch_nms() (yolov8/src/postprocess.cpp:71-129):
 //   keep candidates with conf > conf_thresh (NaN dropped), group by class ascending, order by
@@ -7,13 +7,16 @@
 // same order (this file is compiled with -ffp-contract=off), ties of (class, conf, bbox[0]) are
 // broken by decode slot index (the reference's std::sort leaves them unspecified).
 //
-// Structure (wave64):
-//   1. 128-bit composite keys (class | ~conf | bbox[0] | slot) sorted by a 1024-wide bitonic network:
-//      strides < 64 are exchanged with wave shuffles, strides >= 64 through LDS (10 of 55 stages).
-//   2. blocked greedy pass: block bi (64 sorted boxes = wave bi) is resolved inside one wave with a
-//      64x64 suppression bit-matrix (one row per lane) and a scalar ballot chain; its surviving boxes
-//      are then applied by every later wave to its own boxes.  One barrier per block.
-//   3. ordered compaction of the survivors (ballot + popcount scan).
+// Three launches (wave64), the only sequential part is a few hundred scalar steps per image:
+//   1. yolo_nms_sort_kernel   one workgroup (16 waves) per image: 128-bit composite keys
+//                             (class | ~conf | bbox[0] | slot) through a 1024-wide bitonic network
+//                             (strides < 64 by wave shuffles, >= 64 through LDS); sorted records -> workspace.
+//   2. yolo_nms_mask_kernel   one wave per 64x64 tile of the lower-triangular suppression matrix, spread over the
+//                             whole chip (136 tiles x batch): bit k of word c of row i says "sorted box 64c+k
+//                             suppresses sorted box i".  Tiles whose class ranges cannot meet are skipped.
+//   3. yolo_nms_scan_kernel   one workgroup per image: wave b owns block b of 64 rows (pre-loaded), waves take turns in
+//                             order: cross-block removal is 16 AND/ORs against the published keep words, the in-block
+//                             chain only visits kept boxes that actually suppress something; ordered compaction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,7 +24,8 @@
 
 namespace {
 
-constexpr int kCap = 1024;  // candidates per image held in LDS (reference: kMaxNumOutputBbox = 1000)
+constexpr int kCap = 1024;        // candidates per image (reference: kMaxNumOutputBbox = 1000)
+constexpr int kBlocks = kCap / 64;
 
 __device__ __forceinline__ bool key_less(uint64_t ah, uint64_t al, uint64_t bh, uint64_t bl) {
     return ah < bh || (ah == bh && al < bl);
@@ -45,48 +49,60 @@ __device__ __forceinline__ float iou_xyxy(const float4 l, const float4 r) {
     return inter / uni;
 }
 
-__global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict__ decode, int out_elem,
-                                                        int det_floats, int max_out, float conf_thresh,
-                                                        float nms_thresh, int* __restrict__ keep_idx,
-                                                        int* __restrict__ keep_cnt, float* __restrict__ keep_det, long long* __restrict__ dbg) {
+// workspace layout (per batch; every array is [batch][kCap] unless noted)
+struct NmsWs {
+    float4* box;     // sorted boxes
+    float* cls;      // sorted class ids (-1 for padding)
+    float* conf;
+    int* orig;       // decode slot of the sorted record
+    int* n;          // [batch] number of valid (thresholded) records
+    uint64_t* mask;  // [batch][kCap][kBlocks]
+};
+
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline size_t nms_ws_bytes(int batch) {
+    const size_t rec = (size_t)batch * kCap;
+    return align256(rec * sizeof(float4)) + 3 * align256(rec * 4) + align256((size_t)batch * 4) +
+           align256(rec * kBlocks * sizeof(uint64_t));
+}
+
+inline NmsWs nms_ws_carve(void* base, int batch) {
+    const size_t rec = (size_t)batch * kCap;
+    char* p = static_cast<char*>(base);
+    NmsWs w;
+    w.box = reinterpret_cast<float4*>(p); p += align256(rec * sizeof(float4));
+    w.cls = reinterpret_cast<float*>(p); p += align256(rec * 4);
+    w.conf = reinterpret_cast<float*>(p); p += align256(rec * 4);
+    w.orig = reinterpret_cast<int*>(p); p += align256(rec * 4);
+    w.n = reinterpret_cast<int*>(p); p += align256((size_t)batch * 4);
+    w.mask = reinterpret_cast<uint64_t*>(p);
+    return w;
+}
+
+__global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __restrict__ decode, int out_elem, int det_floats,
+                                                             int max_out, float conf_thresh, NmsWs ws) {
     __shared__ uint64_t s_hi[kCap];
     __shared__ uint64_t s_lo[kCap];
-    __shared__ float4 s_box[kCap];
-    __shared__ float s_cls[kCap];
-    __shared__ float s_conf[kCap];
-    __shared__ uint64_t s_kept[kCap / 64];
-    __shared__ int s_wcnt[kCap / 64];
+    __shared__ int s_wcnt[kBlocks];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const float* img = decode + (size_t)b * out_elem;
     int count = (int)img[0];
     count = count < max_out ? count : max_out;
     count = count < kCap ? count : kCap;
 
-    long long t0 = 0;
-    if (dbg) t0 = wall_clock64();
-#define TRTX_NMS_STAMP(i) if (dbg && tid == 0 && b == 0) dbg[i] = wall_clock64() - t0
-    // ---- load + keys ------------------------------------------------------------------------
     uint64_t hi = ~0ull, lo = ~0ull;
     if (tid < count) {
         const float* det = img + 1 + (size_t)tid * det_floats;
-        const float4 box = make_float4(det[0], det[1], det[2], det[3]);
         const float conf = det[4];
-        const float cls = det[5];
-        s_box[tid] = box;
-        s_cls[tid] = cls;
-        s_conf[tid] = conf;
         if (conf > conf_thresh) {  // false for NaN, as "conf <= thresh || isnan" drops (postprocess.cpp:99)
-            hi = ((uint64_t)trtx::ord_f32(cls) << 32) | (uint32_t)~trtx::ord_f32(conf);
-            lo = ((uint64_t)trtx::ord_f32(box.x) << 32) | (uint32_t)tid;
+            hi = ((uint64_t)trtx::ord_f32(det[5]) << 32) | (uint32_t)~trtx::ord_f32(conf);
+            lo = ((uint64_t)trtx::ord_f32(det[0]) << 32) | (uint32_t)tid;
         }
     }
-
-    TRTX_NMS_STAMP(0);
-    // ---- bitonic sort, ascending, 1024 keys ---------------------------------------------------
+    // bitonic sort, ascending, 1024 keys
     for (int k = 2; k <= kCap; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             uint64_t ph, pl;
@@ -111,123 +127,156 @@ __global__ __launch_bounds__(kCap) void yolo_nms_kernel(const float* __restrict_
             }
         }
     }
-    __syncthreads();
-
-    TRTX_NMS_STAMP(1);
-    // ---- gather the sorted records --------------------------------------------------------------
+    // sorted record -> workspace (the decode buffer is re-read through L2: 24 B per record)
     const bool valid = !(hi == ~0ull && lo == ~0ull);
     const int orig = valid ? (int)(uint32_t)lo : 0;
-    float4 my_box = make_float4(0.f, 0.f, 0.f, 0.f);
-    float my_cls = -1.0f, my_conf = 0.0f;
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cls = -1.0f, conf = 0.0f;
     if (valid) {
-        my_box = s_box[orig];
-        my_cls = s_cls[orig];
-        my_conf = s_conf[orig];
+        const float* det = img + 1 + (size_t)orig * det_floats;
+        box = make_float4(det[0], det[1], det[2], det[3]);
+        conf = det[4];
+        cls = det[5];
     }
-    {
-        const unsigned long long m = __ballot(valid);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
+    const size_t r = (size_t)b * kCap + tid;
+    ws.box[r] = box;
+    ws.cls[r] = cls;
+    ws.conf[r] = conf;
+    ws.orig[r] = orig;
+    const unsigned long long m = __ballot(valid);
+    if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < kBlocks; ++w) n += s_wcnt[w];
+        ws.n[b] = n;
     }
-    __syncthreads();
-    int n = 0;
-#pragma unroll
-    for (int w = 0; w < kCap / 64; ++w) n += s_wcnt[w];
-    s_box[tid] = my_box;  // now indexed by sorted rank
-    s_cls[tid] = my_cls;
-    __syncthreads();
+}
 
-    TRTX_NMS_STAMP(2);
-    // ---- blocked greedy suppression -------------------------------------------------------------
+// grid (col block, row block, image), one wave each
+__global__ __launch_bounds__(64) void yolo_nms_mask_kernel(NmsWs ws, float nms_thresh) {
+    const int c = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    if (c > r) return;
+    const int lane = threadIdx.x;
+    const int n = ws.n[b];
+    const size_t base = (size_t)b * kCap;
+    const int i = r * 64 + lane;
+    uint64_t bits = 0;
+    // classes ascend with the sorted rank: a column block entirely below the row block's first class cannot interact
+    if (r * 64 < n && !(c < r && ws.cls[base + c * 64 + 63] < ws.cls[base + r * 64])) {
+        __shared__ float4 s_box[64];
+        __shared__ float s_cls[64];
+        s_box[lane] = ws.box[base + c * 64 + lane];
+        s_cls[lane] = ws.cls[base + c * 64 + lane];
+        __syncthreads();
+        if (i < n) {
+            const float4 mine = ws.box[base + i];
+            const float my_cls = ws.cls[base + i];
+            const int kend = (c == r) ? lane : 64;  // only earlier boxes suppress
+            for (int k = 0; k < kend; ++k)
+                if (s_cls[k] == my_cls && iou_xyxy(s_box[k], mine) > nms_thresh) bits |= 1ull << k;
+        }
+    }
+    ws.mask[(base + i) * kBlocks + c] = bits;
+}
+
+__global__ __launch_bounds__(kCap) void yolo_nms_scan_kernel(NmsWs ws, int max_out, int* __restrict__ keep_idx,
+                                                             int* __restrict__ keep_cnt, float* __restrict__ keep_det) {
+    __shared__ uint64_t s_kept[kBlocks];
+    __shared__ int s_wcnt[kBlocks];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = ws.n[b];
+    const size_t base = (size_t)b * kCap;
+    const bool valid = tid < n;
+
+    // every wave pre-loads its 64 rows (words 0..wave are meaningful) while earlier waves take their turn
+    uint64_t row[kBlocks];
+    {
+        const uint64_t* src = ws.mask + (base + tid) * kBlocks;
+#pragma unroll
+        for (int c = 0; c < kBlocks; ++c) row[c] = (valid && c <= wave) ? src[c] : 0ull;
+    }
+    uint64_t supby = 0;
+#pragma unroll
+    for (int c = 0; c < kBlocks; ++c)
+        if (c == wave) supby = row[c];
+    // columns of this block's own 64x64 tile that suppress anything at all (wave-wide OR of the rows)
+    uint64_t colany = supby;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) colany |= shfl_xor_u64(colany, m);
+
     bool rem = !valid;
     const int nblk = (n + 63) >> 6;
     for (int bi = 0; bi < nblk; ++bi) {
         if (wave == bi) {
-            // Keys are sorted by class first, so the boxes that can suppress this lane's box are the contiguous run of
-            // equal-class lanes right before it: walk that run only (typically a handful of boxes, not 63).
-            uint64_t supby = 0;  // bit k: sorted box (64*bi + k), k < lane, would suppress this lane's box
-            for (int k = lane - 1; k >= 0; --k) {
-                const int rk = (bi << 6) + k;
-                if (s_cls[rk] != my_cls) break;
-                if (iou_xyxy(s_box[rk], my_box) > nms_thresh) supby |= 1ull << k;
-            }
+            uint64_t hit = 0;
+#pragma unroll
+            for (int c = 0; c < kBlocks; ++c)
+                if (c < wave) hit |= row[c] & s_kept[c];
+            rem = rem || hit != 0;
             uint64_t dead = __ballot(rem);
-            for (int k = 0; k < 64; ++k) {
-                if (!((dead >> k) & 1ull)) dead |= __ballot((supby >> k) & 1ull);
+            uint64_t todo = colany & ~dead;
+            while (todo) {  // ascending over live boxes that suppress something: exactly the sequential greedy order
+                const int k = __ffsll((unsigned long long)todo) - 1;
+                const uint64_t col = __ballot((supby >> k) & 1ull);
+                dead |= col;
+                todo &= ~col & ~(1ull << k);
             }
             rem = (dead >> lane) & 1ull;
             if (lane == 0) s_kept[bi] = ~dead;
         }
         __syncthreads();
-        // Later boxes have a class >= every class of block bi, so only the tail run of block bi with exactly this
-        // class can matter: find its start by binary search (classes are sorted) and test the KEPT boxes of that run.
-        if (wave > bi && !rem && s_cls[(bi << 6) + 63] == my_cls) {
-            int lo = 0, hi = 63;  // first index in the block whose class equals my_cls
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_cls[(bi << 6) + mid] < my_cls) lo = mid + 1; else hi = mid;
-            }
-            uint64_t kept = s_kept[bi] & (~0ull << lo);
-            while (kept) {
-                const int k = __ffsll((unsigned long long)kept) - 1;
-                kept &= kept - 1;
-                if (iou_xyxy(s_box[(bi << 6) + k], my_box) > nms_thresh) {
-                    rem = true;
-                    break;
-                }
-            }
-        }
     }
-
-    TRTX_NMS_STAMP(3);
-    // ---- ordered compaction -----------------------------------------------------------------------
+    // ordered compaction
     const bool keep = valid && !rem;
     const unsigned long long km = __ballot(keep);
-    __syncthreads();  // s_wcnt reuse
     if (lane == 0) s_wcnt[wave] = __popcll(km);
     __syncthreads();
     int pos = __popcll(km & ((1ull << lane) - 1ull));
     int total = 0;
 #pragma unroll
-    for (int w = 0; w < kCap / 64; ++w) {
-        const int c = s_wcnt[w];
-        if (w < wave) pos += c;
-        total += c;
+    for (int w = 0; w < kBlocks; ++w) {
+        const int cnt = s_wcnt[w];
+        if (w < wave) pos += cnt;
+        total += cnt;
     }
     if (keep) {
-        keep_idx[(size_t)b * max_out + pos] = orig;
+        keep_idx[(size_t)b * max_out + pos] = ws.orig[base + tid];
         if (keep_det) {
+            const float4 box = ws.box[base + tid];
             float* o = keep_det + ((size_t)b * max_out + pos) * 6;
-            o[0] = my_box.x;
-            o[1] = my_box.y;
-            o[2] = my_box.z;
-            o[3] = my_box.w;
-            o[4] = my_conf;
-            o[5] = my_cls;
+            o[0] = box.x;
+            o[1] = box.y;
+            o[2] = box.z;
+            o[3] = box.w;
+            o[4] = ws.conf[base + tid];
+            o[5] = ws.cls[base + tid];
         }
     }
     if (tid == 0) keep_cnt[b] = total;
-    TRTX_NMS_STAMP(4);
-    if (dbg && tid == 0 && b == 0) dbg[5] = n;
 }
 
 }  // namespace
 
-extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh,
-                                 float nms_thresh, int32_t* keep_idx, int32_t* keep_cnt, float* keep_det,
-                                 hipStream_t stream) {
-    if (!decode_out || !keep_idx || !keep_cnt || batch < 1 || max_out < 1) return TRTX_ERR_INVALID;
-    if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
-    const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
-    hipLaunchKernelGGL(yolo_nms_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem,
-                       trtx::kYoloDetFloats, max_out, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, (long long*)nullptr);
-    return trtx::check_launch("trtx_yolo_nms");
+extern "C" size_t trtx_yolo_nms_workspace(int batch) {
+    return batch < 1 ? 0 : nms_ws_bytes(batch);
 }
 
-// development probe: same kernel with per-phase wall-clock stamps of image 0 (100 MHz ticks) in dbg[0..5]
-extern "C" int32_t trtx_yolo_nms_probe(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
-                                       int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, long long* dbg, hipStream_t stream) {
+extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                 int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+    if (!decode_out || !keep_idx || !keep_cnt || batch < 1 || max_out < 1) return TRTX_ERR_INVALID;
+    if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < nms_ws_bytes(batch)) return TRTX_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return TRTX_ERR_INVALID;
+    const NmsWs ws = nms_ws_carve(workspace, batch);
     const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
-    hipLaunchKernelGGL(yolo_nms_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, trtx::kYoloDetFloats, max_out,
-                       conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, dbg);
-    return trtx::check_launch("trtx_yolo_nms_probe");
+    hipLaunchKernelGGL(yolo_nms_sort_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, trtx::kYoloDetFloats,
+                       max_out, conf_thresh, ws);
+    hipLaunchKernelGGL(yolo_nms_mask_kernel, dim3(kBlocks, kBlocks, batch), dim3(64), 0, stream, ws, nms_thresh);
+    hipLaunchKernelGGL(yolo_nms_scan_kernel, dim3(batch), dim3(kCap), 0, stream, ws, max_out, keep_idx, keep_cnt, keep_det);
+    return trtx::check_launch("trtx_yolo_nms");
 }
