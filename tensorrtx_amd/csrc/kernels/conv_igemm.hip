@@ -1,27 +1,35 @@
-// Fused implicit-GEMM convolution for gfx950 (MI355X): NHWC fp16 in/out, fp32 accumulate on the
-// matrix cores (v_mfma_f32_16x16x32_f16), epilogue = +bias(folded BN) -> act1 -> +residual -> act2,
-// stored through an LDS transpose as 16-byte NHWC rows into an arbitrary channel slice of the
-// destination (so addConcatenation costs nothing).
+// Fused implicit-GEMM convolution for gfx950 (MI355X): NHWC fp16 activations, fp16 weights packed [Cout_pad][Kpad],
+// fp32 accumulation on v_mfma_f32_16x16x32_f16, epilogue bias(BN) -> act1 -> (+residual) -> act2 in registers.
+// This is the kernel behind every Conv(+Scale)(+Activation)(+ElementWise SUM)(+Activation) chain the reference
+// builders emit (yolov8/src/block.cpp:79-110, resnet/resnet50.cpp:111-151, rcnn/backbone.hpp:104-169).
 //
-// This is the engine side of what the reference delegates to TensorRT for every
-// addConvolutionNd + addScale(BN) + addActivation/addElementWise chain
-// (yolov8/src/block.cpp:79-96 convBnSiLU; resnet/resnet50.cpp:111-151 bottleneck).
+// GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = taps x CinK with CinK = Cin rounded up to the k-step (32 or 64
+// halfs), so a k-step never straddles a filter tap and every address decision is wave-uniform.
 //
-// GEMM view:  M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin (k = (r*kw+q)*Cin + c).
-//   A[m][k] gathered on the fly from the NHWC input (zero outside the image),
-//   B[n][k] = pre-packed weights [Cout_pad][K_pad] (K contiguous, zero padded).
-// Tile: 128 pixels x (16*NFRAG) channels x 32 k per step; 4 waves, wave w owns pixel rows
-// [32w, 32w+32) x all columns (2 x NFRAG accumulator fragments).  Global loads for step t+1 are
-// issued before the MFMAs of step t and written to the other LDS buffer afterwards (one barrier
-// per step).  LDS rows are 64 B with an XOR chunk swizzle so fragment reads are bank-conflict free.
+// What the measurements on MI355X dictated (tools/hip/ldsdma_bw.hip, tools/pmc_conv2.sh, DESIGN.md "conv kernel"):
+//   * the loop was instruction-issue bound (~150 instructions and ~20 branches per k-step for 8 MFMAs), not memory
+//     bound: L2 hit rate 93 %, fabric reads 1x the input, 60 % of wave time in s_waitcnt.  The steady-state k-step
+//     here is straight-line code: tap validity comes from a per-pixel bit mask built once, the tap walk is scalar
+//     select arithmetic, the three pipeline stages are unrolled so every LDS address is an immediate, and tiles past
+//     the end of K are issued as out-of-range (zero-fill, no memory access) instead of being branched around;
+//   * operands go L2 -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction): out-of-image taps,
+//     rows >= M and channels >= Cin are handled by the buffer descriptor's range check (offset 0x80000000 -> zeros);
+//   * the vector L1 serves whole 128-B lines: a 64-B slice of a pixel costs the same slot as the full line, so layers
+//     with Cin % 64 == 0 use 64-wide k-steps (BKT = 64: one line per pixel per step, half the barriers);
+//   * LDS rows are un-padded (the DMA writes lane-linear) and the 16-byte chunks are XOR-swizzled on the SOURCE side so
+//     the MFMA fragment reads (ds_read_b128) are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0);
+//   * consecutive workgroup ids are dealt round-robin to the 8 XCDs, so ids are remapped to give every XCD a contiguous
+//     range of output tiles (halo rows and the A tile shared by n-tiles stay in one L2): fabric reads 2.3x -> 1.0x.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "../common.h"
 #include "kernels.h"
 
-// development hook: tools/hip/igemm_phase_probe.hip defines TRTX_STAMP to record shader-clock stamps of one k-step
 #ifndef TRTX_STAMP
 #define TRTX_STAMP(i, kt)
 #endif
@@ -30,148 +38,173 @@ namespace trtx {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDS_ROW = 32;  // halfs per LDS row: 64 B, un-padded; the four 16-byte chunks of a row are XOR-swizzled
+constexpr int NSTAGE = 3;
+constexpr unsigned kOOB = 0x80000000u;  // offset beyond any num_records: the buffer load returns 0
+constexpr int kMaxTaps = 30;            // tap-validity mask is one 32-bit word (+2 bits of run-out past the last tap)
 
-// chunk permutation that makes ds_read_b128 of an MFMA fragment (16 rows x one chunk per 16-lane service group, see the
-// group table in MI355X_MICROARCH.md) hit 16 distinct 16-byte slots: physical chunk = logical chunk ^ P[(row >> 2) & 3]
-__device__ __forceinline__ int swz(int row) {
-    return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;  // P = {0, 2, 3, 1}
-}
-
-__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+__device__ __attribute__((noinline)) float act_slow(float v, int act, float alpha) {
     switch (act) {
-        case ACT_RELU: return v > 0.f ? v : 0.f;
         case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-        case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // v_exp + v_rcp (1 ulp), rounded to fp16 afterwards
         case ACT_LEAKY: return v > 0.f ? v : v * alpha;
         case ACT_TANH: return tanhf(v);
         default: return v;
     }
 }
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    if (act == ACT_NONE) return v;
+    if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    return act_slow(v, act, alpha);
+}
 
-template <int NFRAG>
-__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
+// physical 16-byte chunk = logical chunk ^ swz(row); see the header comment
+template <int BKT>
+__device__ __forceinline__ int swz(int row) {
+    if (BKT == 32) return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;  // P = {0, 2, 3, 1} over (row >> 2) & 3
+    return (row >> 1) & 7;
+}
+
+// TPS = filter taps per k-step: 1 normally; 2 for Cin <= 16 (CinK = 16), where one 32-wide step covers taps 2kt and 2kt+1
+// and the tap a lane fetches depends on which half of the row it fills.
+template <int NFRAG, int BKT, int TPS>
+__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
+                                                             int total_tiles, int xcd_chunk, int dbg) {
     constexpr int BN = 16 * NFRAG;
-    constexpr int A_TILE = BM * LDS_ROW;  // halfs
-    constexpr int B_TILE = BN * LDS_ROW;
-    constexpr int SMEM_HALFS = 2 * (A_TILE + B_TILE);
-    __shared__ __attribute__((aligned(16))) _Float16 smem[SMEM_HALFS];
-    _Float16* As = smem;
-    _Float16* Bs = smem + 2 * A_TILE;
+    constexpr int ROW_B = BKT * 2;                 // bytes per LDS row
+    constexpr int CH = BKT / 8;                    // 16-byte chunks per row
+    constexpr int RPI = 64 / CH;                   // rows filled by one wave-instruction (16 / 8)
+    constexpr int A_LOADS = BM / (4 * RPI);        // per wave per k-step (2 / 4)
+    constexpr int B_PASSES = (BN + 4 * RPI - 1) / (4 * RPI);
+    constexpr int B_ROWS = B_PASSES * 4 * RPI;     // rows beyond BN are dummy targets
+    constexpr int A_BYTES = BM * ROW_B;
+    constexpr int STAGE_BYTES = A_BYTES + B_ROWS * ROW_B;
+    constexpr int LOADS_PER_TILE = A_LOADS + B_PASSES;
+    constexpr int KSUB = BKT / 32;                 // MFMA k-slices per k-step
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const _Float16* __restrict__ in = static_cast<const _Float16*>(p.in);
-    const _Float16* __restrict__ wgt = static_cast<const _Float16*>(p.wgt);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    if (xcd_chunk) {  // XCD-aware order: id -> (xcd = id % 8, slot = id / 8) -> contiguous tile range per XCD
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
 
-    // ---- per-thread A-gather state: rows (tid>>2) and (tid>>2)+64, k-chunk (tid&3) --------------
-    // Address generation is kept off the vector ALU as far as possible (it, not the MFMA pipe, was the busiest
-    // unit of the first version): each thread precomputes one pointer per row; the filter tap (r, q) and the
-    // channel offset of a k-tile are wave-uniform, so their offset is a scalar added per step.
-    const int kc = tid & 3;
-    int a_hi0[2], a_wi0[2];
-    const _Float16* a_ptr[2];
-    bool a_ok[2];
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
+
+    // ---- per-lane source description.  Instruction i of wave w fills LDS rows (4i + w) * RPI + [0, RPI); lane l
+    // writes row + l / CH, physical chunk l % CH, so it fetches LOGICAL chunk (l % CH) ^ swz(row).
+    const int lrow = lane / CH;
+    const int lswz = BKT == 32 ? swz<32>(lrow) : ((lrow >> 1) | ((wave & 1) << 2));  // row base is a multiple of RPI
+    const int lchunk = (lane % CH) ^ lswz;
+    const int tsel = TPS == 2 ? (lchunk >> 1) : 0;         // which of the step's taps this lane fetches
+    const int cchunk = TPS == 2 ? (lchunk & 1) : lchunk;   // 8-channel chunk inside the tap
     const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    unsigned a_base[A_LOADS];   // byte offset of (n, hi0, wi0, channel lchunk*8); wraps for border pixels (masked)
+    unsigned a_rows[A_LOADS];   // bit r: filter row r of this pixel lies inside the image (0 for pixels >= M)
+    unsigned a_cols[A_LOADS];   // bit q: filter column q lies inside the image
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int n = mm / HoWo;
-        const int rem = mm - n * HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        a_hi0[i] = ho * p.stride_h - p.pad_h;
-        a_wi0[i] = wo * p.stride_w - p.pad_w;
-        // pointer to (n, hi0, wi0, channel kc*8); may lie outside the tensor for border pixels, it is only
-        // dereferenced after the bounds test
-        a_ptr[i] = in + (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.ld_in + kc * 8;
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int m = m0 + (4 * i + wave) * RPI + lrow;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        // quotients are small (image index, output row): a float estimate is within +-1, fixed up exactly
+        int n = (int)((float)mm * inv_howo);
+        int rem = mm - n * HoWo;
+        if (rem < 0) { --n; rem += HoWo; }
+        if (rem >= HoWo) { ++n; rem -= HoWo; }
+        int ho = (int)((float)rem * inv_wo);
+        int wo = rem - ho * p.Wo;
+        if (wo < 0) { --ho; wo += p.Wo; }
+        if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
+        const int hi0 = ho * p.stride_h - p.pad_h;
+        const int wi0 = wo * p.stride_w - p.pad_w;
+        a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;
+        unsigned rows = 0, cols = 0;
+        for (int r = 0; r < p.kh; ++r)
+            if ((unsigned)(hi0 + r * p.dil_h) < (unsigned)p.H) rows |= 1u << r;
+        for (int q = 0; q < p.kw; ++q)
+            if ((unsigned)(wi0 + q * p.dil_w) < (unsigned)p.W) cols |= 1u << q;
+        a_rows[i] = ok ? rows : 0u;
+        a_cols[i] = cols;
     }
-    constexpr int B_PASSES = (BN + 63) / 64;
-    const _Float16* b_ptr = wgt + (size_t)(n0 + (tid >> 2)) * p.Kpad + kc * 8;  // pass j adds 64*j rows
-    const bool uniform_taps = (p.Cin % BK) == 0;  // every k-tile lies inside one filter tap
-    // wave-uniform position of the current k-tile: tap (ur, uq), first channel uc
-    int ur = 0, uq = 0, uc = 0;
-    // per-thread position (general path: Cin % 32 != 0, a k-tile may straddle taps)
-    int kr, kq, kcin;
-    {
-        const int k = kc * 8;
-        const int tap = k / p.Cin;
-        kcin = k - tap * p.Cin;
-        kr = tap / p.kw;
-        kq = tap - kr * p.kw;
+    const int cmax = p.Cin - cchunk * 8;  // this lane's chunk holds real channels while uc < cmax
+    unsigned b_off[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+        const int row = (4 * j + wave) * RPI + lrow;
+        b_off[j] = row < BN ? (unsigned)(((size_t)(n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;
     }
 
-    uint4 a_reg[2];
-    uint4 b_reg[B_PASSES];
-    const int nk = p.Kpad / BK;
-
-    auto load_tile = [&](int kt) {
-        if (uniform_taps) {
-            const int toff = (ur * p.dil_h * p.W + uq * p.dil_w) * p.ld_in + uc;  // scalar
-            const bool tap_ok = ur < p.kh;
+    // wave-uniform walk over K: tap (r, q), channel offset uc inside the tap, byte offset of the tap.  With TPS == 2 the
+    // walk keeps two taps (index 0: tap 2kt, index 1: tap 2kt+1) and every lane selects its own.
+    const int nk = p.Kpad / BKT;
+    int s_kt = 0, s_uc = 0;
+    int s_r[TPS], s_q[TPS];
+    unsigned s_toff[TPS];
+    auto tap_next = [&](int& r, int& q) {  // select arithmetic, no branches
+        ++q;
+        const int wq = q == p.kw;
+        q = wq ? 0 : q;
+        r += wq;
+    };
+    s_r[0] = 0;
+    s_q[0] = 0;
+    if (TPS == 2) {
+        s_r[1] = 0;
+        s_q[1] = 0;
+        tap_next(s_r[1], s_q[1]);
+    }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int hi = a_hi0[i] + ur * p.dil_h;
-                const int wi = a_wi0[i] + uq * p.dil_w;
-                const bool ok = a_ok[i] && tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + toff);
-                a_reg[i] = v;
-            }
-            uc += BK;
-            if (uc >= p.Cin) {
-                uc = 0;
-                if (++uq == p.kw) {
-                    uq = 0;
-                    ++ur;
-                }
+    for (int t = 0; t < TPS; ++t) s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
+
+    auto issue_tile = [&](int stage) {
+        char* sbase = smem + stage * STAGE_BYTES;
+        const bool live = s_kt < nk;
+        const int r = (TPS == 2 && tsel) ? s_r[TPS - 1] : s_r[0];
+        const int q = (TPS == 2 && tsel) ? s_q[TPS - 1] : s_q[0];
+        const unsigned add = ((TPS == 2 && tsel) ? s_toff[TPS - 1] : s_toff[0]) + (unsigned)s_uc * 2u;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const bool ok = ((a_rows[i] >> r) & (a_cols[i] >> q) & 1u) && s_uc < cmax && live && !(dbg & 1);
+            const unsigned voff = ok ? a_base[i] + add : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) {
+            const unsigned voff = (live && !(dbg & 2)) ? b_off[j] : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (4 * j + wave) * RPI * ROW_B), 16, voff, 0, 0,
+                                                     0);
+            b_off[j] += BKT * 2;  // kOOB stays out of range for any K < 2^30
+        }
+        ++s_kt;
+        if (TPS == 2) {
+#pragma unroll
+            for (int t = 0; t < TPS; ++t) {
+                tap_next(s_r[t], s_q[t]);
+                tap_next(s_r[t], s_q[t]);
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int hi = a_hi0[i] + kr * p.dil_h;
-                const int wi = a_wi0[i] + kq * p.dil_w;
-                const bool ok = a_ok[i] && kr < p.kh && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + ((long)(kr * p.dil_h) * p.W + kq * p.dil_w) * p.ld_in + kcin - kc * 8);
-                a_reg[i] = v;
-            }
-            kcin += BK;
-            while (kcin >= p.Cin) {
-                kcin -= p.Cin;
-                if (++kq == p.kw) {
-                    kq = 0;
-                    ++kr;
-                }
-            }
+            s_uc += BKT;
+            const int wrap = s_uc >= p.CinK;
+            s_uc = wrap ? 0 : s_uc;
+            const int q1 = s_q[0] + wrap;
+            const int wq = q1 == p.kw;
+            s_q[0] = wq ? 0 : q1;
+            s_r[0] += wq;
         }
 #pragma unroll
-        for (int j = 0; j < B_PASSES; ++j) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((tid >> 2) + 64 * j < BN) v = *reinterpret_cast<const uint4*>(b_ptr + (size_t)(64 * j) * p.Kpad + kt * BK);
-            b_reg[j] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (tid >> 2) + 64 * i;
-            *reinterpret_cast<uint4*>(As + buf * A_TILE + row * LDS_ROW + (kc ^ swz(row)) * 8) = a_reg[i];
-        }
-#pragma unroll
-        for (int j = 0; j < B_PASSES; ++j) {
-            const int row = (tid >> 2) + 64 * j;
-            if (row < BN) *reinterpret_cast<uint4*>(Bs + buf * B_TILE + row * LDS_ROW + (kc ^ swz(row)) * 8) = b_reg[j];
-        }
+        for (int t = 0; t < TPS; ++t) s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
     };
 
     floatx4 acc[2][NFRAG];
@@ -180,46 +213,108 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NFRAG; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // fragment read offsets inside a stage: row (lane & 15), logical chunk (lane >> 4) [+ 4 for the second k-slice]
+    const int frow = lane & 15;
+    const int fswz = swz<BKT>(frow);
+    int f_off[KSUB];
+#pragma unroll
+    for (int h = 0; h < KSUB; ++h) f_off[h] = frow * ROW_B + ((((lane >> 4) + 4 * h) ^ fswz) * 16);
+    const int a_frag = wave * 32 * ROW_B;
 
-    const int frag_row = lane & 15;
-    const int frag_k = ((lane >> 4) ^ swz(frag_row)) * 8;  // tile bases are multiples of 16 rows: swz depends on the lane only
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        TRTX_STAMP(0, kt);
-        if (kt + 1 < nk) load_tile(kt + 1);
-        TRTX_STAMP(1, kt);
-        const _Float16* Ab = As + buf * A_TILE + (wave * 32 + frag_row) * LDS_ROW + frag_k;
-        const _Float16* Bb = Bs + buf * B_TILE + frag_row * LDS_ROW + frag_k;
-        half8 af[2];
+    auto compute = [&](int stage) {
+        const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(Ab + i * 16 * LDS_ROW);
+        for (int h = 0; h < KSUB; ++h) {
+            half8 af[2];
 #pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
-            const half8 bf = *reinterpret_cast<const half8*>(Bb + j * 16 * LDS_ROW);
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);  // D^T: rows = channels
+            for (int j = 0; j < NFRAG; ++j) {
+                const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+            }
         }
-        TRTX_STAMP(2, kt);
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        TRTX_STAMP(3, kt);
-        __syncthreads();
-        TRTX_STAMP(4, kt);
+    };
+
+    // one k-step: tile kt has landed once at most the LOADS_PER_TILE loads of tile kt+1 are still in flight; the
+    // barrier also guarantees every wave finished reading the stage that is refilled next.
+#define TRTX_KSTEP(S)                                                         \
+    {                                                                         \
+        TRTX_STAMP(0, kt);                                                    \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory"); \
+        TRTX_STAMP(1, kt);                                                    \
+        __builtin_amdgcn_s_barrier();                                         \
+        TRTX_STAMP(2, kt);                                                    \
+        issue_tile(((S) + 2) % NSTAGE);                                       \
+        TRTX_STAMP(3, kt);                                                    \
+        if (!(dbg & 4)) compute(S);                                           \
+        TRTX_STAMP(4, kt);                                                    \
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------------
-    // The MFMAs were issued with the operands swapped (D^T = W * A^T), so each lane holds, per fragment, FOUR
-    // CONSECUTIVE OUTPUT CHANNELS of ONE pixel: channel = n0 + 16j + 4*(lane>>4) + r, pixel = m0 + 32*wave + 16i +
-    // (lane&15).  They are finished in registers (bias, activation, residual, activation) and stored straight to
-    // NHWC global memory as 8-byte runs: no LDS staging, no barrier, 4x fewer store instructions than the first
-    // version (instruction issue, not bandwidth, bounds these layers).
+    issue_tile(0);
+    issue_tile(1);
+    for (int kt = 0; !(dbg & 16);) {
+        TRTX_KSTEP(0);
+        if (++kt == nk) break;
+        TRTX_KSTEP(1);
+        if (++kt == nk) break;
+        TRTX_KSTEP(2);
+        if (++kt == nk) break;
+    }
+#undef TRTX_KSTEP
+    // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: bias/BN + act1 in registers (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15) of
+    // its wave's 32 rows), then through a wave-private LDS tile so that global traffic is row-major 16-byte chunks:
+    // residual reads and output stores cover whole 128-byte lines instead of 32-byte slivers.
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const int px_in = lane & 15;
     const int ch_in = (lane >> 4) * 4;
+    const bool second = res || p.act2 != ACT_NONE;
+    if (dbg & 8) return;
+    if (!p.scalar_out) {
+        constexpr int RS = BN * 2 + 16;  // padded row stride: 16 consecutive rows start in distinct bank groups
+        static_assert(4 * 32 * RS <= NSTAGE * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
+        __syncthreads();  // every wave is done reading the last stage
+        char* mine = smem + wave * 32 * RS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) {
+                const int co = n0 + j * 16 + ch_in;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && co < p.Cout_pad) bv = *reinterpret_cast<const float4*>(p.bias + co);
+                half4 o;
+                o[0] = (_Float16)act_apply(acc[i][j][0] + bv.x, p.act1, p.alpha1);
+                o[1] = (_Float16)act_apply(acc[i][j][1] + bv.y, p.act1, p.alpha1);
+                o[2] = (_Float16)act_apply(acc[i][j][2] + bv.z, p.act1, p.alpha1);
+                o[3] = (_Float16)act_apply(acc[i][j][3] + bv.w, p.act1, p.alpha1);
+                *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
+            }
+        // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
+        constexpr int CPR = BN / 8;  // 16-byte chunks per row
+#pragma unroll
+        for (int t = 0; t < NFRAG; ++t) {
+            const int q = t * 64 + lane;
+            const int row = q / CPR, cc = q % CPR;
+            const int m = m0 + wave * 32 + row;
+            const int co = n0 + cc * 8;
+            if (m >= p.M || co >= p.Cout) continue;
+            half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
+            if (second) {
+                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+            }
+            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+        }
+        return;
+    }
+    // ragged channel counts / unaligned slices: element-wise stores straight from the accumulators
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wave * 32 + i * 16 + px_in;
@@ -230,44 +325,264 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p) {
         for (int j = 0; j < NFRAG; ++j) {
             const int co = n0 + j * 16 + ch_in;
             if (co >= p.Cout) continue;
-            float v[4];
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);  // bias is padded to Cout_pad
-            v[0] = apply_act(acc[i][j][0] + bv.x, p.act1, p.alpha1);
-            v[1] = apply_act(acc[i][j][1] + bv.y, p.act1, p.alpha1);
-            v[2] = apply_act(acc[i][j][2] + bv.z, p.act1, p.alpha1);
-            v[3] = apply_act(acc[i][j][3] + bv.w, p.act1, p.alpha1);
-            if (!p.scalar_out) {
-                if (res || p.act2 != ACT_NONE) {
-                    half4 rv = half4{0, 0, 0, 0};
-                    if (res) rv = *reinterpret_cast<const half4*>(rrow + co);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
+            const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act((float)(_Float16)v[e] + (float)rv[e], p.act2, p.alpha2);
-                }
-                half4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *reinterpret_cast<half4*>(orow + co) = o;
-            } else {
-                // ragged channel counts / unaligned channel slices: element-wise with bounds checks
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (co + e < p.Cout) {
-                        float x = v[e];
-                        if (res || p.act2 != ACT_NONE) x = apply_act((float)(_Float16)x + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
-                        orow[co + e] = (_Float16)x;
-                    }
+            for (int e = 0; e < 4; ++e) {
+                if (co + e < p.Cout) {
+                    float x = act_apply(acc[i][j][e] + b4[e], p.act1, p.alpha1);
+                    if (second) x = act_apply((float)(_Float16)x + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
+                    orow[co + e] = (_Float16)x;
                 }
             }
         }
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M variant (20x20 maps at batch 32 give M = 12800: 100 tiles of 128 rows for 256 CUs, and a 3x3 conv over 256
+// channels is a chain of 72 dependent k-steps).  Here a workgroup owns a 64 x BN tile and its four waves SPLIT K: each
+// wave runs its own quarter of the k-steps through a wave-private LDS pipeline (no barrier inside the loop, no coupling
+// between waves), the four partial accumulators meet in LDS once at the end.  Twice the tiles, a quarter of the chain.
 template <int NFRAG>
-void launch(const ConvArgs& a, hipStream_t s) {
+__global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
+                                                                 int total_tiles, int xcd_chunk) {
+    constexpr int BKT = 32, ROW_B = 64, WM = 64;
+    constexpr int BN = 16 * NFRAG;
+    constexpr int A_LOADS = WM / 16;                      // 16 rows per wave-instruction
+    constexpr int B_LOADS = NFRAG;
+    constexpr int A_BYTES = WM * ROW_B;
+    constexpr int STAGE_BYTES = A_BYTES + BN * ROW_B;
+    constexpr int WAVE_BYTES = NSTAGE * STAGE_BYTES;
+    constexpr int LOADS_PER_TILE = A_LOADS + B_LOADS;
+    constexpr int PS = BN * 4 + 16;                       // partial-tile row stride (fp32, padded)
+    static_assert(WM * PS <= WAVE_BYTES, "partial tile must fit in the wave's stage buffers");
+    __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    if (xcd_chunk) {
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    const int m0 = (tile / tiles_n) * WM;
+    const int n0 = (tile % tiles_n) * BN;
+    char* mine = smem + wave * WAVE_BYTES;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
+
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ swz<32>(lrow);
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    unsigned a_base[A_LOADS], a_rows[A_LOADS], a_cols[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int m = m0 + i * 16 + lrow;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        int n = (int)((float)mm * inv_howo);
+        int rem = mm - n * HoWo;
+        if (rem < 0) { --n; rem += HoWo; }
+        if (rem >= HoWo) { ++n; rem -= HoWo; }
+        int ho = (int)((float)rem * inv_wo);
+        int wo = rem - ho * p.Wo;
+        if (wo < 0) { --ho; wo += p.Wo; }
+        if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
+        const int hi0 = ho * p.stride_h - p.pad_h;
+        const int wi0 = wo * p.stride_w - p.pad_w;
+        a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + lchunk * 8) * 2u;
+        unsigned rows = 0, cols = 0;
+        for (int r = 0; r < p.kh; ++r)
+            if ((unsigned)(hi0 + r * p.dil_h) < (unsigned)p.H) rows |= 1u << r;
+        for (int q = 0; q < p.kw; ++q)
+            if ((unsigned)(wi0 + q * p.dil_w) < (unsigned)p.W) cols |= 1u << q;
+        a_rows[i] = ok ? rows : 0u;
+        a_cols[i] = cols;
+    }
+    const int cmax = p.Cin - lchunk * 8;
+
+    // this wave's contiguous share of the k-steps
+    const int nk = p.Kpad / BKT;
+    const int k_begin = (nk * wave) / 4, k_end = (nk * (wave + 1)) / 4;
+    const int steps = k_end - k_begin;
+    const int spt = p.CinK / BKT;  // k-steps per filter tap
+    int s_kt = k_begin;
+    int s_uc, s_r, s_q;
+    {
+        const int tap = k_begin / spt;
+        s_uc = (k_begin - tap * spt) * BKT;
+        s_r = tap / p.kw;
+        s_q = tap - s_r * p.kw;
+    }
+    unsigned s_toff = (unsigned)((s_r * p.dil_h * p.W + s_q * p.dil_w) * p.ld_in) * 2u;
+    unsigned b_off[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j)
+        b_off[j] = (unsigned)(((size_t)(n0 + j * 16 + lrow) * p.Kpad + (size_t)k_begin * BKT + lchunk * 8) * 2);
+
+    auto issue_tile = [&](int stage) {
+        char* sbase = mine + stage * STAGE_BYTES;
+        const bool live = s_kt < k_end;
+        const unsigned add = s_toff + (unsigned)s_uc * 2u;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const bool ok = ((a_rows[i] >> s_r) & (a_cols[i] >> s_q) & 1u) && s_uc < cmax && live;
+            const unsigned voff = ok ? a_base[i] + add : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + i * 16 * ROW_B), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const unsigned voff = live ? b_off[j] : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + j * 16 * ROW_B), 16, voff, 0, 0, 0);
+            b_off[j] += BKT * 2;
+        }
+        ++s_kt;
+        s_uc += BKT;
+        const int wrap = s_uc >= p.CinK;
+        s_uc = wrap ? 0 : s_uc;
+        s_q += wrap;
+        const int wq = s_q == p.kw;
+        s_q = wq ? 0 : s_q;
+        s_r += wq;
+        s_toff = (unsigned)((s_r * p.dil_h * p.W + s_q * p.dil_w) * p.ld_in) * 2u;
+    };
+
+    floatx4 acc[A_LOADS][NFRAG];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int f_off = frow * ROW_B + (((lane >> 4) ^ swz<32>(frow)) * 16);
+
+    auto compute = [&](int stage) {
+        const char* sb = mine + stage * STAGE_BYTES;
+        half8 af[A_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) af[i] = *reinterpret_cast<const half8*>(sb + i * 16 * ROW_B + f_off);
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) {
+            const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off);
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+#define TRTX_WSTEP(S)                                                         \
+    {                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory"); \
+        issue_tile(((S) + 2) % NSTAGE);                                       \
+        compute(S);                                                           \
+    }
+    issue_tile(0);
+    issue_tile(1);
+    for (int kt = 0; kt < steps;) {
+        TRTX_WSTEP(0);
+        if (++kt >= steps) break;
+        TRTX_WSTEP(1);
+        if (++kt >= steps) break;
+        TRTX_WSTEP(2);
+        ++kt;
+    }
+#undef TRTX_WSTEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- partial tiles -> LDS (wave-private, same bytes the wave's own DMA just finished with), then wave w finishes
+    // rows 16w .. 16w+15: sum of the four partials, bias/BN, act1, (+residual, act2), row-major 16-byte stores
+    const int px_in = lane & 15;
+    const int ch_in = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j)
+            *reinterpret_cast<floatx4*>(mine + (i * 16 + px_in) * PS + (j * 16 + ch_in) * 4) = acc[i][j];
+    __syncthreads();
+    _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
+    const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
+    const bool second = res || p.act2 != ACT_NONE;
+    constexpr int CPR = BN / 8;                  // 8-channel items per row
+    constexpr int ITEMS = 16 * CPR;              // per wave
+#pragma unroll
+    for (int t = 0; t < (ITEMS + 63) / 64; ++t) {
+        const int q = t * 64 + lane;
+        if (q >= ITEMS) break;
+        const int row = wave * 16 + q / CPR, cc = q % CPR;
+        const int m = m0 + row;
+        const int co = n0 + cc * 8;
+        if (m >= p.M || co >= p.Cout) continue;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const char* src = smem + w * WAVE_BYTES + row * PS + cc * 32;
+            const floatx4 lo = *reinterpret_cast<const floatx4*>(src);
+            const floatx4 hi = *reinterpret_cast<const floatx4*>(src + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += lo[e];
+                v[4 + e] += hi[e];
+            }
+        }
+        if (!p.scalar_out) {
+            half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = act_apply(v[e] + (p.bias ? p.bias[co + e] : 0.f), p.act1, p.alpha1);
+                if (second) x = act_apply((float)(_Float16)x + (float)rv[e], p.act2, p.alpha2);
+                o[e] = (_Float16)x;
+            }
+            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (co + e >= p.Cout) break;
+                float x = act_apply(v[e] + (p.bias ? p.bias[co + e] : 0.f), p.act1, p.alpha1);
+                if (second) x = act_apply((float)(_Float16)x + (res ? (float)res[(size_t)m * p.ld_res + co + e] : 0.f), p.act2, p.alpha2);
+                out[(size_t)m * p.ld_out + co + e] = (_Float16)x;
+            }
+        }
+    }
+}
+
+template <int NFRAG>
+void launch_wsk(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int BN = 16 * NFRAG;
-    dim3 grid((a.M + BM - 1) / BM, a.Cout_pad / BN);
-    hipLaunchKernelGGL(conv_igemm_f16_kernel<NFRAG>, grid, dim3(256), 0, s, a);
+    const int tiles_m = (a.M + 63) / 64, tiles_n = a.Cout_pad / BN;
+    const int total = tiles_m * tiles_n;
+    const int chunk = (total + 7) / 8;
+    hipLaunchKernelGGL((conv_igemm_wsk_f16_kernel<NFRAG>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total,
+                       chunk);
+}
+
+template <int NFRAG, int BKT, int TPS>
+void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    const int BN = 16 * NFRAG;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
+    const int total = tiles_m * tiles_n;
+    static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
+    const int chunk = plain ? 0 : (total + 7) / 8;
+    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes,
+                       tiles_n, total, chunk, dbg);
+}
+
+template <int BKT, int TPS>
+int32_t launch_bn(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    switch (a.bn) {
+        case 16: launch<1, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        case 32: launch<2, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        case 64: launch<4, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        case 80: launch<5, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        case 128: launch<8, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+    return TRTX_OK;
 }
 
 }  // namespace
@@ -283,20 +598,54 @@ int conv_igemm_pick_bn(int cout) {
     return conv_igemm_pick_bn(pad16);
 }
 
-bool conv_igemm_supported(const ConvArgs& a) {
-    const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
-    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.Kpad % BK == 0 && (out_vec || a.scalar_out);
+int conv_igemm_pick_bk(int cin) {
+    // 64-wide steps touch whole 128-B lines but triple-buffer 24..32 KB per stage: occupancy drops to 1-2 workgroups per
+    // CU and the layers of the BASELINE configs measured 15 % slower end to end, so they are opt-in
+    static const bool allow64 = getenv("TRTX_CONV_BK64") != nullptr;
+    return (cin % 64 == 0 && allow64) ? 64 : 32;
 }
 
-int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s) {
-    if (!conv_igemm_supported(a)) return TRTX_ERR_UNSUPPORTED;
-    switch (a.bn) {
-        case 16: launch<1>(a, s); break;
-        case 32: launch<2>(a, s); break;
-        case 64: launch<4>(a, s); break;
-        case 80: launch<5>(a, s); break;
-        case 128: launch<8>(a, s); break;
-        default: return TRTX_ERR_UNSUPPORTED;
+int conv_igemm_pick_cink(int cin, int bk) {
+    if (cin <= 16 && bk == 32) return 16;  // two taps per k-step
+    return (cin + bk - 1) / bk * bk;
+}
+
+bool conv_igemm_supported(const ConvArgs& a) {
+    const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
+    const int bk = a.CinK % 64 == 0 && a.bk == 64 ? 64 : 32;
+    const bool cink_ok = a.CinK % bk == 0 || (a.CinK == 16 && bk == 32);
+    const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
+    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
+           a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9;
+}
+
+int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
+    if (!conv_igemm_supported(a0)) return TRTX_ERR_UNSUPPORTED;
+    // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
+    const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
+    const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
+    const unsigned w_bytes = (unsigned)((size_t)a0.Cout_pad * a0.Kpad * 2);
+    for (int n0 = 0; n0 < a0.N; n0 += per) {
+        ConvArgs a = a0;
+        a.N = std::min(per, a0.N - n0);
+        a.M = a.N * a.Ho * a.Wo;
+        a.in = static_cast<const char*>(a0.in) + (size_t)n0 * img_in;
+        a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * 2;
+        if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * 2;
+        // extent of the addressed slice: last pixel's first byte + the channels this conv reads
+        const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 2);
+        // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel)
+        static const bool no_wsk = getenv("TRTX_CONV_NOWSK") != nullptr;  // A/B switch for the micro-benchmarks
+        const int tiles128 = ((a.M + BM - 1) / BM) * (a.Cout_pad / a.bn);
+        int32_t st = TRTX_OK;
+        if (!no_wsk && a.bk == 32 && a.CinK % 32 == 0 && tiles128 <= 256 && a.Kpad / 32 >= 16 && (a.bn == 64 || a.bn == 80)) {
+            if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
+            else launch_wsk<5>(a, in_bytes, w_bytes, s);
+        } else {
+            st = (a.bk == 64) ? launch_bn<64, 1>(a, in_bytes, w_bytes, s)
+                 : (a.CinK == 16 ? launch_bn<32, 2>(a, in_bytes, w_bytes, s) : launch_bn<32, 1>(a, in_bytes, w_bytes, s));
+        }
+        if (st != TRTX_OK) return st;
     }
     return check_launch("conv_igemm_f16");
 }

@@ -17,7 +17,7 @@ enum PoolOp : int { POOL_MAX = 0, POOL_AVG = 1 };
 // first channel of the slice they address and ld_* is the channel stride of the underlying buffer.
 struct ConvArgs {
     const void* in;
-    const void* wgt;    // igemm: fp16 [Cout_pad][Kpad], k = (r*kw+q)*Cin + c.  direct: fp32 [Cout][kh*kw*Cin/groups]
+    const void* wgt;    // igemm: fp16 [Cout_pad][Kpad], k = (r*kw+q)*CinK + c.  direct: fp32 [Cout][kh*kw*Cin/groups]
     const float* bias;  // [Cout_pad] (folded BN shift / conv bias) or nullptr
     void* out;
     const void* residual;  // same geometry as out, or nullptr
@@ -29,28 +29,18 @@ struct ConvArgs {
     float alpha1, alpha2;
     int bn;  // igemm column-tile width (16/32/64/80/128)
     int scalar_out;  // igemm: element-wise epilogue stores (Cout, channel stride or offset not a multiple of 8)
-};
-
-// geometry of the LDS-patch convolution kernel (conv_patch.hip), chosen per layer at plan time
-struct PatchGeom {
-    int th, tw;            // output tile (th*tw <= 128)
-    int ph, pw;            // input patch
-    int cc;                // input channels staged per chunk (32 or 64)
-    int tiles_h, tiles_w;  // tiles per image
+    int CinK;        // igemm: per-tap stride of the packed K axis: Cin rounded up to bk, or 16 (two taps per step);
+                     // Kpad = kh*kw*CinK rounded up to bk
+    int bk;          // igemm: k-step width in halfs (32, or 64 when CinK % 64 == 0)
 };
 
 // --- conv -------------------------------------------------------------------------------------------
-int conv_igemm_pick_bn(int cout);
+// fused implicit-GEMM conv on MFMA (conv_igemm.hip): LDS-DMA operands, range-checked gather, 3-stage pipeline
+int conv_igemm_pick_bn(int cout);   // column-tile width for a Cout
+int conv_igemm_pick_bk(int cin);    // k-step width for a (padded-to-8) Cin
+int conv_igemm_pick_cink(int cin, int bk);  // per-tap stride of the packed K axis
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
-// second generation: LDS-DMA operands, bounds-checked buffer loads, 3-stage pipeline (conv_igemm2.hip)
-bool conv_igemm2_supported(const ConvArgs& a);
-int32_t conv_igemm2_f16(const ConvArgs& a, hipStream_t s);
-// LDS-patch implicit GEMM (k x k, stride 1/2): weights fp16 [Cout_pad][chunk][tap][cc_pad] (conv_patch_kpad per row)
-bool conv_patch_plan(const ConvArgs& a, PatchGeom* g);
-size_t conv_patch_lds_bytes(const ConvArgs& a, const PatchGeom& g);
-int conv_patch_kpad(int cin, int kh, int kw, int cc);
-int32_t conv_patch_f16(const ConvArgs& a, const PatchGeom& g, hipStream_t s);
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);

@@ -45,14 +45,18 @@ extern "C" int32_t trtx_conv_packed_dims(int cout, int cin_pad, int kh, int kw, 
     const int b = conv_igemm_pick_bn(cout);
     if (bn) *bn = b;
     if (cout_pad) *cout_pad = (cout + b - 1) / b * b;
-    if (kpad) *kpad = (kh * kw * cin_pad + 31) / 32 * 32;
+    if (kpad) {
+        const int bk = conv_igemm_pick_bk(cin_pad);
+        *kpad = (kh * kw * conv_igemm_pick_cink(cin_pad, bk) + bk - 1) / bk * bk;
+    }
     return TRTX_OK;
 }
 
 extern "C" int32_t trtx_conv_pack_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
                                               const float* ch_scale, uint16_t* packed) {
     if (!w_kcrs || !packed || cin_pad < cin) return TRTX_ERR_INVALID;
-    pack_conv_weights_f16(w_kcrs, cout, cin, kh, kw, cin_pad, ch_scale, packed);
+    const int bk = conv_igemm_pick_bk(cin_pad);
+    pack_conv_weights_f16(w_kcrs, cout, cin, kh, kw, conv_igemm_pick_cink(cin_pad, bk), bk, ch_scale, packed);
     return TRTX_OK;
 }
 
@@ -75,13 +79,13 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.ld_out = ld_out; a.ld_res = ld_res;
     a.kh = kh; a.kw = kw; a.stride_h = sh; a.stride_w = sw; a.pad_h = ph; a.pad_w = pw; a.dil_h = 1; a.dil_w = 1;
     a.groups = 1;
-    a.K = kh * kw * Cin;
-    a.Kpad = (a.K + 31) / 32 * 32;
+    a.bk = conv_igemm_pick_bk(Cin);
+    a.CinK = conv_igemm_pick_cink(Cin, a.bk);
+    a.K = kh * kw * a.CinK;
+    a.Kpad = (a.K + a.bk - 1) / a.bk * a.bk;
     a.M = N * a.Ho * a.Wo;
     a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
     a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
-    static const bool force_v1 = getenv("TRTX_CONV_V1") != nullptr;  // A/B switch for the micro-benchmarks
-    if (!force_v1 && conv_igemm2_supported(a)) return conv_igemm2_f16(a, stream);
     return conv_igemm_f16(a, stream);
 }
 
@@ -93,52 +97,4 @@ extern "C" int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int 
 extern "C" int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ld_in,
                                                 trtx_stream_t stream) {
     return nhwc_to_nchw_f32(in, DT_F16, out, N, C, H, W, ld_in, stream);
-}
-
-// ---- LDS-patch convolution (development / micro-benchmark entry points)
-extern "C" int32_t trtx_conv_patch_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
-                                        int32_t* geom7, int32_t* cout_pad, int32_t* kpad) {
-    ConvArgs a{};
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = Cin; a.Cout = Cout;
-    a.kh = kh; a.kw = kw; a.stride_h = a.stride_w = stride; a.pad_h = a.pad_w = pad; a.dil_h = a.dil_w = 1; a.groups = 1;
-    a.Ho = (H + 2 * pad - kh) / stride + 1;
-    a.Wo = (W + 2 * pad - kw) / stride + 1;
-    a.bn = conv_igemm_pick_bn(Cout);
-    PatchGeom g{};
-    if (!conv_patch_plan(a, &g)) return TRTX_ERR_UNSUPPORTED;
-    const int v[7] = {g.th, g.tw, g.ph, g.pw, g.cc, g.tiles_h, g.tiles_w};
-    for (int i = 0; i < 7; ++i) geom7[i] = v[i];
-    *cout_pad = (Cout + a.bn - 1) / a.bn * a.bn;
-    *kpad = conv_patch_kpad(Cin, kh, kw, g.cc);
-    return TRTX_OK;
-}
-
-extern "C" int32_t trtx_conv_pack_weights_patch_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_eff, int cc,
-                                                    const float* ch_scale, uint16_t* packed) {
-    if (!w_kcrs || !packed) return TRTX_ERR_INVALID;
-    pack_conv_weights_patch_f16(w_kcrs, cout, cin, kh, kw, cin_eff, cc, ch_scale, packed);
-    return TRTX_OK;
-}
-
-extern "C" int32_t trtx_op_conv2d_nhwc_f16_patch(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked,
-                                                 const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int stride,
-                                                 int pad, int act1, const void* residual, int ld_res, int act2,
-                                                 trtx_stream_t stream) {
-    ConvArgs a{};
-    a.in = in; a.wgt = wpacked; a.bias = bias; a.out = out; a.residual = residual;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in; a.Cout = Cout;
-    a.kh = kh; a.kw = kw; a.stride_h = a.stride_w = stride; a.pad_h = a.pad_w = pad; a.dil_h = a.dil_w = 1; a.groups = 1;
-    a.Ho = (H + 2 * pad - kh) / stride + 1;
-    a.Wo = (W + 2 * pad - kw) / stride + 1;
-    a.bn = conv_igemm_pick_bn(Cout);
-    a.Cout_pad = (Cout + a.bn - 1) / a.bn * a.bn;
-    a.ld_out = ld_out; a.ld_res = ld_res;
-    a.M = N * a.Ho * a.Wo;
-    a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
-    a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
-    PatchGeom g{};
-    if (!conv_patch_plan(a, &g)) return TRTX_ERR_UNSUPPORTED;
-    a.K = kh * kw * Cin;
-    a.Kpad = conv_patch_kpad(Cin, kh, kw, g.cc);
-    return conv_patch_f16(a, g, stream);
 }

@@ -16,6 +16,16 @@ trtx_engine::~trtx_engine() {
 }
 
 trtx_context::~trtx_context() {
+    for (hipStream_t st : lane_stream)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (hipEvent_t ev : op_event)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : lane_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (start_event) (void)hipEventDestroy(start_event);
     if (d_arena) (void)hipFree(d_arena);
 }
 
@@ -81,8 +91,25 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         for (auto& ev : evs) TRTX_HIP_TRY(hipEventCreate(&ev));
         TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
     }
+    // lanes: independent branches of the plan run on the context's own streams, fenced by events (profiling runs
+    // everything on the caller's stream so that the per-op events measure isolated kernels)
+    hipStream_t const user_stream = stream;
+    const bool lanes = !prof && plan.num_lanes > 1;
+    std::vector<char> lane_started(plan.num_lanes, 0);
+    if (lanes) TRTX_HIP_TRY(hipEventRecord(c->start_event, user_stream));
     for (size_t k = 0; k < plan.ops.size(); ++k) {
         const POp& op = plan.ops[k];
+        hipStream_t stream = user_stream;  // shadows the parameter: the stream THIS op is issued on
+        if (lanes) {
+            if (op.lane > 0) {
+                stream = c->lane_stream[op.lane];
+                if (!lane_started[op.lane]) {
+                    TRTX_HIP_TRY(hipStreamWaitEvent(stream, c->start_event, 0));
+                    lane_started[op.lane] = 1;
+                }
+            }
+            for (int d : op.wait_ops) TRTX_HIP_TRY(hipStreamWaitEvent(stream, c->op_event[d], 0));
+        }
         const PTensor& t0 = plan.tensors[op.in.empty() ? op.out[0] : op.in[0]];
         const PTensor& to = plan.tensors[op.out[0]];
         auto nb = [&](const PTensor& t) { return (t.nfix ? t.nfix : batch) * t.nmul; };
@@ -103,7 +130,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 else if (op.stem)
                     st = conv_stem_nchw_f32(a, stream);
                 else if (op.igemm)
-                    st = conv_igemm2_supported(a) ? conv_igemm2_f16(a, stream) : conv_igemm_f16(a, stream);
+                    st = conv_igemm_f16(a, stream);
                 else
                     st = conv_direct(a, op.dtype, stream);
                 break;
@@ -249,7 +276,14 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
             return st;
         }
         if (prof) TRTX_HIP_TRY(hipEventRecord(evs[k + 1], stream));
+        if (lanes && op.signal) TRTX_HIP_TRY(hipEventRecord(c->op_event[k], stream));
     }
+    if (lanes)
+        for (int l = 1; l < plan.num_lanes; ++l)
+            if (lane_started[l]) {  // join: the caller's stream continues after every lane has drained
+                TRTX_HIP_TRY(hipEventRecord(c->lane_done[l], c->lane_stream[l]));
+                TRTX_HIP_TRY(hipStreamWaitEvent(user_stream, c->lane_done[l], 0));
+            }
     if (prof) {
         TRTX_HIP_TRY(hipStreamSynchronize(stream));
         for (size_t k = 0; k < plan.ops.size(); ++k) {
@@ -389,6 +423,19 @@ extern "C" int32_t trtx_context_create(trtx_engine* e, trtx_context** out) {
     if (e->plan.arena_bytes) {
         TRTX_HIP_TRY(hipMalloc(&c->d_arena, e->plan.arena_bytes));
         TRTX_HIP_TRY(hipMemset(c->d_arena, 0, e->plan.arena_bytes));
+    }
+    const Plan& plan = e->plan;
+    if (plan.num_lanes > 1) {
+        c->lane_stream.assign(plan.num_lanes, nullptr);
+        c->lane_done.assign(plan.num_lanes, nullptr);
+        c->op_event.assign(plan.ops.size(), nullptr);
+        TRTX_HIP_TRY(hipEventCreateWithFlags(&c->start_event, hipEventDisableTiming));
+        for (int l = 1; l < plan.num_lanes; ++l) {
+            TRTX_HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
+            TRTX_HIP_TRY(hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming));
+        }
+        for (size_t k = 0; k < plan.ops.size(); ++k)
+            if (plan.ops[k].signal) TRTX_HIP_TRY(hipEventCreateWithFlags(&c->op_event[k], hipEventDisableTiming));
     }
     *out = c.release();
     return TRTX_OK;

@@ -21,6 +21,11 @@ struct trtx_context {
     trtx_engine* engine = nullptr;
     void* d_arena = nullptr;
     std::vector<void*> addr;  // setTensorAddress slots, one per binding
+    // concurrency (plan.num_lanes > 1): lane 0 is the caller's stream, lanes 1.. are streams owned by the context;
+    // op_event[k] is recorded after op k when another lane waits for it
+    std::vector<hipStream_t> lane_stream;
+    std::vector<hipEvent_t> op_event, lane_done;
+    hipEvent_t start_event = nullptr;
     ~trtx_context();
 };
 

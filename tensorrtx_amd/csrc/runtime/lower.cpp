@@ -1031,13 +1031,19 @@ struct Lowerer {
                 // tiny reductions (K < 32, e.g. the DFL 1x1) stay on the direct kernel
                 ok = ok && a.kh * a.kw * cin_eff >= 32;
                 if (ok) {
-                    op.igemm = true;
-                    a.scalar_out = vec_out ? 0 : 1;
-                    a.Cin = cin_eff;
-                    a.K = a.kh * a.kw * a.Cin;
-                    a.Kpad = (a.K + 31) / 32 * 32;
-                    a.bn = conv_igemm_pick_bn(a.Cout);
-                    a.Cout_pad = (a.Cout + a.bn - 1) / a.bn * a.bn;
+                    ConvArgs t = a;
+                    t.scalar_out = vec_out ? 0 : 1;
+                    t.Cin = cin_eff;
+                    t.bk = conv_igemm_pick_bk(cin_eff);
+                    t.CinK = conv_igemm_pick_cink(cin_eff, t.bk);  // a k-step never straddles a filter tap
+                    t.K = t.kh * t.kw * t.CinK;
+                    t.Kpad = (t.K + t.bk - 1) / t.bk * t.bk;
+                    t.bn = conv_igemm_pick_bn(t.Cout);
+                    t.Cout_pad = (t.Cout + t.bn - 1) / t.bn * t.bn;
+                    if (conv_igemm_supported(t)) {
+                        a = t;
+                        op.igemm = true;
+                    }
                 }
             }
             const double es = dt == DT_F16 ? 2 : 4;
@@ -1058,52 +1064,150 @@ struct Lowerer {
             for (int t : op.in) op.bytes += 4.0 * plan.tensors[t].dims.volume();
             for (int t : op.out) op.bytes += 4.0 * plan.tensors[t].dims.volume();
         }
-        // 5. liveness
-        for (size_t k = 0; k < plan.ops.size(); ++k) {
+        // 5. op dependencies at (storage, channel/element range) granularity: RAW, WAR and WAW
+        const int nops = (int)plan.ops.size();
+        struct Access { int storage; long lo, hi; int op; bool write; };
+        auto access_of = [&](int t, int op, bool write) {
+            const PTensor& pt = plan.tensors[t];
+            Access a{pt.storage, 0, 0, op, write};
+            if (pt.layout == LAY_NHWC) {
+                a.lo = pt.rcoff;
+                a.hi = pt.rcoff + (pt.parent < 0 && pt.Calloc > pt.C ? pt.Calloc : pt.C);  // the layout pass zero-fills its padding
+            } else {
+                a.lo = pt.reoff;
+                a.hi = pt.reoff + pt.dims.volume();
+            }
+            return a;
+        };
+        std::vector<std::vector<int>> deps(nops);
+        {
+            std::vector<Access> log;
+            for (int k = 0; k < nops; ++k) {
+                const POp& op = plan.ops[k];
+                std::vector<Access> mine;
+                for (int t : op.in) mine.push_back(access_of(t, k, false));
+                for (int t : op.out) mine.push_back(access_of(t, k, true));
+                for (const Access& m : mine)
+                    for (const Access& o : log)
+                        if (o.storage == m.storage && o.lo < m.hi && m.lo < o.hi && (o.write || m.write) && o.op != k)
+                            deps[k].push_back(o.op);
+                std::sort(deps[k].begin(), deps[k].end());
+                deps[k].erase(std::unique(deps[k].begin(), deps[k].end()), deps[k].end());
+                log.insert(log.end(), mine.begin(), mine.end());
+            }
+        }
+        // 6. lanes (= HIP streams at run time): an op continues the lane of a dependency that is still that lane's tail,
+        // otherwise it opens a free lane, otherwise it queues behind the lane that went idle first.  Independent branches
+        // (the six cv2/cv3 head chains of YOLOv8, model.cpp:224-291; FPN/SSH branches of RetinaFace) end up on different
+        // lanes and overlap on the GPU; a sequential network stays on lane 0.
+        int max_lanes = 6;
+        if (const char* e = getenv("TRTX_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));
+        std::vector<int> tail(max_lanes, -1);
+        plan.num_lanes = 1;
+        for (int k = 0; k < nops; ++k) {
+            int lane = -1;
+            for (int d : deps[k])
+                if (tail[plan.ops[d].lane] == d && (lane < 0 || d > tail[lane])) lane = plan.ops[d].lane;
+            if (lane < 0 && deps[k].empty()) lane = 0;  // sources (input conversions) stay on the caller's stream
+            if (lane < 0) {
+                for (int l = 0; l < max_lanes && lane < 0; ++l)
+                    if (tail[l] < 0) lane = l;
+            }
+            if (lane < 0) {
+                lane = 0;
+                for (int l = 1; l < max_lanes; ++l)
+                    if (tail[l] < tail[lane]) lane = l;
+            }
+            plan.ops[k].lane = lane;
+            tail[lane] = k;
+            plan.num_lanes = std::max(plan.num_lanes, lane + 1);
+        }
+        // happens-before closure over dependency edges and lane order
+        const int words = (nops + 63) / 64;
+        std::vector<std::vector<uint64_t>> anc(nops, std::vector<uint64_t>(words, 0));
+        {
+            std::vector<int> prev_on_lane(max_lanes, -1);
+            for (int k = 0; k < nops; ++k) {
+                auto absorb = [&](int d) {
+                    for (int w = 0; w < words; ++w) anc[k][w] |= anc[d][w];
+                    anc[k][d >> 6] |= 1ull << (d & 63);
+                };
+                for (int d : deps[k]) absorb(d);
+                const int lane = plan.ops[k].lane;
+                if (prev_on_lane[lane] >= 0) absorb(prev_on_lane[lane]);
+                prev_on_lane[lane] = k;
+            }
+            // cross-lane waits: a dependency on another lane needs an event unless an earlier wait already covers it
+            std::vector<std::vector<int>> covered(max_lanes, std::vector<int>(max_lanes, -1));
+            for (int k = 0; k < nops; ++k) {
+                POp& op = plan.ops[k];
+                for (int d : deps[k]) {
+                    const int ld = plan.ops[d].lane;
+                    if (ld == op.lane || covered[op.lane][ld] >= d) continue;
+                    op.wait_ops.push_back(d);
+                    plan.ops[d].signal = true;
+                    covered[op.lane][ld] = d;
+                }
+            }
+        }
+        auto before = [&](int a, int b) { return a == b || ((anc[b][a >> 6] >> (a & 63)) & 1ull); };
+        // 7. which ops touch which arena storage
+        std::vector<std::vector<int>> touch(plan.storages.size());
+        for (int k = 0; k < nops; ++k) {
             const POp& op = plan.ops[k];
-            auto touch = [&](int t) {
-                Storage& s = plan.storages[plan.tensors[t].storage];
-                s.first_use = std::min(s.first_use, (int)k);
-                s.last_use = std::max(s.last_use, (int)k);
+            auto mark = [&](int t) {
+                const int st = plan.tensors[t].storage;
+                Storage& s = plan.storages[st];
+                s.first_use = std::min(s.first_use, k);
+                s.last_use = std::max(s.last_use, k);
+                if (touch[st].empty() || touch[st].back() != k) touch[st].push_back(k);
             };
-            for (int t : op.in) touch(t);
-            for (int t : op.out) touch(t);
+            for (int t : op.in) mark(t);
+            for (int t : op.out) mark(t);
         }
         // plugin workspaces are short-lived arena blocks
         std::vector<std::pair<int, int>> ws_storage;  // (op, storage)
-        for (size_t k = 0; k < plan.ops.size(); ++k) {
+        for (int k = 0; k < nops; ++k) {
             if ((plan.ops[k].kind != OP_PLUGIN && plan.ops[k].kind != OP_YOLO_HEAD) || plan.ops[k].ws_bytes == 0) continue;
             Storage s;
             s.kind = ST_ARENA;
             s.bytes = plan.ops[k].ws_bytes;
-            s.first_use = s.last_use = (int)k;
-            ws_storage.push_back({(int)k, (int)plan.storages.size()});
+            s.first_use = s.last_use = k;
+            ws_storage.push_back({k, (int)plan.storages.size()});
             plan.storages.push_back(s);
+            touch.push_back({k});
         }
-        // 6. arena offsets: first-fit over storages ordered by first use (closed live intervals)
+        // 8. arena offsets, first fit.  Two blocks may share memory only if every op touching one happens-before every op
+        // touching the other (with one lane this is the classic disjoint-live-interval rule).
+        auto ordered = [&](int sa, int sb) {
+            for (int x : touch[sa])
+                for (int y : touch[sb])
+                    if (!before(x, y) || x == y) return false;
+            return true;
+        };
         std::vector<int> order;
-        for (size_t s = 0; s < plan.storages.size(); ++s)
-            if (plan.storages[s].kind == ST_ARENA && plan.storages[s].last_use >= 0) order.push_back((int)s);
+        for (size_t si = 0; si < plan.storages.size(); ++si)
+            if (plan.storages[si].kind == ST_ARENA && plan.storages[si].last_use >= 0) order.push_back((int)si);
         std::stable_sort(order.begin(), order.end(),
-                         [&](int a, int b) { return plan.storages[a].first_use < plan.storages[b].first_use; });
+                         [&](int x, int y) { return plan.storages[x].first_use < plan.storages[y].first_use; });
         std::vector<int> placed;
         size_t arena = 0;
         for (int si : order) {
-            Storage& s = plan.storages[si];
-            const size_t need = align_up256(s.bytes);
+            Storage& st = plan.storages[si];
+            const size_t need = align_up256(st.bytes);
             std::vector<std::pair<size_t, size_t>> busy;
             for (int pj : placed) {
                 const Storage& o = plan.storages[pj];
-                if (o.last_use < s.first_use || o.first_use > s.last_use) continue;
+                if (ordered(pj, si) || ordered(si, pj)) continue;
                 busy.push_back({o.offset, o.offset + align_up256(o.bytes)});
             }
             std::sort(busy.begin(), busy.end());
             size_t off = 0;
-            for (auto& b : busy) {
-                if (off + need <= b.first) break;
-                off = std::max(off, b.second);
+            for (auto& bz : busy) {
+                if (off + need <= bz.first) break;
+                off = std::max(off, bz.second);
             }
-            s.offset = off;
+            st.offset = off;
             arena = std::max(arena, off + need);
             placed.push_back(si);
         }
@@ -1176,7 +1280,7 @@ bool pack_weights(const Network& net, Plan* plan) {
                         dst[(size_t)t * cout + co] = l.w0[(size_t)co * cin_logical * a.kh * a.kw + t] * sc[co];
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
-                pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.Cin, sc.data(),
+                pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.bk, sc.data(),
                                       reinterpret_cast<uint16_t*>(blob.data() + op.w_off));
             } else {
                 op.w_off = reserve((size_t)cout * a.kh * a.kw * (cin_logical / a.groups) * 4);
@@ -1227,7 +1331,7 @@ std::string Plan::describe_json() const {
         }
     }
     o << "{\"fp16\":" << (fp16 ? "true" : "false") << ",\"max_batch\":" << max_batch << ",\"arena_bytes\":" << arena_bytes
-      << ",\"weight_bytes\":" << weight_bytes << ",\"n_ops\":" << ops.size() << ",\"n_conv\":" << n_conv
+      << ",\"weight_bytes\":" << weight_bytes << ",\"n_lanes\":" << num_lanes << ",\"n_ops\":" << ops.size() << ",\"n_conv\":" << n_conv
       << ",\"n_igemm\":" << n_igemm << ",\"flops_per_sample\":" << flops << ",\"bytes_per_sample\":" << bytes
       << ",\"ops\":[";
     for (size_t k = 0; k < ops.size(); ++k) {
@@ -1244,7 +1348,9 @@ std::string Plan::describe_json() const {
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
               << ",\"ld_out\":" << a.ld_out;
         }
-        o << ",\"in\":[";
+        o << ",\"lane\":" << op.lane << ",\"waits\":[";
+        for (size_t j = 0; j < op.wait_ops.size(); ++j) o << (j ? "," : "") << op.wait_ops[j];
+        o << "],\"in\":[";
         for (size_t j = 0; j < op.in.size(); ++j) o << (j ? "," : "") << op.in[j];
         o << "],\"out\":[";
         for (size_t j = 0; j < op.out.size(); ++j) o << (j ? "," : "") << op.out[j];

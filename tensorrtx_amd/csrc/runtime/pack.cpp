@@ -19,12 +19,11 @@ float f16_bits_to_f32(uint16_t u) {
     return (float)h;
 }
 
-void pack_conv_weights_f16(const float* w, int cout, int cin, int kh, int kw, int cin_pad, const float* ch_scale,
+void pack_conv_weights_f16(const float* w, int cout, int cin, int kh, int kw, int cin_pad, int bk, const float* ch_scale,
                            uint16_t* packed) {
     const int bn = conv_igemm_pick_bn(cout);
     const int cout_pad = (cout + bn - 1) / bn * bn;
-    const int K = kh * kw * cin_pad;
-    const int kpad = (K + 31) / 32 * 32;
+    const int kpad = (kh * kw * cin_pad + bk - 1) / bk * bk;  // cin_pad = per-tap K stride (CinK); rows padded to the k-step
     memset(packed, 0, sizeof(uint16_t) * (size_t)cout_pad * kpad);
     for (int co = 0; co < cout; ++co) {
         const float sc = ch_scale ? ch_scale[co] : 1.0f;
@@ -34,28 +33,6 @@ void pack_conv_weights_f16(const float* w, int cout, int cin, int kh, int kw, in
                     const float v = w[(((size_t)co * cin + c) * kh + r) * kw + q] * sc;
                     packed[(size_t)co * kpad + (size_t)(r * kw + q) * cin_pad + c] = f32_to_f16_bits(v);
                 }
-    }
-}
-
-void pack_conv_weights_patch_f16(const float* w, int cout, int cin, int kh, int kw, int cin_eff, int cc,
-                                 const float* ch_scale, uint16_t* packed) {
-    const int bn = conv_igemm_pick_bn(cout);
-    const int cout_pad = (cout + bn - 1) / bn * bn;
-    const int kpad = conv_patch_kpad(cin_eff, kh, kw, cc);
-    memset(packed, 0, sizeof(uint16_t) * (size_t)cout_pad * kpad);
-    for (int co = 0; co < cout; ++co) {
-        const float sc = ch_scale ? ch_scale[co] : 1.0f;
-        int kbase = 0;
-        for (int c0 = 0; c0 < cin_eff; c0 += cc) {
-            const int creal = cin_eff - c0 < cc ? cin_eff - c0 : cc;
-            const int cpad = (creal + 31) / 32 * 32;
-            for (int r = 0; r < kh; ++r)
-                for (int q = 0; q < kw; ++q)
-                    for (int c = 0; c < creal && c0 + c < cin; ++c)
-                        packed[(size_t)co * kpad + kbase + (r * kw + q) * cpad + c] =
-                                f32_to_f16_bits(w[(((size_t)co * cin + c0 + c) * kh + r) * kw + q] * sc);
-            kbase += kh * kw * cpad;
-        }
     }
 }
 

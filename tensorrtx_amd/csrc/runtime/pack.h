@@ -6,15 +6,10 @@
 namespace trtx {
 
 // TensorRT conv weights are KCRS fp32 ([Cout][Cin][kh][kw]).  The implicit-GEMM kernel wants
-// fp16 [Cout_pad][Kpad] with k = (r*kw + q)*cin_pad + c, zero padded; an optional per-output-channel
+// fp16 [Cout_pad][Kpad = kh*kw*cin_pad rounded up to bk] with k = (r*kw + q)*cin_pad + c (cin_pad = CinK, the per-tap stride), zero padded; an optional per-output-channel
 // scale (folded BatchNorm, yolov8/src/block.cpp:45-77) is multiplied in before rounding to fp16.
-void pack_conv_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
+void pack_conv_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad, int bk,
                            const float* ch_scale, uint16_t* packed);
-
-// conv_patch layout: fp16 [Cout_pad][Kpatch], a row = for each chunk of `cc` input channels, for each tap (r,q),
-// the chunk's channels padded to a multiple of 32 (zeros)
-void pack_conv_weights_patch_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_eff, int cc,
-                                 const float* ch_scale, uint16_t* packed);
 
 // fp32 [Cout][kh][kw][Cin/groups] for the generic direct kernel (KCRS source, Cin here = per group)
 void pack_conv_weights_f32(const float* w_kcrs, int cout, int cin_g, int kh, int kw, const float* ch_scale,

@@ -96,6 +96,11 @@ struct POp {
     bool view_batched_in = false, view_batched_in2 = false, view_batched_out = true;
     std::shared_ptr<PluginHolder> plugin;
     size_t ws_off = 0, ws_bytes = 0;
+    // concurrency: lane = HIP stream the op is issued on; before it, the lane waits for the events of wait_ops;
+    // signal = some op on another lane waits for this one (an event is recorded after it)
+    int lane = 0;
+    std::vector<int> wait_ops;
+    bool signal = false;
     double flops = 0;   // algorithmic FLOP per sample (2*MAC)
     double bytes = 0;   // algorithmic bytes per sample (activations in + out) + weights
 };
@@ -110,6 +115,7 @@ struct Plan {
     std::vector<int> binding_tensor;      // binding index -> network tensor id (inputs first, then outputs)
     std::vector<int> binding_ptensor;     // binding index -> plan tensor id
     std::vector<bool> binding_is_input;
+    int num_lanes = 1;
     size_t arena_bytes = 0;
     size_t weight_bytes = 0;
     std::vector<uint8_t> weight_blob;     // host image of the device weight blob (filled by pack_weights)

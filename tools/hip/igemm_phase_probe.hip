@@ -1,24 +1,17 @@
-// dev probe: shader-clock stamps inside one k-step of conv_igemm_f16_kernel<4> (64 -> 64, 3x3, 80x80, batch 32)
+// dev probe: shader-clock stamps inside the k-steps of conv_igemm_f16_kernel<4, 32> (64 -> 64, 3x3, HxH, batch 32)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
 __device__ long long g_dbg[8][6];
 #define TRTX_STAMP(i, kt) do { if (blockIdx.x == 7 && threadIdx.x == 0 && (kt) < 8) { g_dbg[kt][i] = clock64(); } } while (0)
-#ifdef PROBE_V2
-#include "../../tensorrtx_amd/csrc/kernels/kernels.h"
-namespace trtx { bool conv_igemm_supported(const ConvArgs&) { return true; } int32_t conv_igemm_f16(const ConvArgs&, hipStream_t) { return 0; } }
-#include "../../tensorrtx_amd/csrc/kernels/conv_igemm2.hip"
-#else
 #include "../../tensorrtx_amd/csrc/kernels/conv_igemm.hip"
-namespace trtx { int32_t conv_igemm2_f16(const ConvArgs&, hipStream_t) { return 0; } }
-#endif
 using namespace trtx;
 int main(int argc, char** argv) {
     const int N = 32, H = argc > 1 ? atoi(argv[1]) : 80, Cin = 64, Cout = 64, k = 3;
     ConvArgs a{};
     a.N = N; a.H = a.W = H; a.Cin = Cin; a.ld_in = Cin; a.Ho = a.Wo = H; a.Cout = Cout; a.Cout_pad = 64; a.ld_out = 64;
     a.kh = a.kw = k; a.stride_h = a.stride_w = 1; a.pad_h = a.pad_w = 1; a.dil_h = a.dil_w = 1; a.groups = 1;
-    a.K = k * k * Cin; a.Kpad = a.K; a.M = N * H * H; a.act1 = ACT_SILU; a.bn = 64;
+    a.bk = 32; a.CinK = Cin; a.K = k * k * Cin; a.Kpad = a.K; a.M = N * H * H; a.act1 = ACT_SILU; a.bn = 64;
     void *in, *w, *out; float* bias;
     hipMalloc(&in, (size_t)a.M * Cin * 2); hipMalloc(&w, (size_t)64 * a.Kpad * 2); hipMalloc(&out, (size_t)a.M * 64 * 2); hipMalloc(&bias, 256);
     hipMemset(in, 0x11, (size_t)a.M * Cin * 2); hipMemset(w, 0x11, (size_t)64 * a.Kpad * 2); hipMemset(bias, 0, 256);
@@ -26,7 +19,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        if (argc > 2) conv_igemm2_f16(a, 0); else conv_igemm_f16(a, 0);
+        conv_igemm_f16(a, 0);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long h[8][6];
