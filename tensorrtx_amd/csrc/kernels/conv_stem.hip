@@ -4,13 +4,19 @@
 // (YOLOv8 model.0: 3->16 3x3/2, yolov8/src/model.cpp:115; ResNet-50 conv1: 3->64 7x7/2, resnet50.cpp:165-170.)
 //
 // With K = kh*kw*Cin = 27..147 and Cout <= 64 this layer is far below the MFMA ridge: it is bound by the HBM
-// read of the fp32 image and the fp16 store.  One thread per output pixel keeps COUT fp32 accumulators in
-// registers; lanes walk consecutive output columns so the NCHW loads are coalesced along W and the NHWC
-// store is one contiguous COUT*2-byte run per lane.  Weights ([tap][COUT] fp32) are broadcast from LDS as
-// float4.
+// read of the fp32 image and the fp16 store.  Two kernels:
+//   * conv_stem_lds_kernel (Cout 16/32/64, K <= 160, W % 4 == 0): a workgroup stages the fp32 input patch of a 4x64
+//     output tile in LDS with coalesced 16-byte LDS-DMA loads (borders range-checked to zero), then every lane
+//     gathers the 8 taps of its (pixel, k-chunk) from LDS into the B fragment of v_mfma_f32_16x16x32_f16 (converted to
+//     fp16 in registers); the weights sit in registers as A fragments, a wave stores 32..128 contiguous bytes per pixel.
+//     Gathering the taps straight from global memory (per-lane 4-byte loads, stride-2 columns) was bound by the
+//     L1 request rate: 120-140 us on the 3->16 3x3/2 640x640 batch-32 layer against a 44 us traffic floor.
+//   * conv_stem_kernel (fallback, any Cout in 8..64): one thread per output pixel, fp32 FMAs, weights broadcast
+//     from LDS.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../common.h"
 #include "kernels.h"
@@ -81,6 +87,140 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs p) {
     }
 }
 
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kStemTW = 64, kStemTH = 4;  // output tile of a workgroup: 4 rows x 64 columns = 16 MFMA groups of 16 pixels
+
+struct StemGeom {
+    int PR, PCA;            // input patch rows / 4-float-aligned columns staged in LDS per channel
+    int tiles_x, tiles_y;
+    int chunks;             // 16-byte chunks of the patch (Cin * PR * PCA / 4)
+};
+
+// NFRAG = Cout / 16, KS = 32-wide slices of K (K = kh*kw*Cin <= 32*KS).
+// Stage 1: the fp32 input patch of the tile (Cin x PR x PCA) goes HBM -> LDS with 16-byte LDS-DMA loads, rows and
+//          columns outside the image are range-checked to zero by the buffer descriptor.
+// Stage 2: every lane gathers the 8 taps of its (pixel, k-chunk) from LDS, converts to fp16 and feeds the B operand of
+//          v_mfma_f32_16x16x32_f16; the weights stay in registers as A fragments.
+template <int NFRAG, int KS>
+__global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, const StemGeom g, unsigned in_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float s_patch[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int khw = p.kh * p.kw;
+    const int K = khw * p.Cin;
+    // tile coordinates
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) * kStemTW;
+    t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) * kStemTH;
+    const int n = t / g.tiles_y;
+    const int hi_start = ty0 * p.stride_h - p.pad_h;
+    const int wi_start = tx0 * p.stride_w - p.pad_w;
+    const int al_start = (wi_start >= 0 ? wi_start : wi_start - 3) / 4 * 4;  // floor to a multiple of 4
+    const int shift = wi_start - al_start;
+    // ---- stage 1
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
+        const int cpr = g.PCA / 4;                  // chunks per patch row
+        const float inv_cpr = 1.0f / (float)cpr, inv_pr = 1.0f / (float)g.PR;
+        for (int base = 0; base < g.chunks; base += 256) {
+            const int ci = base + tid;
+            int row = (int)((float)ci * inv_cpr);   // (c * PR + pr); estimate within +-1, fixed up exactly
+            int cq = ci - row * cpr;
+            if (cq < 0) { --row; cq += cpr; }
+            if (cq >= cpr) { ++row; cq -= cpr; }
+            int c = (int)((float)row * inv_pr);
+            int pr = row - c * g.PR;
+            if (pr < 0) { --c; pr += g.PR; }
+            if (pr >= g.PR) { ++c; pr -= g.PR; }
+            const int hi = hi_start + pr, wi = al_start + cq * 4;
+            const bool ok = ci < g.chunks && (unsigned)hi < (unsigned)p.H && wi >= 0 && wi + 3 < p.W;
+            const unsigned off = ok ? (unsigned)(((((long)n * p.Cin + c) * p.H + hi) * p.W + wi) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(s_patch + (size_t)(base + wave * 64) * 4), 16, off, 0, 0, 0);
+        }
+    }
+    // ---- weights and tap tables while the patch is in flight
+    const float* __restrict__ w = static_cast<const float*>(p.wgt);  // [tap = (c*kh + r)*kw + q][Cout]
+    const int kq = (lane >> 4) * 8;
+    half8 wf[NFRAG][KS];
+    int l_off[KS][8];  // float index inside the patch of tap (c, r, q) relative to the pixel's top-left corner
+    const float inv_khw = 1.0f / (float)khw, inv_kw = 1.0f / (float)p.kw;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 32 + kq + e;
+            // k < 160, khw <= 49: (k + 0.5) / d is never within rounding distance of an integer, the floor is exact
+            const int c = (int)(((float)k + 0.5f) * inv_khw), rem = k - c * khw;
+            const int r = (int)(((float)rem + 0.5f) * inv_kw), q = rem - r * p.kw;
+            l_off[ks][e] = k < K ? (c * g.PR + r) * g.PCA + q : 0;  // padded taps: zero weights, any valid address
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) {
+                const int co = j * 16 + (lane & 15);
+                wf[j][ks][e] = (k < K && co < p.Cout) ? (_Float16)w[(size_t)k * p.Cout + co] : (_Float16)0.f;
+            }
+        }
+    const int ch4 = (lane >> 4) * 4;
+    float bias4[NFRAG][4];
+#pragma unroll
+    for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = j * 16 + ch4 + e;
+            bias4[j][e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- stage 2: wave w owns tile row w (64 pixels = 4 groups)
+    _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        const int ty = wave, tx = gi * 16 + (lane & 15);
+        const int ho = ty0 + ty, wo = tx0 + tx;
+        const float* src = s_patch + (ty * p.stride_h) * g.PCA + tx * p.stride_w + shift;
+        floatx4 acc[NFRAG];
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 xf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[e] = (_Float16)src[l_off[ks][e]];
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], xf, acc[j], 0, 0, 0);
+        }
+        if (ho >= p.Ho || wo >= p.Wo) continue;
+        const long m = ((long)n * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) {
+            const int co = j * 16 + ch4;
+            if (co >= p.Cout) continue;
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)stem_act(acc[j][e] + bias4[j][e], p.act1, p.alpha1);
+            *reinterpret_cast<half4_t*>(out + m * p.ld_out + co) = o;
+        }
+    }
+}
+
+template <int NFRAG, int KS>
+void launch_lds(const ConvArgs& a, hipStream_t s) {
+    StemGeom g;
+    g.PR = (kStemTH - 1) * a.stride_h + a.kh;
+    g.PCA = ((kStemTW - 1) * a.stride_w + a.kw + 3 + 3) / 4 * 4;  // + up to 3 floats of alignment slack
+    g.tiles_x = (a.Wo + kStemTW - 1) / kStemTW;
+    g.tiles_y = (a.Ho + kStemTH - 1) / kStemTH;
+    g.chunks = a.Cin * g.PR * g.PCA / 4;
+    const size_t lds = (size_t)((g.chunks + 255) / 256 * 256) * 16;  // whole 1 KiB DMA rows
+    const unsigned in_bytes = (unsigned)((size_t)a.N * a.Cin * a.H * a.W * 4);
+    hipLaunchKernelGGL((conv_stem_lds_kernel<NFRAG, KS>), dim3((unsigned)(a.N * g.tiles_x * g.tiles_y)), dim3(256), lds, s, a, g,
+                       in_bytes);
+}
+
 template <int COUT>
 void launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)a.kh * a.kw * a.Cin * COUT * sizeof(float);
@@ -98,6 +238,22 @@ bool conv_stem_supported(const ConvArgs& a) {
 // in: fp32 NCHW [N][Cin][H][W]; wgt: fp32 [kh*kw*Cin (c,r,q order)][Cout]; out: NHWC fp16 (ld_out % 8 == 0, 16-B aligned)
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s) {
     if (!conv_stem_supported(a) || a.ld_out % 8 || (reinterpret_cast<uintptr_t>(a.out) & 15)) return TRTX_ERR_UNSUPPORTED;
+    const int K = a.kh * a.kw * a.Cin;
+    static const bool no_mfma = getenv("TRTX_STEM_FMA") != nullptr;  // A/B switch for the micro-benchmarks
+    const size_t patch = (size_t)a.Cin * ((kStemTH - 1) * a.stride_h + a.kh) * ((kStemTW - 1) * a.stride_w + a.kw + 9) * 4;
+    if (!no_mfma && a.Cout % 16 == 0 && K <= 160 && a.W % 4 == 0 && patch <= 60 * 1024 &&
+        (size_t)a.N * a.Cin * a.H * a.W * 4 < 2000000000u && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0) {
+        const int ks = K <= 32 ? 1 : 5;
+        bool done = true;
+        if (a.Cout == 16 && ks == 1) launch_lds<1, 1>(a, s);
+        else if (a.Cout == 32 && ks == 1) launch_lds<2, 1>(a, s);
+        else if (a.Cout == 64 && ks == 1) launch_lds<4, 1>(a, s);
+        else if (a.Cout == 16 && ks == 5) launch_lds<1, 5>(a, s);
+        else if (a.Cout == 32 && ks == 5) launch_lds<2, 5>(a, s);
+        else if (a.Cout == 64 && ks == 5) launch_lds<4, 5>(a, s);
+        else done = false;
+        if (done) return check_launch("conv_stem_nchw_f32");
+    }
     switch (a.Cout) {
         case 8: launch<8>(a, s); break;
         case 16: launch<16>(a, s); break;
