@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     constexpr int STAGE_BYTES = A_BYTES + B_ROWS * ROW_B;
     constexpr int LOADS_PER_TILE = A_LOADS + B_PASSES;
     constexpr int KSUB = BKT / 32;                 // MFMA k-slices per k-step
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES];
+    constexpr int NST = BKT == 64 ? 2 : 3;         // pipeline stages (64-wide stages are double-buffered to keep occupancy)
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -242,25 +243,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 #define TRTX_KSTEP(S)                                                         \
     {                                                                         \
         TRTX_STAMP(0, kt);                                                    \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory"); \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory"); \
         TRTX_STAMP(1, kt);                                                    \
         __builtin_amdgcn_s_barrier();                                         \
         TRTX_STAMP(2, kt);                                                    \
-        issue_tile(((S) + 2) % NSTAGE);                                       \
+        issue_tile(((S) + NST - 1) % NST);                                    \
         TRTX_STAMP(3, kt);                                                    \
         if (!(dbg & 4)) compute(S);                                           \
         TRTX_STAMP(4, kt);                                                    \
     }
 
     issue_tile(0);
-    issue_tile(1);
+    if (NST == 3) issue_tile(1);
     for (int kt = 0; !(dbg & 16);) {
         TRTX_KSTEP(0);
         if (++kt == nk) break;
         TRTX_KSTEP(1);
         if (++kt == nk) break;
-        TRTX_KSTEP(2);
-        if (++kt == nk) break;
+        if (NST == 3) {
+            TRTX_KSTEP(2);
+            if (++kt == nk) break;
+        }
     }
 #undef TRTX_KSTEP
     // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     if (dbg & 8) return;
     if (!p.scalar_out) {
         constexpr int RS = BN * 2 + 16;  // padded row stride: 16 consecutive rows start in distinct bank groups
-        static_assert(4 * 32 * RS <= NSTAGE * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
+        static_assert(4 * 32 * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
         __syncthreads();  // every wave is done reading the last stage
         char* mine = smem + wave * 32 * RS;
 #pragma unroll

@@ -226,3 +226,59 @@ def test_rcnn_lowering_at_reference_size():
     e = engine.describe_plan(plan)
     out_dims = {t["name"]: t["dims"] for t in e["tensors"] if t["is_output"]}
     assert out_dims == {"scores": [100, 1], "boxes": [100, 4], "labels": [100, 1]}
+
+
+def _happens_before(ops):
+    """closure over same-lane order and cross-lane waits, as bit masks: hb[k] has bit j set iff op j happens-before op k"""
+    hb = [0] * len(ops)
+    last_on_lane = {}
+    for k, o in enumerate(ops):
+        m = 0
+        for d in o["waits"] + ([last_on_lane[o["lane"]]] if o["lane"] in last_on_lane else []):
+            m |= hb[d] | (1 << d)
+        hb[k] = m
+        last_on_lane[o["lane"]] = k
+    return hb
+
+
+@pytest.mark.parametrize("model,opts", [("yolov8n", dict(batch=4, h=640, w=640, fp16=1)),
+                                        ("retinaface_r50", dict(batch=1, fp16=1, h=320, w=320)),
+                                        ("resnet50", dict(batch=2, fp16=1)),
+                                        ("rcnn_r50c4", dict(batch=1, fp16=1, h=128, w=160, pre_nms_topk=200, post_nms_topk=40,
+                                                            detections=10))])
+def test_lanes_and_arena_plan_are_race_free(model, opts):
+    """Independent check of the concurrency plan the lowering emits (lanes = HIP streams, waits = events): every reader
+    is ordered after every writer of its storage, and two arena blocks share bytes only if all ops touching one
+    happen-before all ops touching the other."""
+    path, _ = synth_wts(model)
+    low = engine.describe_plan(engine.build_plan(model, path, **opts), lowered=True)
+    ops, tensors, storages = low["ops"], low["tensors"], low["storages"]
+    hb = _happens_before(ops)
+    before = lambda a, b: (hb[b] >> a) & 1  # noqa: E731
+    touch = {}
+    writers = {}
+    for k, o in enumerate(ops):
+        for t in o["in"] + o["out"]:
+            touch.setdefault(tensors[t]["storage"], set()).add(k)
+        for t in o["out"]:
+            writers.setdefault(tensors[t]["storage"], set()).add(k)
+    for k, o in enumerate(ops):            # RAW (storage granularity, stricter than the planner's channel ranges)
+        for t in o["in"]:
+            for w in writers.get(tensors[t]["storage"], ()):
+                if w < k and w not in [k]:
+                    assert before(w, k), (model, "op", k, "reads storage written by unordered op", w)
+    used = set(touch)
+    for si, s in enumerate(storages):      # plugin / head workspaces: arena blocks no tensor refers to
+        if s["kind"] == 0 and si not in used and s["last"] >= 0:
+            touch[si] = {s["first"]}
+    arena = [si for si, s in enumerate(storages) if s["kind"] == 0 and si in touch]
+    for i, a in enumerate(arena):
+        for b in arena[i + 1:]:
+            sa, sb = storages[a], storages[b]
+            if sa["offset"] + sa["bytes"] <= sb["offset"] or sb["offset"] + sb["bytes"] <= sa["offset"]:
+                continue
+            ab = all(before(x, y) for x in touch[a] for y in touch[b])
+            ba = all(before(y, x) for x in touch[a] for y in touch[b])
+            assert ab or ba, (model, "arena blocks", a, b, "overlap without ordering")
+    if model in ("yolov8n", "retinaface_r50"):
+        assert low["n_lanes"] > 1  # independent head branches really are spread over streams
