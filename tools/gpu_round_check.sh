@@ -1,7 +1,8 @@
+# full GPU validation of the round: parity suite, headline bench, profiles
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r1c
-timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r1c/pytest.log 2>&1; echo "pytest rc=$?" 
-timeout 300 python bench.py > gpurun_out/r1c/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r1c/bench.log
-timeout 120 python tools/nms_probe.py > gpurun_out/r1c/nms.log 2>&1
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r1c/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r1c/prof.log 2>&1; echo "prof rc=$?"
-cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/r1c/pytest.log
+mkdir -p gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/final/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/final/pytest.log
+timeout 600 python bench.py > gpurun_out/final/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/final/bench.log
+for m in "resnet50 batch=32 fp16=1" "retinaface_r50 batch=1 fp16=1 h=1280 w=1280" "rcnn_r50c4 batch=1 fp16=1" "rcnn_r50c4 batch=4 fp16=1"; do
+  timeout 300 python tools/model_profile.py $m 2>&1 | grep -v amdgpu.ids | head -9
+done > gpurun_out/final/models.log 2>&1; cat gpurun_out/final/models.log

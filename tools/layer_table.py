@@ -1,7 +1,9 @@
 """Per-layer table for the YOLOv8n b32 640 engine: measured time (hipEvent profile) vs algorithmic bytes / FLOP floors.
 usage: python tools/layer_table.py [out.json]"""
 import json, sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np, torch
 from tensorrtx_amd import engine, synth
 from util import synth_wts

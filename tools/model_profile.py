@@ -2,8 +2,11 @@
 import sys
 import time
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+import os  # noqa: E402
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
