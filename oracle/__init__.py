@@ -4,8 +4,11 @@ CPU restatements of the wang-xinyu/tensorrtx algorithms on the hot path (SURVEY.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this package, and only as the checker.  The product (``tensorrtx_amd``) never imports it.
 
-Parity status: **parity unpinned** — the reference ships no golden vectors, unit tests or weights
-for this path; each function cites the reference file:line it restates.
+Parity status: the `.wts` reader and the LeNet restatement are pinned on fixtures generated from the
+reference's own runnable Python (tests/golden/make_golden.py imports lenet/gen_wts.py from /root/reference);
+everything else is **parity unpinned** — the reference ships no golden vectors, unit tests or weights
+for this path and cannot be compiled here (TensorRT / CUDA / OpenCV absent), so
+oracle/_ref does not exist; each function cites the reference file:line it restates.
 """
 import ctypes
 import os
