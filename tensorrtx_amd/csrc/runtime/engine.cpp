@@ -139,6 +139,12 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 st = nhwc_pool(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, op.i[0], nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
                                to.W, to.ld, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], stream);
                 break;
+            case OP_POOL_CHAIN: {
+                const PTensor &y1 = plan.tensors[op.out[0]], &y2 = plan.tensors[op.out[1]], &y3 = plan.tensors[op.out[2]];
+                st = nhwc_maxpool_chain3_f16(R.ptr(op.in[0]), R.ptr(op.out[0]), R.ptr(op.out[1]), R.ptr(op.out[2]), nb(t0), t0.H,
+                                             t0.W, t0.C, t0.ld, y1.ld, y2.ld, y3.ld, op.i[1], stream);
+                break;
+            }
             case OP_RESIZE:
                 st = nhwc_resize_nearest(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
                                          to.W, to.ld, stream);

@@ -14,8 +14,9 @@ namespace trtx {
 const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
-                              "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head"};
-    return (k >= 0 && k <= OP_YOLO_HEAD) ? n[k] : "?";
+                              "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head",
+                              "pool_chain"};
+    return (k >= 0 && k <= OP_POOL_CHAIN) ? n[k] : "?";
 }
 
 namespace {
@@ -1063,6 +1064,28 @@ struct Lowerer {
             op.ws_bytes = op.plugin->v.workspace_size ? op.plugin->v.workspace_size(op.plugin->v.self, plan.max_batch) : 0;
             for (int t : op.in) op.bytes += 4.0 * plan.tensors[t].dims.volume();
             for (int t : op.out) op.bytes += 4.0 * plan.tensors[t].dims.volume();
+        }
+        // SPPF (yolov8/src/block.cpp:214-237): y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1,
+        // 'same' padding.  Three tiny launches (20x20 maps) become one that keeps the map in LDS.
+        for (size_t k = 0; k + 2 < plan.ops.size(); ++k) {
+            auto same_max = [&](const POp& o) {
+                return o.kind == OP_POOL && o.i[0] == POOL_MAX && o.i[1] == o.i[2] && (o.i[1] & 1) && o.i[3] == 1 && o.i[4] == 1 &&
+                       o.i[5] == o.i[1] / 2 && o.i[6] == o.i[1] / 2;
+            };
+            POp &a = plan.ops[k], &b = plan.ops[k + 1], &c3 = plan.ops[k + 2];
+            if (!same_max(a) || !same_max(b) || !same_max(c3) || a.i[1] != b.i[1] || a.i[1] != c3.i[1]) continue;
+            if (b.in[0] != a.out[0] || c3.in[0] != b.out[0] || dt != DT_F16) continue;
+            const PTensor& tx = plan.tensors[a.in[0]];
+            bool ok = tx.C % 8 == 0 && tx.ld % 8 == 0 && tx.rcoff % 8 == 0 && (long)tx.H * tx.W <= 2304 && tx.nmul == 1;
+            for (const POp* o : {&a, &b, &c3}) {
+                const PTensor& ty = plan.tensors[o->out[0]];
+                ok = ok && ty.ld % 8 == 0 && ty.rcoff % 8 == 0 && ty.H == tx.H && ty.W == tx.W && ty.C == tx.C;
+            }
+            if (!ok) continue;
+            a.kind = OP_POOL_CHAIN;
+            a.name += " [x3 chained]";
+            a.out = {a.out[0], b.out[0], c3.out[0]};
+            plan.ops.erase(plan.ops.begin() + k + 1, plan.ops.begin() + k + 3);
         }
         // 5. op dependencies at (storage, channel/element range) granularity: RAW, WAR and WAW
         const int nops = (int)plan.ops.size();

@@ -41,6 +41,7 @@ enum OpKind : int {
     OP_PLUGIN,
     OP_COPY_LIN,      // dense copy (e.g. into an output binding)
     OP_YOLO_HEAD,     // fused DFL + YoloLayer decode on the NHWC head tensors
+    OP_POOL_CHAIN,    // three chained k x k stride-1 'same' max-pools (SPPF) in one launch, three outputs
 };
 const char* op_kind_name(int k);
 

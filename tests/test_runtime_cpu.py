@@ -131,8 +131,8 @@ def test_yolov8n_lowering_at_benchmark_size():
     assert len(convs) == 63 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 62
     assert abs(low["flops_per_sample"] / 1e9 - 8.743) < 0.01
     kinds = [o["kind"] for o in low["ops"]]
-    assert sorted(set(kinds)) == ["conv", "pool", "resize", "yolo_head"]  # everything else fused / aliased away
-    assert len(kinds) == 69
+    assert sorted(set(kinds)) == ["conv", "pool_chain", "resize", "yolo_head"]  # everything else fused / aliased away
+    assert len(kinds) == 67  # 63 conv + 1 fused SPPF pool chain + 2 resize + 1 fused head
     assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
     assert sum(o["residual"] for o in convs) == 6  # bottleneck shortcuts of model.2/4/6/8
     assert low["arena_bytes"] < 450e6
