@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "../common.h"
 #include "kernels.h"
@@ -60,6 +61,14 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
     if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     return act_slow(v, act, alpha);
+}
+
+// bit t set iff 0 <= x0 + t < extent, for t in [0, k), k <= 30
+__device__ __forceinline__ unsigned tap_range_mask(int x0, int k, int extent) {
+    const int lo = x0 < 0 ? -x0 : 0;
+    int hi = extent - x0;
+    hi = hi < k ? hi : k;
+    return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
 }
 
 // physical 16-byte chunk = logical chunk ^ swz(row); see the header comment
@@ -131,13 +140,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         const int hi0 = ho * p.stride_h - p.pad_h;
         const int wi0 = wo * p.stride_w - p.pad_w;
         a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;
-        unsigned rows = 0, cols = 0;
-        for (int r = 0; r < p.kh; ++r)
-            if ((unsigned)(hi0 + r * p.dil_h) < (unsigned)p.H) rows |= 1u << r;
-        for (int q = 0; q < p.kw; ++q)
-            if ((unsigned)(wi0 + q * p.dil_w) < (unsigned)p.W) cols |= 1u << q;
-        a_rows[i] = ok ? rows : 0u;
-        a_cols[i] = cols;
+        // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
+        a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
+        a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
     }
     const int cmax = p.Cin - cchunk * 8;  // this lane's chunk holds real channels while uc < cmax
     unsigned b_off[B_PASSES];
@@ -283,20 +288,35 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         static_assert(4 * 32 * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
         __syncthreads();  // every wave is done reading the last stage
         char* mine = smem + wave * 32 * RS;
+        // act1 is wave-uniform: select the code path once, not per element (the kernel is instruction-issue bound)
+        auto stage1 = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NFRAG; ++j) {
-                const int co = n0 + j * 16 + ch_in;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias && co < p.Cout_pad) bv = *reinterpret_cast<const float4*>(p.bias + co);
-                half4 o;
-                o[0] = (_Float16)act_apply(acc[i][j][0] + bv.x, p.act1, p.alpha1);
-                o[1] = (_Float16)act_apply(acc[i][j][1] + bv.y, p.act1, p.alpha1);
-                o[2] = (_Float16)act_apply(acc[i][j][2] + bv.z, p.act1, p.alpha1);
-                o[3] = (_Float16)act_apply(acc[i][j][3] + bv.w, p.act1, p.alpha1);
-                *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
-            }
+                for (int j = 0; j < NFRAG; ++j) {
+                    const int co = n0 + j * 16 + ch_in;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
+                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[i][j][e] + b4[e];
+                        float y;
+                        if (ACT == ACT_NONE) y = x;
+                        else if (ACT == ACT_SILU) y = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                        else if (ACT == ACT_RELU) y = x > 0.f ? x : 0.f;
+                        else y = act_slow(x, p.act1, p.alpha1);
+                        o[e] = (_Float16)y;
+                    }
+                    *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
+                }
+        };
+        if (p.act1 == ACT_SILU) stage1(std::integral_constant<int, ACT_SILU>{});
+        else if (p.act1 == ACT_RELU) stage1(std::integral_constant<int, ACT_RELU>{});
+        else if (p.act1 == ACT_NONE) stage1(std::integral_constant<int, ACT_NONE>{});
+        else stage1(std::integral_constant<int, -1>{});
         // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
         constexpr int CPR = BN / 8;  // 16-byte chunks per row
 #pragma unroll
@@ -399,13 +419,9 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
         const int hi0 = ho * p.stride_h - p.pad_h;
         const int wi0 = wo * p.stride_w - p.pad_w;
         a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + lchunk * 8) * 2u;
-        unsigned rows = 0, cols = 0;
-        for (int r = 0; r < p.kh; ++r)
-            if ((unsigned)(hi0 + r * p.dil_h) < (unsigned)p.H) rows |= 1u << r;
-        for (int q = 0; q < p.kw; ++q)
-            if ((unsigned)(wi0 + q * p.dil_w) < (unsigned)p.W) cols |= 1u << q;
-        a_rows[i] = ok ? rows : 0u;
-        a_cols[i] = cols;
+        // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
+        a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
+        a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
     }
     const int cmax = p.Cin - lchunk * 8;
 
@@ -618,7 +634,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const int bk = a.CinK % 64 == 0 && a.bk == 64 ? 64 : 32;
     const bool cink_ok = a.CinK % bk == 0 || (a.CinK == 16 && bk == 32);
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
-    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
+    return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
            a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9;
 }
 
