@@ -63,6 +63,23 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
     return act_slow(v, act, alpha);
 }
 
+// activation with the kind fixed at compile time (-1 = anything else, resolved at run time out of line)
+template <int ACT>
+__device__ __forceinline__ float act_fixed(float x, int act, float alpha) {
+    if (ACT == ACT_NONE) return x;
+    if (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
+    return act_slow(x, act, alpha);
+}
+// call f(std::integral_constant<int, ACT>) for the wave-uniform activation code `act`
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+    if (act == ACT_SILU) f(std::integral_constant<int, ACT_SILU>{});
+    else if (act == ACT_RELU) f(std::integral_constant<int, ACT_RELU>{});
+    else if (act == ACT_NONE) f(std::integral_constant<int, ACT_NONE>{});
+    else f(std::integral_constant<int, -1>{});
+}
+
 // bit t set iff 0 <= x0 + t < extent, for t in [0, k), k <= 30
 __device__ __forceinline__ unsigned tap_range_mask(int x0, int k, int extent) {
     const int lo = x0 < 0 ? -x0 : 0;
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
         const int hi0 = ho * p.stride_h - p.pad_h;
         const int wi0 = wo * p.stride_w - p.pad_w;
-        a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;
+        a_base[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;  // element index < 2^30 (slice < 2 GB)
         // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
         a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
         a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
@@ -149,13 +166,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
         const int row = (4 * j + wave) * RPI + lrow;
-        b_off[j] = row < BN ? (unsigned)(((size_t)(n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;
+        b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;  // weights < 2 GB
     }
 
-    // wave-uniform walk over K: tap (r, q), channel offset uc inside the tap, byte offset of the tap.  With TPS == 2 the
-    // walk keeps two taps (index 0: tap 2kt, index 1: tap 2kt+1) and every lane selects its own.
+    // wave-uniform walk over K.  TPS == 1: a single tap counter; validity of (pixel, tap) is one bit of a per-pixel tap mask
+    // (rows x cols expanded once, below) and the tap's byte offset advances by constant deltas.  TPS == 2 keeps (r, q) of
+    // the two taps of a step (index 0: tap 2kt, index 1: tap 2kt+1) and every lane selects its own.
     const int nk = p.Kpad / BKT;
-    int s_kt = 0, s_uc = 0;
+    int s_kt = 0, s_uc = 0, s_tap = 0, s_q0 = 0;
+    unsigned s_off = 0;  // byte offset of the current tap (TPS == 1)
+    const unsigned d_q = (unsigned)(p.dil_w * p.ld_in) * 2u;                                   // next column, same row
+    const unsigned d_r = (unsigned)((p.dil_h * p.W - (p.kw - 1) * p.dil_w) * p.ld_in) * 2u;   // first column of the next row
+    unsigned a_taps[A_LOADS];
+    if (TPS == 1) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            unsigned t = 0;
+            for (int r = 0; r < p.kh; ++r) t |= ((a_rows[i] >> r) & 1u) ? (a_cols[i] << (r * p.kw)) : 0u;  // kh <= 5: kh*kw <= 30
+            a_taps[i] = t;
+        }
+    }
+    const bool full_c = p.Cin == p.CinK;  // no ragged channel chunk to mask
     int s_r[TPS], s_q[TPS];
     unsigned s_toff[TPS];
     auto tap_next = [&](int& r, int& q) {  // select arithmetic, no branches
@@ -176,19 +207,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 
     auto issue_tile = [&](int stage) {
         char* sbase = smem + stage * STAGE_BYTES;
-        const bool live = s_kt < nk;
-        const int r = (TPS == 2 && tsel) ? s_r[TPS - 1] : s_r[0];
-        const int q = (TPS == 2 && tsel) ? s_q[TPS - 1] : s_q[0];
-        const unsigned add = ((TPS == 2 && tsel) ? s_toff[TPS - 1] : s_toff[0]) + (unsigned)s_uc * 2u;
+        const bool live = s_kt < nk && !(dbg & 1);
+        if (TPS == 1) {
+            const unsigned add = s_off + (unsigned)s_uc * 2u;
+            const bool chunk_ok = full_c || s_uc < cmax;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const bool ok = ((a_rows[i] >> r) & (a_cols[i] >> q) & 1u) && s_uc < cmax && live && !(dbg & 1);
-            const unsigned voff = ok ? a_base[i] + add : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+            for (int i = 0; i < A_LOADS; ++i) {
+                const bool ok = ((a_taps[i] >> s_tap) & 1u) && chunk_ok && live;
+                const unsigned voff = ok ? a_base[i] + add : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+            }
+        } else {
+            const int r = tsel ? s_r[TPS - 1] : s_r[0];
+            const int q = tsel ? s_q[TPS - 1] : s_q[0];
+            const unsigned add = (tsel ? s_toff[TPS - 1] : s_toff[0]) + (unsigned)s_uc * 2u;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const bool ok = ((a_rows[i] >> r) & (a_cols[i] >> q) & 1u) && s_uc < cmax && live;
+                const unsigned voff = ok ? a_base[i] + add : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
-            const unsigned voff = (live && !(dbg & 2)) ? b_off[j] : kOOB;
+            const unsigned voff = (s_kt < nk && !(dbg & 2)) ? b_off[j] : kOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (4 * j + wave) * RPI * ROW_B), 16, voff, 0, 0,
                                                      0);
             b_off[j] += BKT * 2;  // kOOB stays out of range for any K < 2^30
@@ -199,18 +241,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             for (int t = 0; t < TPS; ++t) {
                 tap_next(s_r[t], s_q[t]);
                 tap_next(s_r[t], s_q[t]);
+                s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
             }
         } else {
             s_uc += BKT;
             const int wrap = s_uc >= p.CinK;
             s_uc = wrap ? 0 : s_uc;
-            const int q1 = s_q[0] + wrap;
+            s_tap += wrap;
+            const int q1 = s_q0 + wrap;
             const int wq = q1 == p.kw;
-            s_q[0] = wq ? 0 : q1;
-            s_r[0] += wq;
+            s_q0 = wq ? 0 : q1;
+            s_off += wrap ? (wq ? d_r : d_q) : 0u;
         }
-#pragma unroll
-        for (int t = 0; t < TPS; ++t) s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
     };
 
     floatx4 acc[2][NFRAG];
@@ -301,40 +343,33 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
                     const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
                     half4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = acc[i][j][e] + b4[e];
-                        float y;
-                        if (ACT == ACT_NONE) y = x;
-                        else if (ACT == ACT_SILU) y = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-                        else if (ACT == ACT_RELU) y = x > 0.f ? x : 0.f;
-                        else y = act_slow(x, p.act1, p.alpha1);
-                        o[e] = (_Float16)y;
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)act_fixed<ACT>(acc[i][j][e] + b4[e], p.act1, p.alpha1);
                     *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
                 }
         };
-        if (p.act1 == ACT_SILU) stage1(std::integral_constant<int, ACT_SILU>{});
-        else if (p.act1 == ACT_RELU) stage1(std::integral_constant<int, ACT_RELU>{});
-        else if (p.act1 == ACT_NONE) stage1(std::integral_constant<int, ACT_NONE>{});
-        else stage1(std::integral_constant<int, -1>{});
+        dispatch_act(p.act1, stage1);
         // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
         constexpr int CPR = BN / 8;  // 16-byte chunks per row
+        auto stage2 = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int t = 0; t < NFRAG; ++t) {
-            const int q = t * 64 + lane;
-            const int row = q / CPR, cc = q % CPR;
-            const int m = m0 + wave * 32 + row;
-            const int co = n0 + cc * 8;
-            if (m >= p.M || co >= p.Cout) continue;
-            half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
-            if (second) {
-                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+            for (int t = 0; t < NFRAG; ++t) {
+                const int q = t * 64 + lane;
+                const int row = q / CPR, cc = q % CPR;
+                const int m = m0 + wave * 32 + row;
+                const int co = n0 + cc * 8;
+                if (m >= p.M || co >= p.Cout) continue;
+                half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
+                if (second) {
+                    half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (_Float16)act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)act_fixed<ACT>((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+                }
+                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
             }
-            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
-        }
+        };
+        dispatch_act(p.act2, stage2);
         return;
     }
     // ragged channel counts / unaligned slices: element-wise stores straight from the accumulators
@@ -418,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
         if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
         const int hi0 = ho * p.stride_h - p.pad_h;
         const int wi0 = wo * p.stride_w - p.pad_w;
-        a_base[i] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.ld_in + lchunk * 8) * 2u;
+        a_base[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ld_in + lchunk * 8) * 2u;
         // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
         a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
         a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
     unsigned b_off[B_LOADS];
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j)
-        b_off[j] = (unsigned)(((size_t)(n0 + j * 16 + lrow) * p.Kpad + (size_t)k_begin * BKT + lchunk * 8) * 2);
+        b_off[j] = (unsigned)(((n0 + j * 16 + lrow) * p.Kpad + k_begin * BKT + lchunk * 8) * 2);
 
     auto issue_tile = [&](int stage) {
         char* sbase = mine + stage * STAGE_BYTES;
@@ -549,13 +584,24 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
         if (!p.scalar_out) {
             half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
             if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = act_apply(v[e] + (p.bias ? p.bias[co + e] : 0.f), p.act1, p.alpha1);
-                if (second) x = act_apply((float)(_Float16)x + (float)rv[e], p.act2, p.alpha2);
-                o[e] = (_Float16)x;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (p.bias) {
+                b0 = *reinterpret_cast<const float4*>(p.bias + co);
+                b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
             }
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            half8 o;
+            dispatch_act(p.act1, [&](auto t1) {
+                constexpr int A1 = decltype(t1)::value;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)act_fixed<A1>(v[e] + bb[e], p.act1, p.alpha1);
+            });
+            if (second)
+                dispatch_act(p.act2, [&](auto t2) {
+                    constexpr int A2 = decltype(t2)::value;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)act_fixed<A2>((float)o[e] + (float)rv[e], p.act2, p.alpha2);
+                });
             *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = o;
         } else {
 #pragma unroll
@@ -617,11 +663,13 @@ int conv_igemm_pick_bn(int cout) {
     return conv_igemm_pick_bn(pad16);
 }
 
-int conv_igemm_pick_bk(int cin) {
-    // 64-wide steps touch whole 128-B lines but triple-buffer 24..32 KB per stage: occupancy drops to 1-2 workgroups per
-    // CU and the layers of the BASELINE configs measured 15 % slower end to end, so they are opt-in
+int conv_igemm_pick_bk(int cin, int taps) {
+    // 64-wide steps touch whole 128-B lines (the vector L1 serves lines, not halves) and halve the barriers, but their
+    // 24..32 KB stages are double- instead of triple-buffered and occupancy drops.  Measured on YOLOv8n b32: isolated
+    // 3x3 layers over Cin % 64 == 0 gain 5-12 %, 1x1 layers lose 15-20 %, and with 3x3-only selection the whole engine
+    // step is still 4 % slower (1.61 vs 1.54 ms on the same box): opt-in.
     static const bool allow64 = getenv("TRTX_CONV_BK64") != nullptr;
-    return (cin % 64 == 0 && allow64) ? 64 : 32;
+    return (cin % 64 == 0 && taps >= 9 && allow64) ? 64 : 32;
 }
 
 int conv_igemm_pick_cink(int cin, int bk) {

@@ -200,8 +200,22 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
             const int co = j * 16 + ch4;
             if (co >= p.Cout) continue;
             half4_t o;
+            if (p.act1 == ACT_SILU) {  // wave-uniform: pick the activation once, not per element
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)stem_act(acc[j][e] + bias4[j][e], p.act1, p.alpha1);
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[j][e] + bias4[j][e];
+                    o[e] = (_Float16)(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)));
+                }
+            } else if (p.act1 == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[j][e] + bias4[j][e];
+                    o[e] = (_Float16)(x > 0.f ? x : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)stem_act(acc[j][e] + bias4[j][e], p.act1, p.alpha1);
+            }
             *reinterpret_cast<half4_t*>(out + m * p.ld_out + co) = o;
         }
     }

@@ -37,7 +37,7 @@ struct ConvArgs {
 // --- conv -------------------------------------------------------------------------------------------
 // fused implicit-GEMM conv on MFMA (conv_igemm.hip): LDS-DMA operands, range-checked gather, 3-stage pipeline
 int conv_igemm_pick_bn(int cout);   // column-tile width for a Cout
-int conv_igemm_pick_bk(int cin);    // k-step width for a (padded-to-8) Cin
+int conv_igemm_pick_bk(int cin, int taps);  // k-step width for a (padded-to-8) Cin and kh*kw filter taps
 int conv_igemm_pick_cink(int cin, int bk);  // per-tap stride of the packed K axis
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);

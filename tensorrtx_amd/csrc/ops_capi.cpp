@@ -46,7 +46,7 @@ extern "C" int32_t trtx_conv_packed_dims(int cout, int cin_pad, int kh, int kw, 
     if (bn) *bn = b;
     if (cout_pad) *cout_pad = (cout + b - 1) / b * b;
     if (kpad) {
-        const int bk = conv_igemm_pick_bk(cin_pad);
+        const int bk = conv_igemm_pick_bk(cin_pad, kh * kw);
         *kpad = (kh * kw * conv_igemm_pick_cink(cin_pad, bk) + bk - 1) / bk * bk;
     }
     return TRTX_OK;
@@ -55,7 +55,7 @@ extern "C" int32_t trtx_conv_packed_dims(int cout, int cin_pad, int kh, int kw, 
 extern "C" int32_t trtx_conv_pack_weights_f16(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad,
                                               const float* ch_scale, uint16_t* packed) {
     if (!w_kcrs || !packed || cin_pad < cin) return TRTX_ERR_INVALID;
-    const int bk = conv_igemm_pick_bk(cin_pad);
+    const int bk = conv_igemm_pick_bk(cin_pad, kh * kw);
     pack_conv_weights_f16(w_kcrs, cout, cin, kh, kw, conv_igemm_pick_cink(cin_pad, bk), bk, ch_scale, packed);
     return TRTX_OK;
 }
@@ -79,7 +79,7 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.ld_out = ld_out; a.ld_res = ld_res;
     a.kh = kh; a.kw = kw; a.stride_h = sh; a.stride_w = sw; a.pad_h = ph; a.pad_w = pw; a.dil_h = 1; a.dil_w = 1;
     a.groups = 1;
-    a.bk = conv_igemm_pick_bk(Cin);
+    a.bk = conv_igemm_pick_bk(Cin, kh * kw);
     a.CinK = conv_igemm_pick_cink(Cin, a.bk);
     a.K = kh * kw * a.CinK;
     a.Kpad = (a.K + a.bk - 1) / a.bk * a.bk;

@@ -1035,7 +1035,13 @@ struct Lowerer {
                     ConvArgs t = a;
                     t.scalar_out = vec_out ? 0 : 1;
                     t.Cin = cin_eff;
-                    t.bk = conv_igemm_pick_bk(cin_eff);
+                    t.bn = conv_igemm_pick_bn(t.Cout);
+                    t.bk = conv_igemm_pick_bk(cin_eff, t.kh * t.kw);
+                    {   // few tiles + long K at the largest batch: keep 32-wide steps so the wave-split-K variant applies
+                        const long m_max = (long)(ti.nfix ? ti.nfix : plan.max_batch) * ti.nmul * t.Ho * t.Wo;
+                        const long tiles128 = (m_max + 127) / 128 * ((t.Cout + t.bn - 1) / t.bn);
+                        if (tiles128 <= 256 && (t.bn == 64 || t.bn == 80)) t.bk = 32;
+                    }
                     t.CinK = conv_igemm_pick_cink(cin_eff, t.bk);  // a k-step never straddles a filter tap
                     t.K = t.kh * t.kw * t.CinK;
                     t.Kpad = (t.K + t.bk - 1) / t.bk * t.bk;
