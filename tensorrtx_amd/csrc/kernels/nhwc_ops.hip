@@ -183,35 +183,35 @@ __global__ __launch_bounds__(256) void maxpool_chain3_f16_kernel(const _Float16*
                                                                  _Float16* __restrict__ o2, _Float16* __restrict__ o3, int H,
                                                                  int W, int C, int ld_in, int ld1, int ld2, int ld3, int k) {
     typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-    extern __shared__ __attribute__((aligned(16))) half8_t s_map[];  // [2][H*W]
+    extern __shared__ __attribute__((aligned(16))) half8_t s_map[];  // [2][(H + 2r) * (W + 2r)], -inf border: no bound tests
     const int HW = H * W;
     const int chunks = C / 8;
     const int cv = blockIdx.x % chunks;
     const long n = blockIdx.x / chunks;
     const int r = k / 2;
-    for (int p = threadIdx.x; p < HW; p += 256) s_map[p] = *reinterpret_cast<const half8_t*>(in + (n * HW + p) * ld_in + cv * 8);
+    const int PW = W + 2 * r, PHW = (H + 2 * r) * PW;
+    const _Float16 ninf = -__builtin_inff16();
+    const half8_t vinf = half8_t{ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+    for (int p = threadIdx.x; p < 2 * PHW; p += 256) s_map[p] = vinf;
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const int h = p / W, w = p - h * W;
+        s_map[(h + r) * PW + w + r] = *reinterpret_cast<const half8_t*>(in + (n * HW + p) * ld_in + cv * 8);
+    }
     __syncthreads();
     _Float16* outs[3] = {o1, o2, o3};
     const int lds[3] = {ld1, ld2, ld3};
 #pragma unroll
     for (int stage = 0; stage < 3; ++stage) {
-        const half8_t* src = s_map + (stage & 1) * HW;
-        half8_t* dst = s_map + ((stage + 1) & 1) * HW;
+        const half8_t* src = s_map + (stage & 1) * PHW;
+        half8_t* dst = s_map + ((stage + 1) & 1) * PHW;
         for (int p = threadIdx.x; p < HW; p += 256) {
             const int h = p / W, w = p - h * W;
-            half8_t m = src[p];
-            for (int dy = -r; dy <= r; ++dy) {
-                const int hh = h + dy;
-                if ((unsigned)hh >= (unsigned)H) continue;
-                for (int dx = -r; dx <= r; ++dx) {
-                    const int ww = w + dx;
-                    if ((unsigned)ww >= (unsigned)W) continue;
-                    const half8_t v = src[hh * W + ww];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-                }
-            }
-            dst[p] = m;
+            const half8_t* win = src + h * PW + w;  // top-left corner of the k x k window in padded coordinates
+            half8_t m = win[0];
+            for (int dy = 0; dy < k; ++dy)
+                for (int dx = 0; dx < k; ++dx) m = __builtin_elementwise_max(m, win[dy * PW + dx]);  // v_pk_max_f16
+            dst[(h + r) * PW + w + r] = m;
             *reinterpret_cast<half8_t*>(outs[stage] + (n * HW + p) * lds[stage] + cv * 8) = m;
         }
         __syncthreads();
@@ -472,8 +472,8 @@ int32_t nhwc_pool(const void* in, void* out, int dtype, int op, int N, int H, in
 
 int32_t nhwc_maxpool_chain3_f16(const void* in, void* o1, void* o2, void* o3, int N, int H, int W, int C, int ld_in, int ld1,
                                 int ld2, int ld3, int k, hipStream_t s) {
-    const size_t lds = (size_t)2 * H * W * 16;
-    if (C % 8 || lds > 60 * 1024) return TRTX_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * (H + k - 1) * (W + k - 1) * 16;  // two padded planes
+    if (C % 8 || lds > 64 * 1024) return TRTX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(maxpool_chain3_f16_kernel, dim3((unsigned)(N * (C / 8))), dim3(256), lds, s, static_cast<const _Float16*>(in),
                        static_cast<_Float16*>(o1), static_cast<_Float16*>(o2), static_cast<_Float16*>(o3), H, W, C, ld_in, ld1, ld2,
                        ld3, k);

@@ -195,18 +195,55 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
                                                               float* __restrict__ score, int* __restrict__ cls_out,
                                                               float4* __restrict__ boxes,
                                                               int* __restrict__ chunk_cnt, int n_chunks) {
+    __shared__ int s_list[256];
+    __shared__ int s_n, s_keep;
     const int b = blockIdx.y;
     const int g = blockIdx.x * 256 + threadIdx.x;
-    int keep_i = 0;
-    if (g < total_cells) {
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        s_keep = 0;
+    }
+    __syncthreads();
+    auto cell_ptr = [&](int gg) {
         int l = 0;
 #pragma unroll
         for (int i = 1; i < kMaxLevels; ++i)
-            if (i < t.n_levels && g >= t.cell_off[i]) l = i;
+            if (i < t.n_levels && gg >= t.cell_off[i]) l = i;
         const int cells = t.cell_off[l + 1] - t.cell_off[l];
-        const int e = g - t.cell_off[l];
-        const _Float16* cell = t.in[l] + ((size_t)b * cells + e) * t.ld[l];
-        // ---- DFL: 4 sides x softmax(16) . w
+        return t.in[l] + ((size_t)b * cells + (gg - t.cell_off[l])) * t.ld[l];
+    };
+    // ---- phase 1, every cell: the cell can only survive if some sigmoid(logit) >= 0.1, i.e. some logit >= -2.1972.  The
+    // maximum of the raw fp16 logits (exact, packed max, no exp) settles that; possible survivors are compacted into a
+    // list so that the expensive exact pass below runs on dense lanes instead of a few lanes of every wave.
+    bool maybe = false;
+    if (g < total_cells) {
+        const _Float16* cl = cell_ptr(g) + 64;
+        half8_t mx8 = *reinterpret_cast<const half8_t*>(cl);
+        for (int c0 = 8; c0 < classes; c0 += 8) mx8 = __builtin_elementwise_max(mx8, *reinterpret_cast<const half8_t*>(cl + c0));
+        float mlogit = (float)mx8[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mlogit = fmaxf(mlogit, (float)mx8[i]);
+        maybe = mlogit > -2.3f;  // NaN logits fail this test exactly like they fail 'pr > best' in the scan
+        if (!maybe) {
+            const size_t o = (size_t)b * total_cells + g;
+            score[o] = -1.0f;
+            cls_out[o] = 0;
+        }
+    }
+    {
+        const unsigned long long m = __ballot(maybe);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+        base = __shfl(base, 0);
+        if (maybe) s_list[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = threadIdx.x;
+    }
+    __syncthreads();
+    // ---- phase 2, possible survivors only: the reference arithmetic (DFL softmax . w per side, sigmoid of every class, strict
+    // '>' argmax), so kept candidates are bit-identical to evaluating every cell
+    int kept = 0;
+    for (int k = threadIdx.x; k < s_n; k += 256) {
+        const int gg = blockIdx.x * 256 + s_list[k];
+        const _Float16* cell = cell_ptr(gg);
         float w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) w[i] = dfl_w[i];
@@ -233,11 +270,10 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
             }
             side[s] = acc / sum;
         }
-        // ---- class scan (classes % 8 == 0 on this path)
         float best = 0.0f;
         int bcls = 0;
         const _Float16* cl = cell + 64;
-        for (int c0 = 0; c0 < classes; c0 += 8) {
+        for (int c0 = 0; c0 < classes; c0 += 8) {  // classes % 8 == 0 on this path
             const half8_t v = *reinterpret_cast<const half8_t*>(cl + c0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -249,17 +285,16 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
             }
         }
         const bool keep = !((double)best < 0.1);
-        const size_t o = (size_t)b * total_cells + g;
+        const size_t o = (size_t)b * total_cells + gg;
         score[o] = keep ? best : -1.0f;
         cls_out[o] = bcls;
         boxes[o] = make_float4(side[0], side[1], side[2], side[3]);
-        keep_i = keep ? 1 : 0;
+        kept += keep ? 1 : 0;
     }
     // per-kChunk candidate counts (two 256-thread workgroups feed one chunk counter)
-    int wsum = keep_i;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
-    if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&chunk_cnt[b * n_chunks + (blockIdx.x * 256) / kChunk], wsum);
+    if (kept) atomicAdd(&s_keep, kept);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_keep) atomicAdd(&chunk_cnt[b * n_chunks + (blockIdx.x * 256) / kChunk], s_keep);
 }
 
 }  // namespace

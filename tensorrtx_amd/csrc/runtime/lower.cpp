@@ -1082,7 +1082,7 @@ struct Lowerer {
             if (!same_max(a) || !same_max(b) || !same_max(c3) || a.i[1] != b.i[1] || a.i[1] != c3.i[1]) continue;
             if (b.in[0] != a.out[0] || c3.in[0] != b.out[0] || dt != DT_F16) continue;
             const PTensor& tx = plan.tensors[a.in[0]];
-            bool ok = tx.C % 8 == 0 && tx.ld % 8 == 0 && tx.rcoff % 8 == 0 && (long)tx.H * tx.W <= 2304 && tx.nmul == 1;
+            bool ok = tx.C % 8 == 0 && tx.ld % 8 == 0 && tx.rcoff % 8 == 0 && (long)(tx.H + a.i[1] - 1) * (tx.W + a.i[1] - 1) * 32 <= 64 * 1024 && tx.nmul == 1;
             for (const POp* o : {&a, &b, &c3}) {
                 const PTensor& ty = plan.tensors[o->out[0]];
                 ok = ok && ty.ld % 8 == 0 && ty.rcoff % 8 == 0 && ty.H == tx.H && ty.W == tx.W && ty.C == tx.C;
