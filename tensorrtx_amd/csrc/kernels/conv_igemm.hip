@@ -169,16 +169,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;  // weights < 2 GB
     }
 
-    // wave-uniform walk over K.  TPS == 1: a single tap counter; validity of (pixel, tap) is one bit of a per-pixel tap mask
-    // (rows x cols expanded once, below) and the tap's byte offset advances by constant deltas.  TPS == 2 keeps (r, q) of
-    // the two taps of a step (index 0: tap 2kt, index 1: tap 2kt+1) and every lane selects its own.
+    // wave-uniform walk over K.  TPS == 1: the (tap, channel offset, byte offset) of k-step e is precomputed by lane e & 63 into
+    // two VGPRs (a 64-step window, rebuilt every 64 steps) and fetched with v_readlane: the kernel is instruction-issue bound
+    // and this replaces ~25 scalar instructions per step.  Validity of (pixel, tap) is one bit of a per-pixel tap mask (rows x
+    // cols expanded once, below).  TPS == 2 keeps (r, q) of the two taps of a step and every lane selects its own.
     const int nk = p.Kpad / BKT;
-    int s_kt = 0, s_uc = 0, s_tap = 0, s_q0 = 0;
-    unsigned s_off = 0;  // byte offset of the current tap (TPS == 1)
-    const unsigned d_q = (unsigned)(p.dil_w * p.ld_in) * 2u;                                   // next column, same row
-    const unsigned d_r = (unsigned)((p.dil_h * p.W - (p.kw - 1) * p.dil_w) * p.ld_in) * 2u;   // first column of the next row
+    int s_kt = 0, s_uc = 0;
     unsigned a_taps[A_LOADS];
+    unsigned t_add = 0, t_tap = 0;  // lane l: byte offset / (tap | uc << 8) of k-step window_base + l
+    const int spt = p.CinK / BKT;   // k-steps per tap (TPS == 1)
+    const float inv_spt = 1.0f / (float)spt, inv_kw = 1.0f / (float)p.kw;
+    auto build_window = [&](int base) {
+        const int e = base + lane;
+        const int tap = (int)(((float)e + 0.5f) * inv_spt);  // e < 2^20, spt <= 64: the estimate is exact
+        const int ucs = (e - tap * spt) * BKT;
+        const int r = (int)(((float)tap + 0.5f) * inv_kw);
+        const int q = tap - r * p.kw;
+        t_add = (unsigned)((r * p.dil_h * p.W + q * p.dil_w) * p.ld_in + ucs) * 2u;
+        t_tap = (unsigned)(tap < 31 ? tap : 31) | ((unsigned)ucs << 8);  // tap masks have no bit 31: run-out steps are dead
+    };
     if (TPS == 1) {
+        build_window(0);
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             unsigned t = 0;
@@ -209,11 +220,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         char* sbase = smem + stage * STAGE_BYTES;
         const bool live = s_kt < nk && !(dbg & 1);
         if (TPS == 1) {
-            const unsigned add = s_off + (unsigned)s_uc * 2u;
-            const bool chunk_ok = full_c || s_uc < cmax;
+            const unsigned add = (unsigned)__builtin_amdgcn_readlane((int)t_add, s_kt & 63);
+            const unsigned tw = (unsigned)__builtin_amdgcn_readlane((int)t_tap, s_kt & 63);
+            const int tap = (int)(tw & 255u), uc = (int)(tw >> 8);
+            const bool chunk_ok = full_c || uc < cmax;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
-                const bool ok = ((a_taps[i] >> s_tap) & 1u) && chunk_ok && live;
+                const bool ok = ((a_taps[i] >> tap) & 1u) && chunk_ok && live;
                 const unsigned voff = ok ? a_base[i] + add : kOOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             }
@@ -243,15 +256,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
                 tap_next(s_r[t], s_q[t]);
                 s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
             }
-        } else {
-            s_uc += BKT;
-            const int wrap = s_uc >= p.CinK;
-            s_uc = wrap ? 0 : s_uc;
-            s_tap += wrap;
-            const int q1 = s_q0 + wrap;
-            const int wq = q1 == p.kw;
-            s_q0 = wq ? 0 : q1;
-            s_off += wrap ? (wq ? d_r : d_q) : 0u;
+        } else if ((s_kt & 63) == 0) {
+            build_window(s_kt);  // next 64-step window (uniform, once per 64 steps)
         }
     };
 
