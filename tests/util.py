@@ -27,7 +27,7 @@ def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
     }[model]
     tensors, _ = mt.make_weights(fn, x, seed=seed, **kw)
     if not os.path.exists(path):
-        tmp = path + ".tmp"
+        tmp = f"{path}.{os.getpid()}.tmp"  # ranks of a multi-GPU bench may generate the same file concurrently
         wts_writer.write_wts(tmp, {k: v.numpy() for k, v in tensors.items()}, dialect=dialect)
         os.replace(tmp, path)
     return path, tensors
