@@ -17,7 +17,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BATCH = 32
 SIZE = 640
@@ -95,9 +94,15 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from tensorrtx_amd import capi, engine, replicas, synth
-    from util import synth_wts
+    from tensorrtx_amd import wts as wts_writer
 
-    path, _ = synth_wts("yolov8n")
+    # seeded synthetic YOLOv8n weights (no trained weights offline), written once per box in the reference's .wts format
+    path = os.path.join(os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache"), "bench_yolov8n_seed0.wts")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        wts_writer.write_wts(tmp, synth.yolov8n_state(seed=0), dialect="double")
+        os.replace(tmp, path)
     plan = engine.build_plan("yolov8n", path, batch=BATCH, h=SIZE, w=SIZE, fp16=1)
     low = engine.describe_plan(plan, lowered=True)
     eng = engine.Engine(plan)

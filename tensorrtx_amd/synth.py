@@ -105,3 +105,70 @@ def rcnn_box_head_tensors(batch, n=1000, classes=80, img_h=800, img_w=1333, seed
     bw = rng.uniform(8, 300, size=(batch, n)); bh = rng.uniform(8, 300, size=(batch, n))
     props = np.stack([x1, y1, np.minimum(x1 + bw, img_w), np.minimum(y1 + bh, img_h)], -1).astype(np.float32)
     return scores, deltas, props
+
+
+def yolov8n_state(seed=0, num_class=80):
+    """Seeded synthetic weights of YOLOv8n-det under the reference's `.wts` key names (ultralytics state_dict keys, as
+    read by yolov8/src/block.cpp:79-257 / model.cpp:98-310): OrderedDict name -> fp32 array.  Trained weights cannot be
+    obtained offline; the values are He-scaled with near-identity BatchNorm statistics, the class head has gain 80 and
+    bias -7 so that a few hundred cells per image pass the 0.1 confidence gate.  Used by bench.py (product side: no oracle
+    involved).  Draw order and distributions are those of the test-suite's generator, so both produce the same file
+    (tests/test_runtime_cpu.py::test_product_side_yolov8n_weights_match_the_test_generator)."""
+    import math
+    from collections import OrderedDict
+
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    randn = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
+    rand = lambda *shape: torch.rand(*shape, generator=g)    # noqa: E731
+
+    def conv(name, cout, cin, k, gain=2.0):
+        sd[name + ".weight"] = (randn(cout, cin, k, k) * math.sqrt(gain / (cin * k * k))).float()
+
+    def cbs(name, cout, cin, k):  # Conv + BatchNorm (+ SiLU)
+        conv(name + ".conv", cout, cin, k)
+        sd[name + ".bn.weight"] = (1.0 * (0.9 + 0.2 * rand(cout))).float()
+        sd[name + ".bn.bias"] = (0.1 * randn(cout)).float()
+        sd[name + ".bn.running_mean"] = (0.1 * randn(cout)).float()
+        sd[name + ".bn.running_var"] = (0.8 + 0.4 * rand(cout)).float()
+        sd[name + ".bn.num_batches_tracked"] = torch.zeros(1)
+
+    def c2f(name, cin, c2, n):
+        c_ = c2 // 2
+        cbs(name + ".cv1", 2 * c_, cin, 1)
+        for i in range(n):
+            cbs(f"{name}.m.{i}.cv1", c_, c_, 3)
+            cbs(f"{name}.m.{i}.cv2", c_, c_, 3)
+        cbs(name + ".cv2", c2, (2 + n) * c_, 1)
+
+    cbs("model.0", 16, 3, 3)
+    cbs("model.1", 32, 16, 3)
+    c2f("model.2", 32, 32, 1)
+    cbs("model.3", 64, 32, 3)
+    c2f("model.4", 64, 64, 2)
+    cbs("model.5", 128, 64, 3)
+    c2f("model.6", 128, 128, 2)
+    cbs("model.7", 256, 128, 3)
+    c2f("model.8", 256, 256, 1)
+    cbs("model.9.cv1", 128, 256, 1)
+    cbs("model.9.cv2", 256, 512, 1)
+    c2f("model.12", 384, 128, 1)
+    c2f("model.15", 192, 64, 1)
+    cbs("model.16", 64, 64, 3)
+    c2f("model.18", 192, 128, 1)
+    cbs("model.19", 128, 128, 3)
+    c2f("model.21", 384, 256, 1)
+    c3 = max(64, min(num_class, 100))
+    for lv, cin in enumerate((64, 128, 256)):
+        cbs(f"model.22.cv2.{lv}.0", 64, cin, 3)
+        cbs(f"model.22.cv2.{lv}.1", 64, 64, 3)
+        conv(f"model.22.cv2.{lv}.2", 64, 64, 1, gain=4.0)
+        sd[f"model.22.cv2.{lv}.2.bias"] = (1.0 + 0.1 * randn(64)).float()
+        cbs(f"model.22.cv3.{lv}.0", c3, cin, 3)
+        cbs(f"model.22.cv3.{lv}.1", c3, c3, 3)
+        conv(f"model.22.cv3.{lv}.2", num_class, c3, 1, gain=80.0)
+        sd[f"model.22.cv3.{lv}.2.bias"] = (-7.0 + 0.1 * randn(num_class)).float()
+        if lv == 0:
+            sd["model.22.dfl.conv.weight"] = torch.arange(16.0).reshape(1, 16, 1, 1)
+    return OrderedDict((k, v.numpy()) for k, v in sd.items())

@@ -282,3 +282,12 @@ def test_lanes_and_arena_plan_are_race_free(model, opts):
             assert ab or ba, (model, "arena blocks", a, b, "overlap without ordering")
     if model in ("yolov8n", "retinaface_r50"):
         assert low["n_lanes"] > 1  # independent head branches really are spread over streams
+
+
+def test_product_side_yolov8n_weights_match_the_test_generator():
+    """bench.py must not touch the oracle outside its cpu_baseline leg, so it draws its synthetic YOLOv8n weights with
+    tensorrtx_amd.synth.yolov8n_state; that generator and the oracle-driven one used by the tests stay identical."""
+    _, tensors = synth_wts("yolov8n")
+    sd = synth.yolov8n_state(0)
+    assert list(sd) == list(tensors)
+    assert all(np.array_equal(sd[k], tensors[k].numpy()) for k in sd)
