@@ -34,6 +34,14 @@
 #ifndef TRTX_STAMP
 #define TRTX_STAMP(i, kt)
 #endif
+// Ablation switches for the timing experiments of tools/conv_dbg.sh (build with -DTRTX_CONV_ABLATE to get them from the
+// TRTX_CONV_DBG environment variable: 1 A loads range-checked away, 2 B loads, 4 no ds_read/MFMA, 8 no epilogue, 16 no
+// k-loop).  In the product build the flag word is the constant 0 and every test on it folds away.
+#ifdef TRTX_CONV_ABLATE
+#define TRTX_DBG(flags) (flags)
+#else
+#define TRTX_DBG(flags) 0
+#endif
 
 namespace trtx {
 namespace {
@@ -99,7 +107,8 @@ __device__ __forceinline__ int swz(int row) {
 // and the tap a lane fetches depends on which half of the row it fills.
 template <int NFRAG, int BKT, int TPS>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
-                                                             int total_tiles, int xcd_chunk, int dbg) {
+                                                             int total_tiles, int xcd_chunk, int dbg_flags) {
+    const int dbg = TRTX_DBG(dbg_flags);
     constexpr int BN = 16 * NFRAG;
     constexpr int ROW_B = BKT * 2;                 // bytes per LDS row
     constexpr int CH = BKT / 8;                    // 16-byte chunks per row

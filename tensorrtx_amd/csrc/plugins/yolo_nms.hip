@@ -12,7 +12,7 @@
 //                             (class | ~conf | bbox[0] | slot) through a 1024-wide bitonic network
 //                             (strides < 64 by wave shuffles, >= 64 through LDS); sorted records -> workspace.
 //   2. yolo_nms_mask_kernel   one wave per 64x64 tile of the lower-triangular suppression matrix, spread over the
-//                             whole chip (136 tiles x batch): bit k of word c of row i says "sorted box 64c+k
+//                             whole chip (16 row-block workgroups x batch, wave c takes column block c): bit k of word c of row i says "sorted box 64c+k
 //                             suppresses sorted box i".  Tiles whose class ranges cannot meet are skipped.
 //   3. yolo_nms_scan_kernel   one workgroup per image: wave b owns block b of 64 rows (pre-loaded), waves take turns in
 //                             order: cross-block removal is 16 AND/ORs against the published keep words, the in-block
@@ -153,28 +153,28 @@ __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __rest
     }
 }
 
-// grid (col block, row block, image), one wave each
-__global__ __launch_bounds__(64) void yolo_nms_mask_kernel(NmsWs ws, float nms_thresh) {
-    const int c = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
-    if (c > r) return;
-    const int lane = threadIdx.x;
+// grid (row block, image); wave c of the workgroup computes tile (c, r) for c <= r, the other waves leave at once
+__global__ __launch_bounds__(kCap) void yolo_nms_mask_kernel(NmsWs ws, float nms_thresh) {
+    const int r = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int c = threadIdx.x >> 6;
+    if (c > r) return;  // whole waves: no barrier below
     const int n = ws.n[b];
     const size_t base = (size_t)b * kCap;
     const int i = r * 64 + lane;
     uint64_t bits = 0;
     // classes ascend with the sorted rank: a column block entirely below the row block's first class cannot interact
     if (r * 64 < n && !(c < r && ws.cls[base + c * 64 + 63] < ws.cls[base + r * 64])) {
-        __shared__ float4 s_box[64];
-        __shared__ float s_cls[64];
-        s_box[lane] = ws.box[base + c * 64 + lane];
-        s_cls[lane] = ws.cls[base + c * 64 + lane];
-        __syncthreads();
+        __shared__ float4 s_box[kBlocks][64];  // wave-private rows: a wave's own LDS accesses are ordered
+        __shared__ float s_cls[kBlocks][64];
+        s_box[c][lane] = ws.box[base + c * 64 + lane];
+        s_cls[c][lane] = ws.cls[base + c * 64 + lane];
         if (i < n) {
             const float4 mine = ws.box[base + i];
             const float my_cls = ws.cls[base + i];
             const int kend = (c == r) ? lane : 64;  // only earlier boxes suppress
             for (int k = 0; k < kend; ++k)
-                if (s_cls[k] == my_cls && iou_xyxy(s_box[k], mine) > nms_thresh) bits |= 1ull << k;
+                if (s_cls[c][k] == my_cls && iou_xyxy(s_box[c][k], mine) > nms_thresh) bits |= 1ull << k;
         }
     }
     ws.mask[(base + i) * kBlocks + c] = bits;
@@ -276,7 +276,7 @@ extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out
     const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
     hipLaunchKernelGGL(yolo_nms_sort_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, trtx::kYoloDetFloats,
                        max_out, conf_thresh, ws);
-    hipLaunchKernelGGL(yolo_nms_mask_kernel, dim3(kBlocks, kBlocks, batch), dim3(64), 0, stream, ws, nms_thresh);
+    hipLaunchKernelGGL(yolo_nms_mask_kernel, dim3(kBlocks, batch), dim3(kCap), 0, stream, ws, nms_thresh);
     hipLaunchKernelGGL(yolo_nms_scan_kernel, dim3(batch), dim3(kCap), 0, stream, ws, max_out, keep_idx, keep_cnt, keep_det);
     return trtx::check_launch("trtx_yolo_nms");
 }
