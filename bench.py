@@ -26,7 +26,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 
 # HBM traffic of the conv kernels per launch, measured in a separate `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum`
 # pass over this same command (profiles/r01_pmc_conv_traffic.txt): (2 x RDREQ + WRREQ) x 64 B summed over the conv
 # launches of a step / launches (reads doubled per the gfx950 note in MI355X_MICROARCH.md "HBM").  None = not measured.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 39330908  # profiles/r01_pmc_conv_traffic.txt (algorithmic: 34.46 MB -> 1.14x)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 39352748  # profiles/r01_pmc_conv_traffic.txt (algorithmic: 34.46 MB -> 1.14x)
 
 
 def cpu_baseline(path, seconds_budget=20.0):
