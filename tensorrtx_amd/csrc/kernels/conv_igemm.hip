@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     const int tsel = TPS == 2 ? (lchunk >> 1) : 0;         // which of the step's taps this lane fetches
     const int cchunk = TPS == 2 ? (lchunk & 1) : lchunk;   // 8-channel chunk inside the tap
     const int HoWo = p.Ho * p.Wo;
-    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    const float inv_howo = __builtin_amdgcn_rcpf((float)HoWo), inv_wo = __builtin_amdgcn_rcpf((float)p.Wo);  // +-1 estimates, fixed up
     unsigned a_base[A_LOADS];   // byte offset of (n, hi0, wi0, channel lchunk*8); wraps for border pixels (masked)
     unsigned a_rows[A_LOADS];   // bit r: filter row r of this pixel lies inside the image (0 for pixels >= M)
     unsigned a_cols[A_LOADS];   // bit q: filter column q lies inside the image
@@ -187,10 +187,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     unsigned a_taps[A_LOADS];
     unsigned t_add = 0, t_tap = 0;  // lane l: byte offset / (tap | uc << 8) of k-step window_base + l
     const int spt = p.CinK / BKT;   // k-steps per tap (TPS == 1)
-    const float inv_spt = 1.0f / (float)spt, inv_kw = 1.0f / (float)p.kw;
+    const float inv_spt = __builtin_amdgcn_rcpf((float)spt), inv_kw = __builtin_amdgcn_rcpf((float)p.kw);
     auto build_window = [&](int base) {
         const int e = base + lane;
-        const int tap = (int)(((float)e + 0.5f) * inv_spt);  // e < 2^20, spt <= 64: the estimate is exact
+        const int tap = (int)(((float)e + 0.5f) * inv_spt);  // (e + 0.5) / spt is >= 1/128 away from an integer: 1-ulp rcp is exact enough
         const int ucs = (e - tap * spt) * BKT;
         const int r = (int)(((float)tap + 0.5f) * inv_kw);
         const int q = tap - r * p.kw;
@@ -199,11 +199,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     };
     if (TPS == 1) {
         build_window(0);
+        // tap (r, q) is bit r*kw + q: the column mask replicated into every filter row (one multiply by the constant
+        // sum_r 2^(r*kw)), restricted to the contiguous range of valid rows
+        unsigned rep = 0;
+        for (int r = 0; r < p.kh; ++r) rep |= 1u << (r * p.kw);  // wave-uniform (scalar)
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            unsigned t = 0;
-            for (int r = 0; r < p.kh; ++r) t |= ((a_rows[i] >> r) & 1u) ? (a_cols[i] << (r * p.kw)) : 0u;  // kh <= 5: kh*kw <= 30
-            a_taps[i] = t;
+            const unsigned rows = a_rows[i];
+            const int lo = rows ? __builtin_ctz(rows) : 0, hi = rows ? 32 - __builtin_clz(rows) : 0;  // valid rows [lo, hi)
+            const unsigned range = hi > lo ? ((hi * p.kw >= 32 ? ~0u : ((1u << (hi * p.kw)) - 1u)) & ~((1u << (lo * p.kw)) - 1u)) : 0u;
+            a_taps[i] = (a_cols[i] * rep) & range;
         }
     }
     const bool full_c = p.Cin == p.CinK;  // no ragged channel chunk to mask
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
     const int lrow = lane >> 2;
     const int lchunk = (lane & 3) ^ swz<32>(lrow);
     const int HoWo = p.Ho * p.Wo;
-    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    const float inv_howo = __builtin_amdgcn_rcpf((float)HoWo), inv_wo = __builtin_amdgcn_rcpf((float)p.Wo);  // +-1 estimates, fixed up
     unsigned a_base[A_LOADS], a_rows[A_LOADS], a_cols[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
