@@ -8,6 +8,7 @@
 //   RoiAlignPlugin        rcnn/RoiAlignPlugin.h:60-68           trtx_roi_align
 //   PredictorDecodePlugin rcnn/PredictorDecodePlugin.h:76-84    trtx_predictor_decode
 //   BatchedNmsPlugin      rcnn/BatchedNmsPlugin.h:55-62         trtx_batched_nms
+//   MaskRcnnInferencePlugin rcnn/MaskRcnnInferencePlugin.h:50-57  trtx_mask_rcnn_inference
 //
 // These are *user* plugins in the TensorRT sense: they live in the application (here: libtrtx_models.so), reach the
 // engine through the IPluginV2 trampoline of include/NvInfer.h and are re-created at deserialization by the creators
@@ -324,7 +325,44 @@ class BatchedNmsPlugin : public rcnn_detail::Base<BatchedNmsPlugin> {
     int dets_ = 0, count_ = 1;
 };
 
+// inputs : labels {D, 1}, masks {D, C, S, S};  output: {D, 1, S, S} = sigmoid of each detection's own class plane
+// blob   : i32 detections_per_im | i32 output_size | i32 num_classes
+class MaskRcnnInferencePlugin : public rcnn_detail::Base<MaskRcnnInferencePlugin> {
+   public:
+    static constexpr const char* kType = "MaskRcnnInference";
+    MaskRcnnInferencePlugin(int detections_per_im, int output_size) : dets_(detections_per_im), size_(output_size) {}
+    MaskRcnnInferencePlugin(const void* data, size_t length) {
+        rcnn_detail::BlobReader r(data, length);
+        dets_ = r.get<int32_t>();
+        size_ = r.get<int32_t>();
+        classes_ = r.get<int32_t>();
+    }
+    std::vector<char> pack() const {
+        rcnn_detail::BlobWriter w;
+        w.put<int32_t>(dets_);
+        w.put<int32_t>(size_);
+        w.put<int32_t>(classes_);
+        return w.bytes;
+    }
+    const char* getPluginType() const noexcept override { return kType; }
+    int32_t getNbOutputs() const noexcept override { return 1; }
+    Dims getOutputDimensions(int32_t, const Dims*, int32_t) noexcept override { return Dims4(dets_, 1, size_, size_); }
+    void configurePlugin(const Dims* in, int32_t nbInputs, const Dims*, int32_t, const DataType*, const DataType*, const bool*,
+                         const bool*, PluginFormat, int32_t) noexcept override {
+        if (nbInputs == 2 && in[1].nbDims == 4) classes_ = (int)in[1].d[1];
+    }
+    size_t getWorkspaceSize(int32_t) const noexcept override { return 0; }
+    int32_t enqueue(int32_t batch, const void* const* in, void* const* out, void*, hipStream_t stream) noexcept override {
+        return trtx_mask_rcnn_inference(batch, static_cast<const float*>(in[0]), static_cast<const float*>(in[1]), dets_, size_,
+                                        classes_, static_cast<float*>(out[0]), stream);
+    }
+
+   private:
+    int dets_ = 0, size_ = 0, classes_ = 1;
+};
+
 using RpnDecodePluginCreator = rcnn_detail::Creator<RpnDecodePlugin>;
+using MaskRcnnInferencePluginCreator = rcnn_detail::Creator<MaskRcnnInferencePlugin>;
 using RpnNmsPluginCreator = rcnn_detail::Creator<RpnNmsPlugin>;
 using RoiAlignPluginCreator = rcnn_detail::Creator<RoiAlignPlugin>;
 using PredictorDecodePluginCreator = rcnn_detail::Creator<PredictorDecodePlugin>;

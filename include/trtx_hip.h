@@ -145,6 +145,12 @@ int32_t trtx_batched_nms(int nms_method, int batch, const float* scores, const f
                          int count, int detections_per_im, float nms_thresh, float* out_scores, float* out_boxes,
                          float* out_classes, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
 
+/* maskRcnnInference (rcnn/MaskRcnnInference.cu:8-62): sigmoid of the mask plane of each detection's predicted class.
+ * labels [batch][D] (class ids as floats), masks [batch][D][C][S][S] -> out_masks [batch][D][1][S][S]; class ids outside
+ * [0, C) give a zero plane (the reference leaves it unwritten). */
+int32_t trtx_mask_rcnn_inference(int batch, const float* labels, const float* masks, int detections_per_im, int output_size,
+                                 int num_classes, float* out_masks, trtx_stream_t stream);
+
 /* ---- single-kernel entry points (parity tests / micro-benchmarks) ----------------------------- */
 /* activation codes for the fused conv epilogue */
 #define TRTX_ACT_NONE 0

@@ -99,3 +99,18 @@ def batched_nms(method, scores, boxes, classes, dets, thresh):
     lib().batched_nms_ref(method, B, _fp(s), _fp(b), _fp(c), count, dets, ctypes.c_float(thresh), _fp(os_), _fp(ob),
                           _fp(oc))
     return os_, ob, oc
+
+
+def mask_select(labels, masks):
+    """rcnn/MaskRcnnInference.cu:8-30: out[b, d, 0] = sigmoid(masks[b, d, class(d)]); class ids outside [0, C) give zeros
+    (the reference leaves those planes unwritten).  NumPy (the arithmetic is one sigmoid)."""
+    lab = np.asarray(labels, np.float32)
+    m = np.asarray(masks, np.float32)
+    B, D, C = m.shape[:3]
+    out = np.zeros((B, D, 1) + m.shape[3:], np.float32)
+    for b in range(B):
+        for d in range(D):
+            c = int(lab[b, d])
+            if 0 <= c < C:
+                out[b, d, 0] = (np.float32(1.0) / (np.float32(1.0) + np.exp(-m[b, d, c], dtype=np.float32))).astype(np.float32)
+    return out

@@ -208,4 +208,8 @@ def _plugin(l, ins, batch):
         dets, count = i32(8, 2)
         s, b, cl = det_post.batched_nms(method, arr[0].reshape(batch, count), arr[1], arr[2].reshape(batch, count), dets, thresh)
         return [torch.from_numpy(s).reshape(batch, dets, 1), torch.from_numpy(b), torch.from_numpy(cl).reshape(batch, dets, 1)]
+    if l["plugin_type"] == "MaskRcnnInference":
+        dets, size, classes = i32(0, 3)
+        out = det_post.mask_select(arr[0].reshape(batch, dets), arr[1].reshape(batch, dets, classes, size, size))
+        return [torch.from_numpy(out)]
     raise NotImplementedError(l["plugin_type"])

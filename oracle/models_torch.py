@@ -373,4 +373,19 @@ def rcnn_r50c4(p: Params, x_hwc, stage="all", given=None, **cfg):
     out["pred_scores"], out["pred_boxes"], out["pred_classes"] = ps, pb, pc
     dets = min(c["detections_per_image"], P)
     out["scores"], out["boxes"], out["labels"] = det_post.batched_nms(c["nms_method"], ps, pb, pc, dets, c["nms_thresh_test"])
+    if c.get("mask_on") or stage == "init":
+        # MaskHead, rcnn.cpp:202-232: RoIAlign of the final boxes -> res5 (same weights) -> ConvTranspose 2x2/2 + ReLU ->
+        # 1x1 predictor -> the plane of each detection's own class through a sigmoid (MaskRcnnInference.cu:8-30)
+        boxes = np.asarray(given.get("boxes", out["boxes"]), np.float32)
+        labels = np.asarray(given.get("labels", out["labels"]), np.float32)
+        D = boxes.shape[1]
+        mroi = det_post.roi_align(boxes, feats.numpy(), c["pooler_resolution"], 1.0 / c["stride"], c["sampling_ratio"])
+        m = torch.from_numpy(mroi).reshape(B * D, feats.shape[1], c["pooler_resolution"], c["pooler_resolution"])
+        m = stage_(m, 3, feats.shape[1], 512, 2048, 2, "roi_heads.res5")
+        wd = p._get("roi_heads.mask_head.deconv.weight", (2048, 256, 2, 2), lambda: p.randn(2048, 256, 2, 2) * math.sqrt(2.0 / 2048))
+        bd = p.vec("roi_heads.mask_head.deconv.bias", 256, lambda: 0.05 * p.randn(256))
+        m = F.relu(F.conv_transpose2d(m, wd, bd, stride=2))
+        logits = conv(m, "roi_heads.mask_head.predictor", nc, 1, 1, 0, False, gain=4.0)
+        out["mask_logits"] = logits.reshape(B, D, nc, *logits.shape[-2:])
+        out["masks"] = det_post.mask_select(labels, out["mask_logits"].numpy())
     return out

@@ -60,6 +60,9 @@ int32_t nhwc_to_nchw_f32(const void* in, int dtype, float* out, int N, int C, in
 // SPPF: three chained k x k stride-1 'same' max-pools (fp16, C % 8 == 0, H*W*32 B <= 60 KB of LDS)
 int32_t nhwc_maxpool_chain3_f16(const void* in, void* o1, void* o2, void* o3, int N, int H, int W, int C, int ld_in, int ld1,
                                 int ld2, int ld3, int k, hipStream_t s);
+// [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c], fp16, C % 8 == 0
+int32_t nhwc_depth_to_space_f16(const void* in, void* out, int N, int H, int W, int C, int bh, int bw, int ld_in, int ld_out,
+                                hipStream_t s);
 int32_t nhwc_pool(const void* in, void* out, int dtype, int op, int N, int H, int W, int C, int ld_in, int Ho, int Wo,
                   int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int avg_exclusive, hipStream_t s);
 int32_t nhwc_resize_nearest(const void* in, void* out, int dtype, int N, int H, int W, int C, int ld_in, int Ho,

@@ -480,6 +480,34 @@ int32_t nhwc_maxpool_chain3_f16(const void* in, void* o1, void* o2, void* o3, in
     return check_launch("nhwc_maxpool_chain3_f16");
 }
 
+// depth to space (fp16, 8-channel chunks): out[n][h*bh + r][w*bw + q][c] = in[n][h][w][(r*bw + q)*C + c]
+__global__ void depth_to_space_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, long total, int H, int W,
+                                          int C, int bh, int bw, int ld_in, int ld_out) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cv = C / 8;
+    const int c8 = (int)(i % cv);
+    long px = i / cv;  // output pixel (n, ho, wo)
+    const int Wo = W * bw, Ho = H * bh;
+    const int wo = (int)(px % Wo);
+    px /= Wo;
+    const int ho = (int)(px % Ho);
+    const long n = px / Ho;
+    const int h = ho / bh, r = ho - h * bh, w = wo / bw, q = wo - w * bw;
+    const half8_t v = *reinterpret_cast<const half8_t*>(in + ((n * H + h) * W + w) * ld_in + (r * bw + q) * C + c8 * 8);
+    *reinterpret_cast<half8_t*>(out + ((n * Ho + ho) * Wo + wo) * ld_out + c8 * 8) = v;
+}
+
+int32_t nhwc_depth_to_space_f16(const void* in, void* out, int N, int H, int W, int C, int bh, int bw, int ld_in, int ld_out,
+                                hipStream_t s) {
+    if (C % 8 || ld_in % 8 || ld_out % 8) return TRTX_ERR_UNSUPPORTED;
+    const long total = (long)N * H * bh * W * bw * (C / 8);
+    hipLaunchKernelGGL(depth_to_space_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const _Float16*>(in), static_cast<_Float16*>(out), total, H, W, C, bh, bw, ld_in, ld_out);
+    return check_launch("nhwc_depth_to_space_f16");
+}
+
 int32_t nhwc_resize_nearest(const void* in, void* out, int dtype, int N, int H, int W, int C, int ld_in, int Ho,
                             int Wo, int ld_out, hipStream_t s) {
     const bool vec = can_vec(dtype, C, {ld_in, ld_out}, {in, out});

@@ -1025,3 +1025,29 @@ extern "C" int32_t trtx_predictor_decode(int batch, const float* scores, const f
                        num_boxes, num_classes, (float)image_width, w[0], w[1], w[2], w[3], out_scores, out_boxes, out_classes);
     return trtx::check_launch("trtx_predictor_decode");
 }
+
+// ---- maskRcnnInference (MaskRcnnInference.cu:8-62): per detection, the mask plane of its predicted class through a sigmoid.
+// labels [batch][D] (class ids as floats), masks [batch][D][C][S][S] -> out [batch][D][1][S][S].  The reference leaves the
+// output untouched when the class id is outside [0, C); here such planes are written as zeros.
+__global__ void mask_select_kernel(const float* __restrict__ labels, const float* __restrict__ masks, int detections,
+                                   int plane, int num_classes, long total, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long det = i / plane;  // detection index across the batch
+    const int px = (int)(i - det * plane);
+    const int cls = (int)labels[det];
+    float v = 0.0f;
+    if (cls >= 0 && cls < num_classes) v = 1.0f / (1.0f + expf(-masks[(det * num_classes + cls) * plane + px]));
+    out[i] = v;
+}
+
+extern "C" int32_t trtx_mask_rcnn_inference(int batch, const float* labels, const float* masks, int detections_per_im,
+                                            int output_size, int num_classes, float* out_masks, hipStream_t stream) {
+    if (!labels || !masks || !out_masks || batch < 1 || detections_per_im < 1 || output_size < 1 || num_classes < 1)
+        return TRTX_ERR_INVALID;
+    const int plane = output_size * output_size;
+    const long total = (long)batch * detections_per_im * plane;
+    hipLaunchKernelGGL(mask_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, labels, masks,
+                       detections_per_im, plane, num_classes, total, out_masks);
+    return trtx::check_launch("trtx_mask_rcnn_inference");
+}

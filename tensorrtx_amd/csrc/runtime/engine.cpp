@@ -145,6 +145,10 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                                              t0.W, t0.C, t0.ld, y1.ld, y2.ld, y3.ld, op.i[1], stream);
                 break;
             }
+            case OP_D2S:
+                st = nhwc_depth_to_space_f16(R.ptr(op.in[0]), R.ptr(op.out[0]), nb(t0), t0.H, t0.W, to.C, op.i[0], op.i[1], t0.ld,
+                                             to.ld, stream);
+                break;
             case OP_RESIZE:
                 st = nhwc_resize_nearest(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
                                          to.W, to.ld, stream);

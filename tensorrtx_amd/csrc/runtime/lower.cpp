@@ -15,8 +15,8 @@ const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
                               "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head",
-                              "pool_chain"};
-    return (k >= 0 && k <= OP_POOL_CHAIN) ? n[k] : "?";
+                              "pool_chain", "depth_to_space"};
+    return (k >= 0 && k <= OP_D2S) ? n[k] : "?";
 }
 
 namespace {
@@ -525,6 +525,32 @@ struct Lowerer {
             case L_DECONV: {
                 const int in = need_nhwc(l.inputs[0]);
                 const PTensor ti = plan.tensors[in];
+                // kernel == stride, no padding, one group (Mask R-CNN's 2x2/2 ConvTranspose over 2048 channels,
+                // rcnn.cpp:209-212): every output sub-position (r, q) is its own 1x1 convolution, so the layer is one MFMA
+                // implicit GEMM with Cout' = kh*kw*Cout followed by a depth-to-space shuffle (41.7 ms -> ~0.15 ms there)
+                if (dt == DT_F16 && l.groups == 1 && l.kernel[0] == l.stride[0] && l.kernel[1] == l.stride[1] && l.padding[0] == 0 &&
+                    l.padding[1] == 0 && l.dilation[0] == 1 && l.dilation[1] == 1 && ti.C % 8 == 0 && l.nb_out % 8 == 0 &&
+                    l.kernel[0] * l.kernel[1] > 1) {
+                    Dims dmid = net.tensors[l.inputs[0]].dims;
+                    dmid.d[dmid.nb - 3] = (int64_t)l.nb_out * l.kernel[0] * l.kernel[1];
+                    const int mid = new_tensor(-1, dmid, LAY_NHWC, true);
+                    const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                    {
+                        POp& op = add_op(OP_CONV, l.name + " [as 1x1]", {in}, {mid});
+                        op.src_layer = li;
+                        op.from_deconv = true;
+                        ConvArgs& a = op.conv;
+                        const PTensor& tm = plan.tensors[mid];
+                        a.H = ti.H; a.W = ti.W; a.Cin = ti.C; a.Ho = ti.H; a.Wo = ti.W; a.Cout = tm.C;
+                        a.kh = a.kw = 1; a.stride_h = a.stride_w = 1; a.pad_h = a.pad_w = 0; a.dil_h = a.dil_w = 1; a.groups = 1;
+                        op.flops = 2.0 * tm.nmul * a.Ho * a.Wo * a.Cout * (double)a.Cin;
+                    }
+                    POp& d2s = add_op(OP_D2S, l.name + " [depth to space]", {mid}, {out});
+                    d2s.i[0] = l.kernel[0];
+                    d2s.i[1] = l.kernel[1];
+                    pt_of[l.outputs[0]] = out;
+                    return true;
+                }
                 const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
                 POp& op = add_op(OP_DECONV, l.name, {in}, {out});
                 op.src_layer = li;
@@ -1307,6 +1333,17 @@ bool pack_weights(const Network& net, Plan* plan) {
                 for (int co = 0; co < cout; ++co)
                     for (int t = 0; t < cin_logical * a.kh * a.kw; ++t)
                         dst[(size_t)t * cout + co] = l.w0[(size_t)co * cin_logical * a.kh * a.kw + t] * sc[co];
+            } else if (op.igemm && op.from_deconv) {
+                // CKRS [Cin][Cout][kh][kw] -> KCRS of the stand-in 1x1 conv: output channel (r*kw + q)*Cout + co
+                const int taps = l.kernel[0] * l.kernel[1], dc = l.nb_out;
+                std::vector<float> w2((size_t)cout * cin_logical);
+                for (int ci = 0; ci < cin_logical; ++ci)
+                    for (int co = 0; co < dc; ++co)
+                        for (int t = 0; t < taps; ++t) w2[(size_t)(t * dc + co) * cin_logical + ci] = l.w0[((size_t)ci * dc + co) * taps + t];
+                for (int c = 0; c < cout; ++c) bias[c] = l.w1.empty() ? 0.f : l.w1[c % dc];
+                op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
+                pack_conv_weights_f16(w2.data(), cout, cin_logical, 1, 1, a.CinK, a.bk, sc.data(),
+                                      reinterpret_cast<uint16_t*>(blob.data() + op.w_off));
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
                 pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.bk, sc.data(),

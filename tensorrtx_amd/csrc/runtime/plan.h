@@ -42,6 +42,7 @@ enum OpKind : int {
     OP_COPY_LIN,      // dense copy (e.g. into an output binding)
     OP_YOLO_HEAD,     // fused DFL + YoloLayer decode on the NHWC head tensors
     OP_POOL_CHAIN,    // three chained k x k stride-1 'same' max-pools (SPPF) in one launch, three outputs
+    OP_D2S,           // depth-to-space: [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c] (second half of a kernel == stride deconvolution)
 };
 const char* op_kind_name(int k);
 
@@ -86,6 +87,7 @@ struct POp {
     ConvArgs conv{};
     bool igemm = false;
     bool stem = false;         // conv_stem kernel: reads the LINEAR fp32 input directly
+    bool from_deconv = false;  // 1x1 conv standing in for a kernel == stride deconvolution (weights re-laid from CKRS)
     int src_layer = -1;        // network layer holding the kernel weights
     int scale_layer = -1;      // folded IScaleLayer (BatchNorm) or -1
     size_t w_off = 0, b_off = 0, s_off = 0;  // byte offsets into the device weight blob

@@ -109,3 +109,14 @@ def batched_nms(method, scores, boxes, classes, dets, thresh):
     check(L.trtx_batched_nms(method, B, _p(scores), _p(boxes), _p(classes), count, dets, ctypes.c_float(thresh), _p(os_), _p(ob),
                              _p(oc), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), "trtx_batched_nms")
     return os_, ob, oc
+
+
+def mask_rcnn_inference(labels, masks):
+    """maskRcnnInference (rcnn/MaskRcnnInference.cu:8-62). labels [B, D] class ids as floats, masks [B, D, C, S, S]
+    -> [B, D, 1, S, S]."""
+    import torch
+    B, D, C, S, _ = masks.shape
+    out = torch.empty((B, D, 1, S, S), dtype=torch.float32, device=masks.device)
+    check(_L().trtx_mask_rcnn_inference(B, _p(labels.contiguous()), _p(masks.contiguous()), D, S, C, _p(out), _stream()),
+          "trtx_mask_rcnn_inference")
+    return out

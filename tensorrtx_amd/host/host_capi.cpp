@@ -64,6 +64,7 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
         cfg.detections_per_image = geti(o, "detections", cfg.detections_per_image);
         cfg.nms_method = geti(o, "nms_method", cfg.nms_method);
         cfg.mark_stages = geti(o, "mark_stages", 0) != 0;
+        cfg.mask_on = geti(o, "mask", 0) != 0;
         plan.reset(trtx_host::buildRcnnR50C4(builder.get(), config.get(), wts_path, cfg));
     } else {
         return TRTX_ERR_INVALID;

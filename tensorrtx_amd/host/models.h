@@ -56,9 +56,10 @@ struct RcnnConfig {
     int detections_per_image = 100;
     float bbox_reg_weights[4] = {10.0f, 10.0f, 5.0f, 5.0f};
     int nms_method = 1;                     // 0 hard, 1 soft-NMS linear (reference default), 2 soft-NMS gaussian
+    bool mask_on = false;                   // MASK_ON: Mask R-CNN head (rcnn.cpp:202-232), extra output "masks"
     bool mark_stages = false;               // debugging: also expose "features" and "proposals"
 };
-// rcnn/rcnn.cpp:79-278 (box head; MASK_ON = false)
+// rcnn/rcnn.cpp:79-278 (box head, and the mask head when mask_on)
 nvinfer1::IHostMemory* buildRcnnR50C4(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config, const std::string& wts,
                                       const RcnnConfig& cfg);
 

@@ -3,7 +3,7 @@
 // res2..res4 (detectron2 weights after fuse-bn, so every conv carries a bias; stride lives in the first 1x1,
 // STRIDE_IN_1X1) -> RPN head (3x3 + objectness/anchor-delta 1x1) -> RpnDecode -> RpnNms -> RoiAlign(14) -> res5 run on
 // the (proposals, C, 14, 14) tensor -> HW mean -> two FullyConnected -> softmax / slice -> PredictorDecode -> BatchedNms.
-// The Mask head (MASK_ON, rcnn.cpp:202-232) is off by default in the reference and not built here.
+// The Mask head (MASK_ON, rcnn.cpp:202-232; off by default in the reference) is built when RcnnConfig::mask_on is set.
 // The reference's file-scope constants (rcnn.cpp:16-60) are the fields of RcnnConfig.
 #include "common.h"
 #include "models.h"
@@ -17,6 +17,7 @@ REGISTER_TENSORRT_PLUGIN(RpnNmsPluginCreator);
 REGISTER_TENSORRT_PLUGIN(RoiAlignPluginCreator);
 REGISTER_TENSORRT_PLUGIN(PredictorDecodePluginCreator);
 REGISTER_TENSORRT_PLUGIN(BatchedNmsPluginCreator);
+REGISTER_TENSORRT_PLUGIN(MaskRcnnInferencePluginCreator);
 }  // namespace nvinfer1
 
 namespace trtx_host {
@@ -149,6 +150,33 @@ IHostMemory* buildRcnnR50C4(IBuilder* builder, IBuilderConfig* config, const std
     for (int i = 0; i < 3; ++i) {
         dets->getOutput(i)->setName(names[i]);
         network->markOutput(*dets->getOutput(i));
+    }
+    if (cfg.mask_on) {  // MaskHead, rcnn.cpp:202-232: the final boxes go through RoIAlign + res5 (shared weights) once more
+        RoiAlignPlugin maskRoiAlign(cfg.pooler_resolution, 1.0f / (float)cfg.stride, cfg.sampling_ratio, cfg.detections_per_image,
+                                    featCh);
+        ITensor* maskRoiIn[] = {dets->getOutput(1), features};
+        auto* maskRois = network->addPluginV2(maskRoiIn, 2, maskRoiAlign);
+        assert(maskRois);
+        ITensor* maskFeatures =
+                makeStage(c, *maskRois->getOutput(0), 3, featCh, 512, cfg.res2_out_channels * 8, 2, "roi_heads.res5");
+        auto* deconv = network->addDeconvolutionNd(*maskFeatures, 256, DimsHW{2, 2}, need(wm, "roi_heads.mask_head.deconv.weight"),
+                                                   need(wm, "roi_heads.mask_head.deconv.bias"));
+        assert(deconv);
+        deconv->setStrideNd(DimsHW{2, 2});
+        auto* deconvRelu = network->addActivation(*deconv->getOutput(0), ActivationType::kRELU);
+        ITensor* maskLogits = conv(c, *deconvRelu->getOutput(0), cfg.num_classes, 1, 1, 0, "roi_heads.mask_head.predictor", false);
+        ITensor* masks;
+        if (cfg.num_classes == 1) {
+            masks = network->addActivation(*maskLogits, ActivationType::kSIGMOID)->getOutput(0);
+        } else {
+            MaskRcnnInferencePlugin maskSelect(cfg.detections_per_image, cfg.pooler_resolution);
+            ITensor* selIn[] = {dets->getOutput(2), maskLogits};
+            auto* sel = network->addPluginV2(selIn, 2, maskSelect);
+            assert(sel);
+            masks = sel->getOutput(0);
+        }
+        masks->setName("masks");
+        network->markOutput(*masks);
     }
     if (cfg.mark_stages) {  // debugging taps for the parity tests
         features->setName("features");

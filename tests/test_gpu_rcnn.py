@@ -103,3 +103,59 @@ def test_rcnn_fp16_engine_stagewise(gpu, hw, batch, cfg):
     assert np.isfinite(scores).all() and scores[:, 0].min() > 0.05
     assert pm >= 0.85
     assert dm >= 0.8 and top < 0.05
+
+
+def test_mask_rcnn_fp32_engine(gpu):
+    """Mask R-CNN head on the GPU (fp32, small config): masks of the engine's own detections vs the oracle restarted from
+    the engine's features / boxes / labels; and the plugin alone against its NumPy restatement."""
+    from oracle import det_post as dp
+    from tensorrtx_amd import det_ops
+    cfg = dict(pre_nms_topk=300, post_nms_topk=50, detections=20)
+    path, _ = synth_wts("rcnn_r50c4")
+    B, H, W = 2, 128, 160
+    plan = engine.build_plan("rcnn_r50c4", path, batch=B, fp16=0, h=H, w=W, mark_stages=1, mask=1, **cfg)
+    x = _images(B, H, W, 7)
+    out = _run(plan, {"images": x.numpy()}, B, gpu)
+    fdim = lambda n: functools.reduce(lambda v, _: (v - 1) // 2 + 1, range(4), n)  # noqa: E731
+    feats = out["features"].reshape(B, 1024, fdim(H), fdim(W))
+    boxes = out["boxes"].reshape(B, 20, 4).numpy()
+    labels = out["labels"].reshape(B, 20).numpy()
+    with torch.inference_mode():
+        ref = mt.rcnn_r50c4(mt.Params(owts.load_wts(path)), x, pre_nms_topk=300, post_nms_topk=50, detections_per_image=20,
+                            mask_on=True, given={"features": feats, "proposals": out["proposals"].reshape(B, 50, 4).numpy(),
+                                                 "boxes": boxes, "labels": labels})
+    masks = out["masks"].reshape(B, 20, 1, 14, 14).numpy()
+    err = float(np.abs(masks - ref["masks"]).max())
+    _metric("mask_rcnn_fp32", mask_err=err, mask_mean=float(masks.mean()))
+    assert err < 2e-3 and masks.std() > 0.01
+    # the plugin operator by itself
+    g = torch.Generator().manual_seed(3)
+    lab = torch.randint(-1, 6, (2, 7), generator=g).float()
+    m = torch.randn(2, 7, 5, 6, 6, generator=g)
+    got = det_ops.mask_rcnn_inference(lab.to(gpu), m.to(gpu)).cpu().numpy()
+    assert np.allclose(got, dp.mask_select(lab.numpy(), m.numpy()), atol=1e-6)
+
+
+def test_mask_rcnn_fp16_engine(gpu):
+    """fp16 build: the 2x2/2 ConvTranspose runs as a 1x1 MFMA implicit GEMM + depth-to-space; masks vs the oracle restarted
+    from the engine's own features / boxes / labels."""
+    cfg = dict(pre_nms_topk=500, post_nms_topk=100, detections=30)
+    path, _ = synth_wts("rcnn_r50c4")
+    B, H, W = 2, 160, 224
+    plan = engine.build_plan("rcnn_r50c4", path, batch=B, fp16=1, h=H, w=W, mark_stages=1, mask=1, **cfg)
+    kinds = [o["kind"] for o in engine.describe_plan(plan, lowered=True)["ops"]]
+    assert "depth_to_space" in kinds and "deconv" not in kinds
+    x = _images(B, H, W, 9)
+    out = _run(plan, {"images": x.numpy()}, B, gpu)
+    fdim = lambda n: functools.reduce(lambda v, _: (v - 1) // 2 + 1, range(4), n)  # noqa: E731
+    feats = out["features"].reshape(B, 1024, fdim(H), fdim(W))
+    boxes = out["boxes"].reshape(B, 30, 4).numpy()
+    labels = out["labels"].reshape(B, 30).numpy()
+    with torch.inference_mode():
+        ref = mt.rcnn_r50c4(mt.Params(owts.load_wts(path)), x, pre_nms_topk=500, post_nms_topk=100, detections_per_image=30,
+                            mask_on=True, given={"features": feats, "proposals": out["proposals"].reshape(B, 100, 4).numpy(),
+                                                 "boxes": boxes, "labels": labels})
+    masks = out["masks"].reshape(B, 30, 1, 14, 14).numpy()
+    err = float(np.abs(masks - ref["masks"]).max())
+    _metric("mask_rcnn_fp16", mask_err=err, mask_mean=float(masks.mean()))
+    assert np.isfinite(masks).all() and err < 3e-2 and masks.std() > 0.01

@@ -245,7 +245,7 @@ def _happens_before(ops):
                                         ("retinaface_r50", dict(batch=1, fp16=1, h=320, w=320)),
                                         ("resnet50", dict(batch=2, fp16=1)),
                                         ("rcnn_r50c4", dict(batch=1, fp16=1, h=128, w=160, pre_nms_topk=200, post_nms_topk=40,
-                                                            detections=10))])
+                                                            detections=10, mask=1))])
 def test_lanes_and_arena_plan_are_race_free(model, opts):
     """Independent check of the concurrency plan the lowering emits (lanes = HIP streams, waits = events): every reader
     is ordered after every writer of its storage, and two arena blocks share bytes only if all ops touching one
@@ -291,3 +291,23 @@ def test_product_side_yolov8n_weights_match_the_test_generator():
     sd = synth.yolov8n_state(0)
     assert list(sd) == list(tensors)
     assert all(np.array_equal(sd[k], tensors[k].numpy()) for k in sd)
+
+
+def test_mask_rcnn_builder_matches_pytorch_restatement():
+    """MASK_ON (rcnn.cpp:202-232): second RoIAlign on the final boxes, res5 with shared weights, ConvTranspose + ReLU,
+    1x1 predictor, MaskRcnnInference plugin; interpreted layer by layer == the PyTorch restatement."""
+    path, _ = synth_wts("rcnn_r50c4")
+    plan = engine.build_plan("rcnn_r50c4", path, batch=1, fp16=0, h=64, w=96, mask=1, **RCNN_SMALL)
+    desc = engine.describe_plan(plan)
+    plugs = [l["plugin_type"] for l in desc["layers"] if l["kind"] == 16]
+    assert plugs == ["RpnDecode", "RpnNms", "RoiAlign", "PredictorDecode", "BatchedNms", "RoiAlign", "MaskRcnnInference"]
+    out_dims = {t["name"]: t["dims"] for t in desc["tensors"] if t["is_output"]}
+    assert out_dims["masks"] == [10, 1, 14, 14]
+    x = torch.from_numpy(synth.images(1, 64, 96, seed=5)).permute(0, 2, 3, 1).contiguous() * 255
+    res = gi.run(desc, plan, {"images": x.numpy()})
+    with torch.inference_mode():
+        ref = mt.rcnn_r50c4(mt.Params(owts.load_wts(path)), x, pre_nms_topk=100, post_nms_topk=20, detections_per_image=10,
+                            mask_on=True)
+    assert np.array_equal(res["labels"].numpy().reshape(1, -1), ref["labels"])
+    got = res["masks"].numpy().reshape(ref["masks"].shape)
+    assert np.allclose(got, ref["masks"], atol=1e-5) and 0.05 < float(ref["masks"].mean()) < 0.95 and ref["masks"].std() > 0.01

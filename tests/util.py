@@ -10,7 +10,7 @@ from oracle import models_torch as mt
 from tensorrtx_amd import wts as wts_writer
 
 CACHE = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
-WTS_VERSION = {"retinaface_r50": 2, "rcnn_r50c4": 2}  # bump when a model's synthetic initialisation changes (cache key)
+WTS_VERSION = {"retinaface_r50": 2, "rcnn_r50c4": 3}  # bump when a model's synthetic initialisation changes (cache key)
 
 
 def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
