@@ -90,6 +90,16 @@ int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float con
                       trtx_stream_t stream);
 
 
+/*
+ * The reference's optional GPU post-processing mode "g": cuda_decode + cuda_nms (yolov8/src/postprocess.cu:42-111, call
+ * site yolov8/yolov8_det.cpp:105-112; batch 1 only there, any batch here).  NOT the same result as trtx_yolo_nms: the
+ * suppression is non-greedy (a box is dropped if any same-class box with higher confidence overlaps it).
+ *   out  device, fp32 [batch][1 + max_out*7]: out[0] = input count, then records x1,y1,x2,y2,conf,class,keep (1/0) in input
+ *        slot order; records of positions with conf < conf_thresh are all-zero.  max_out <= 1024.
+ */
+int32_t trtx_yolo_postprocess_gpu(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                  float* out, trtx_stream_t stream);
+
 /* ---- RetinaFace ------------------------------------------------------------------------------- */
 /*
  * DecodePlugin::enqueue (reference retinaface/decode.cu:110-191).  inputs[l] (l = stride 8/16/32): device fp32

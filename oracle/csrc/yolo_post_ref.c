@@ -164,3 +164,57 @@ void yolo_batch_nms_ref(const float* output, int batch, int max_out, float conf_
                                    keep_det ? keep_det + (size_t)b * max_out * 6 : NULL);
     }
 }
+
+/* ---- GPU post-processing mode "g" (yolov8/src/postprocess.cu:42-111; call site yolov8_det.cpp:105-112), restated
+ * sequentially.  decode_kernel copies candidates with conf >= conf_thresh into 7-float records (x1,y1,x2,y2,conf,cls,keep=1);
+ * every position takes a slot (atomicAdd before the confidence test), so slots of rejected positions stay zero and the
+ * count is the input count.  Canonical slot order = input order (the reference's atomics make it arbitrary).
+ * nms_kernel is NOT greedy: a box is dropped if ANY same-class box with higher confidence (equal confidence: higher
+ * index) overlaps it by more than the threshold, whether or not that box survives itself.
+ * out: [batch][1 + max_out*7] */
+static float gpu_box_iou(const float* a, const float* b) {
+    const float cleft = a[0] > b[0] ? a[0] : b[0];
+    const float ctop = a[1] > b[1] ? a[1] : b[1];
+    const float cright = a[2] < b[2] ? a[2] : b[2];
+    const float cbottom = a[3] < b[3] ? a[3] : b[3];
+    float cw = cright - cleft, ch = cbottom - ctop;
+    cw = cw > 0.0f ? cw : 0.0f;
+    ch = ch > 0.0f ? ch : 0.0f;
+    const float c_area = cw * ch;
+    if (c_area == 0.0f) return 0.0f;
+    float aw = a[2] - a[0], ah = a[3] - a[1], bw = b[2] - b[0], bh = b[3] - b[1];
+    aw = aw > 0.0f ? aw : 0.0f;
+    ah = ah > 0.0f ? ah : 0.0f;
+    bw = bw > 0.0f ? bw : 0.0f;
+    bh = bh > 0.0f ? bh : 0.0f;
+    return c_area / (aw * ah + bw * bh - c_area);
+}
+
+void yolo_gpu_postprocess_ref(const float* output, int batch, int max_out, float conf_thresh, float nms_thresh, float* out) {
+    const int in_elem = 1 + max_out * DET_FLOATS, out_elem = 1 + max_out * 7;
+    for (int b = 0; b < batch; ++b) {
+        const float* src = output + (size_t)b * in_elem;
+        float* dst = out + (size_t)b * out_elem;
+        memset(dst, 0, sizeof(float) * out_elem);
+        int count = (int)src[0];
+        if (count > max_out) count = max_out; /* decode-count clamp, as everywhere in this oracle */
+        dst[0] = (float)count;
+        for (int i = 0; i < count; ++i) {
+            const float* it = src + 1 + (size_t)i * DET_FLOATS;
+            if (it[4] < conf_thresh) continue; /* NaN passes "<", exactly as in the kernel */
+            float* o = dst + 1 + (size_t)i * 7;
+            o[0] = it[0]; o[1] = it[1]; o[2] = it[2]; o[3] = it[3]; o[4] = it[4]; o[5] = it[5]; o[6] = 1.0f;
+        }
+        for (int p = 0; p < count; ++p) {
+            float* cur = dst + 1 + (size_t)p * 7;
+            for (int i = 0; i < count; ++i) {
+                const float* it = dst + 1 + (size_t)i * 7;
+                if (i == p || cur[5] != it[5]) continue;
+                if (it[4] >= cur[4]) {
+                    if (it[4] == cur[4] && i < p) continue;
+                    if (gpu_box_iou(cur, it) > nms_thresh) { cur[6] = 0.0f; break; }
+                }
+            }
+        }
+    }
+}

@@ -119,3 +119,50 @@ def nms_py(output_row, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
                     n += 1
             m += 1
     return keep
+
+
+def gpu_postprocess_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """Mode "g" of the reference (yolov8/src/postprocess.cu:42-111), C restatement: [B, 1 + max_out*7]."""
+    output = np.ascontiguousarray(output, dtype=np.float32)
+    batch = output.shape[0]
+    out = np.zeros((batch, 1 + max_out * 7), dtype=np.float32)
+    lib().yolo_gpu_postprocess_ref(_fp(output), batch, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh), _fp(out))
+    return out
+
+
+def gpu_postprocess_py(row, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """Independent pure-Python statement of the same mode for one image (cross-check of the C)."""
+    f32 = np.float32
+    count = min(int(row[0]), max_out)
+    out = np.zeros(1 + max_out * 7, dtype=np.float32)
+    out[0] = count
+    det = np.asarray(row[1:1 + max_out * DET_FLOATS], dtype=np.float32).reshape(max_out, DET_FLOATS)
+    for i in range(count):
+        if not (det[i, 4] < conf_thresh):
+            out[1 + 7 * i:1 + 7 * i + 6] = det[i, :6]
+            out[1 + 7 * i + 6] = 1.0
+    rec = out[1:].reshape(max_out, 7)
+
+    def iou(a, b):
+        cw = max(f32(min(a[2], b[2]) - max(a[0], b[0])), f32(0))
+        ch = max(f32(min(a[3], b[3]) - max(a[1], b[1])), f32(0))
+        c = f32(cw * ch)
+        if c == 0:
+            return f32(0)
+        aa = f32(max(f32(a[2] - a[0]), f32(0)) * max(f32(a[3] - a[1]), f32(0)))
+        bb = f32(max(f32(b[2] - b[0]), f32(0)) * max(f32(b[3] - b[1]), f32(0)))
+        return f32(c / f32(f32(aa + bb) - c))
+
+    keep = rec[:, 6].copy()
+    for p in range(count):
+        for i in range(count):
+            if i == p or rec[p, 5] != rec[i, 5]:
+                continue
+            if rec[i, 4] >= rec[p, 4]:
+                if rec[i, 4] == rec[p, 4] and i < p:
+                    continue
+                if iou(rec[p], rec[i]) > f32(nms_thresh):
+                    keep[p] = 0.0
+                    break
+    rec[:, 6] = keep
+    return out

@@ -89,6 +89,16 @@ def yolo_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45, with_de
     return keep_idx, keep_cnt, keep_det
 
 
+def yolo_postprocess_gpu(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """The reference's GPU post-processing mode "g" (yolov8/src/postprocess.cu:42-111): [B, 1 + max_out*7]."""
+    import torch
+    B = decode_out.shape[0]
+    out = torch.empty((B, 1 + max_out * 7), dtype=torch.float32, device=decode_out.device)
+    check(lib().trtx_yolo_postprocess_gpu(_p(decode_out), B, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+                                          _p(out), _stream()), "trtx_yolo_postprocess_gpu")
+    return out
+
+
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "silu": 3, "leaky": 4, "tanh": 5}
 
 

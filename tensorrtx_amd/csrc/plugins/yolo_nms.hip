@@ -259,7 +259,78 @@ __global__ __launch_bounds__(kCap) void yolo_nms_scan_kernel(NmsWs ws, int max_o
     if (tid == 0) keep_cnt[b] = total;
 }
 
+// ---- the reference's optional GPU post-processing mode "g" (yolov8/src/postprocess.cu:42-111): threshold + copy into
+// 7-float records, then the NON-greedy NMS of nms_kernel (a box is dropped if any same-class box with higher confidence -
+// equal confidence: higher index - overlaps it, whether or not that box survives).  One workgroup per image, records in LDS.
+// Slots keep the input order (the reference assigns them with an atomicAdd, i.e. arbitrarily); slots of positions below the
+// threshold stay zero and out[0] = input count, as in the reference.
+__device__ __forceinline__ float box_iou_g(const float* a, const float* b) {  // postprocess.cu:73-85
+    const float cleft = a[0] > b[0] ? a[0] : b[0];
+    const float ctop = a[1] > b[1] ? a[1] : b[1];
+    const float cright = a[2] < b[2] ? a[2] : b[2];
+    const float cbottom = a[3] < b[3] ? a[3] : b[3];
+    float cw = cright - cleft, ch = cbottom - ctop;
+    cw = cw > 0.0f ? cw : 0.0f;
+    ch = ch > 0.0f ? ch : 0.0f;
+    const float c_area = cw * ch;
+    if (c_area == 0.0f) return 0.0f;
+    float aw = a[2] - a[0], ah = a[3] - a[1], bw = b[2] - b[0], bh = b[3] - b[1];
+    aw = aw > 0.0f ? aw : 0.0f;
+    ah = ah > 0.0f ? ah : 0.0f;
+    bw = bw > 0.0f ? bw : 0.0f;
+    bh = bh > 0.0f ? bh : 0.0f;
+    return c_area / (aw * ah + bw * bh - c_area);
+}
+
+__global__ __launch_bounds__(kCap) void yolo_gpu_post_kernel(const float* __restrict__ decode, int in_elem, int det_floats,
+                                                             int max_out, float conf_thresh, float nms_thresh,
+                                                             float* __restrict__ out) {
+    __shared__ float s_rec[kCap][7];  // odd stride: conflict-free row reads
+    const int b = blockIdx.x, p = threadIdx.x;
+    const float* img = decode + (size_t)b * in_elem;
+    float* dst = out + (size_t)b * (1 + (size_t)max_out * 7);
+    int count = (int)img[0];
+    count = count < max_out ? count : max_out;
+    float rec[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p < count) {
+        const float* it = img + 1 + (size_t)p * det_floats;
+        if (!(it[4] < conf_thresh)) {
+            rec[0] = it[0]; rec[1] = it[1]; rec[2] = it[2]; rec[3] = it[3]; rec[4] = it[4]; rec[5] = it[5]; rec[6] = 1.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 7; ++e) s_rec[p][e] = rec[e];
+    __syncthreads();
+    if (p < count) {
+        for (int i = 0; i < count; ++i) {
+            if (i == p || rec[5] != s_rec[i][5]) continue;
+            const float ci = s_rec[i][4];
+            if (ci >= rec[4]) {
+                if (ci == rec[4] && i < p) continue;
+                if (box_iou_g(rec, s_rec[i]) > nms_thresh) {
+                    rec[6] = 0.0f;
+                    break;
+                }
+            }
+        }
+    }
+    if (p == 0) dst[0] = (float)count;
+    if (p < max_out) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) dst[1 + (size_t)p * 7 + e] = rec[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t trtx_yolo_postprocess_gpu(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                             float* out, hipStream_t stream) {
+    if (!decode_out || !out || batch < 1 || max_out < 1) return TRTX_ERR_INVALID;
+    if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(yolo_gpu_post_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, 1 + max_out * trtx::kYoloDetFloats,
+                       trtx::kYoloDetFloats, max_out, conf_thresh, nms_thresh, out);
+    return trtx::check_launch("trtx_yolo_postprocess_gpu");
+}
 
 extern "C" size_t trtx_yolo_nms_workspace(int batch) {
     return batch < 1 ? 0 : nms_ws_bytes(batch);

@@ -149,3 +149,15 @@ def test_decode_then_nms_end_to_end_properties(gpu):
         assert (conf > 0.5).all()
     _, gc2, _ = capi.yolo_nms(torch.from_numpy(buf).to(gpu))
     assert np.array_equal(gc2.cpu().numpy(), gc_h)
+
+
+def test_gpu_mode_postprocess_matches_oracle(gpu):
+    """trtx_yolo_postprocess_gpu == the sequential restatement of the reference's mode "g" (bit exact, input slot order)."""
+    import torch
+    heads = synth.yolo_head_tensors(3, 80, 640, 640, objects=(60, 200), seed=21)
+    dec = yp.decode_c(heads, 80, 640, 640, [8, 16, 32])
+    dec[2, 0] = 0  # an empty image
+    ref = yp.gpu_postprocess_c(dec)
+    got = capi.yolo_postprocess_gpu(torch.from_numpy(dec).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert ref[0, 1:].reshape(-1, 7)[:, 6].sum() > 20

@@ -106,3 +106,22 @@ def test_nms_edge_cases():
     out[0, 0] = 0
     ki, kc, _ = yp.batch_nms_c(out)
     assert kc[0] == 0
+
+
+def test_gpu_mode_postprocess_c_matches_python_and_differs_from_greedy_on_chains():
+    """Mode "g" of the reference (postprocess.cu:42-111): C restatement == pure-Python statement; and its non-greedy rule
+    really is different from batch_nms on a chain A > B > C where A kills B and B (dead) would still kill C."""
+    from tensorrtx_amd import synth
+    heads = synth.yolo_head_tensors(2, 80, 320, 320, objects=(20, 60), seed=3)
+    dec = yp.decode_c(heads, 80, 320, 320, [8, 16, 32])
+    g = yp.gpu_postprocess_c(dec)
+    p = np.stack([yp.gpu_postprocess_py(dec[b]) for b in range(2)])
+    assert np.array_equal(g, p) and g[:, 0].min() > 50
+    # chain: A=(0,0,10,10) .9, B=(4,0,14,10) .8, C=(8,0,18,10) .7, same class: IoU(A,B)=IoU(B,C)=0.43 (>0.4), IoU(A,C)=0.11
+    row = np.zeros((1, 1 + 1000 * yp.DET_FLOATS), np.float32)
+    row[0, 0] = 3
+    for i, (x0, conf) in enumerate(((0, .9), (4, .8), (8, .7))):
+        row[0, 1 + i * yp.DET_FLOATS:1 + i * yp.DET_FLOATS + 6] = [x0, 0, x0 + 10, 10, conf, 2]
+    keep_flags = yp.gpu_postprocess_c(row, nms_thresh=0.4)[0, 1:].reshape(-1, 7)[:3, 6]
+    _, cnt, _ = yp.batch_nms_c(row, nms_thresh=0.4)
+    assert keep_flags.tolist() == [1.0, 0.0, 0.0] and cnt[0] == 2  # greedy keeps A and C, mode "g" keeps only A
