@@ -311,3 +311,23 @@ def test_mask_rcnn_builder_matches_pytorch_restatement():
     assert np.array_equal(res["labels"].numpy().reshape(1, -1), ref["labels"])
     got = res["masks"].numpy().reshape(ref["masks"].shape)
     assert np.allclose(got, ref["masks"], atol=1e-5) and 0.05 < float(ref["masks"].mean()) < 0.95 and ref["masks"].std() > 0.01
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_device():
+    """Error behaviour of the operator entry points: null pointers / impossible sizes come back as TRTX_ERR_INVALID (1),
+    capacities beyond the kernel's design as TRTX_ERR_UNSUPPORTED (4) - no launch, no crash, also without a GPU."""
+    L = capi.lib()
+    null = ctypes.c_void_p()
+    buf = (ctypes.c_float * 16)()
+    f = ctypes.c_float
+    assert L.trtx_yolo_nms(null, 1, 1000, f(0.5), f(0.45), null, null, null, null, ctypes.c_size_t(0), null) == 1
+    assert L.trtx_yolo_nms(buf, 1, 4096, f(0.5), f(0.45), buf, buf, null, buf, ctypes.c_size_t(1 << 30), null) == 4
+    assert L.trtx_yolo_nms(buf, 1, 1000, f(0.5), f(0.45), buf, buf, null, buf, ctypes.c_size_t(16), null) == 3  # workspace too small
+    assert L.trtx_yolo_postprocess_gpu(null, 1, 1000, f(0.5), f(0.45), buf, null) == 1
+    assert L.trtx_yolo_postprocess_gpu(buf, 1, 2000, f(0.5), f(0.45), buf, null) == 4
+    assert L.trtx_mask_rcnn_inference(1, null, buf, 10, 14, 80, buf, null) == 1
+    assert L.trtx_mask_rcnn_inference(0, buf, buf, 10, 14, 80, buf, null) == 1
+    assert L.trtx_rpn_nms(1, null, buf, 6000, 1000, f(0.7), buf, buf, ctypes.c_size_t(64), null) == 1
+    assert L.trtx_batched_nms(1, 1, buf, buf, null, 1000, 100, f(0.5), buf, buf, buf, buf, ctypes.c_size_t(64), null) == 1
+    L.trtx_status_string.restype = ctypes.c_char_p
+    assert L.trtx_status_string(3) == b"workspace too small" and L.trtx_status_string(5) == b"no HIP device"
