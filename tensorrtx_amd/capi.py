@@ -17,6 +17,26 @@ def lib_path() -> str:
     return os.path.join(_HERE, "lib", "libtrtx_hip.so")
 
 
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (must be exactly one once lib() has run)."""
+    seen = []
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in os.path.basename(path) and path not in seen:
+                seen.append(path)
+    return seen
+
+
+def _bind_hip_runtime():
+    """libtrtx_hip.so NEEDs `libamdhip64.so.7` and PyTorch-ROCm bundles its own copy under torch/lib with the
+    same SONAME.  Whichever copy is mapped first satisfies the other's NEEDED entry *only* in the torch-first
+    order (torch dlopens its copy by path; ours is looked up by SONAME).  Two runtimes in one process each own a
+    separate device table: torch sees the GPU, trtx_device_count() in the other does not.  So the binding always
+    brings torch's runtime in first; a process that never uses torch (pure C++ callers) links the system ROCm."""
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so; plumbing only)
+
+
 def lib() -> ctypes.CDLL:
     """Load libtrtx_hip.so.  Fails loudly when the extension has not been built (no fallback)."""
     global _LIB
@@ -25,7 +45,12 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(p):
             raise ImportError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _bind_hip_runtime()
         L = ctypes.CDLL(p)
+        rts = hip_runtimes_mapped()
+        if len(rts) > 1:
+            raise ImportError("two HIP runtimes are mapped in this process (%s): something dlopened a HIP library "
+                              "before tensorrtx_amd/torch; import torch (or tensorrtx_amd) first" % ", ".join(rts))
         L.trtx_status_string.restype = ctypes.c_char_p
         L.trtx_status_string.argtypes = [ctypes.c_int32]
         L.trtx_yolo_decode_workspace.restype = ctypes.c_size_t

@@ -331,3 +331,20 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert L.trtx_batched_nms(1, 1, buf, buf, null, 1000, 100, f(0.5), buf, buf, buf, buf, ctypes.c_size_t(64), null) == 1
     L.trtx_status_string.restype = ctypes.c_char_p
     assert L.trtx_status_string(3) == b"workspace too small" and L.trtx_status_string(5) == b"no HIP device"
+
+
+@pytest.mark.parametrize("order", ["package_first", "torch_first", "entry_build_first"])
+def test_single_hip_runtime_whatever_the_import_order(order):
+    """Round-1 regression: dlopening libtrtx_hip.so before torch mapped two libamdhip64 runtimes (torch saw the GPU,
+    trtx_device_count() did not).  The binding now maps torch's runtime first; assert exactly one copy in a fresh
+    process for every import order a user script / the driver can produce."""
+    import subprocess
+    import sys
+    pre = {"package_first": "import tensorrtx_amd; tensorrtx_amd.lib(); import torch",
+           "torch_first": "import torch; import tensorrtx_amd; tensorrtx_amd.lib()",
+           "entry_build_first": "import __graft_entry__ as g; g.build(); import torch"}[order]
+    code = pre + "; from tensorrtx_amd import capi, engine; engine.models_lib(); r = capi.hip_runtimes_mapped(); " \
+                 "print(len(r), r); assert len(r) == 1, r"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
