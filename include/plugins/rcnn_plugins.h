@@ -13,7 +13,8 @@
 // These are *user* plugins in the TensorRT sense: they live in the application (here: libtrtx_models.so), reach the
 // engine through the IPluginV2 trampoline of include/NvInfer.h and are re-created at deserialization by the creators
 // registered below, so the process that deserializes an R-CNN plan must have this header's creators linked in, exactly
-// as with the reference.  Serialized parameter blobs are little-endian PODs (layout documented per class).
+// as with the reference.  Serialized parameter blobs use the reference's byte layouts (documented
+// per class), so a blob written by a reference plugin loads here and vice versa (tests/test_ref_pinning.py).
 #pragma once
 #include <cstring>
 #include <string>
@@ -43,6 +44,12 @@ struct BlobReader {
         if (p + sizeof(T) <= end) std::memcpy(&v, p, sizeof(T));
         p += sizeof(T);
         return v;
+    }
+    // element count read from the blob, clamped to what the blob can still hold (a corrupt count must not allocate)
+    template <typename T>
+    size_t count(uint64_t n) const {
+        const size_t left = p < end ? (size_t)(end - p) / sizeof(T) : 0;
+        return n < left ? (size_t)n : left;
     }
 };
 
@@ -88,7 +95,8 @@ class Creator : public IPluginCreator {
 
 // inputs : objectness {A, fh, fw}, anchor deltas {4A, fh, fw}
 // outputs: scores {top_n, 1}, boxes {top_n, 4} (XYXY, clipped to the image), best first
-// blob   : i32 top_n | i32 n_anchor_floats | f32 anchors[] | f32 stride | i32 fh | i32 fw | i32 image_h | i32 image_w
+// blob   : the reference's byte layout (RpnDecodePlugin.h:41-76): i32 top_n | u64 n_anchor_floats | f32 anchors[] | f32 stride |
+//          u64 fh | u64 fw | u64 image_h | u64 image_w  (size_t = u64 on LP64)
 class RpnDecodePlugin : public rcnn_detail::Base<RpnDecodePlugin> {
    public:
     static constexpr const char* kType = "RpnDecode";
@@ -97,24 +105,24 @@ class RpnDecodePlugin : public rcnn_detail::Base<RpnDecodePlugin> {
     RpnDecodePlugin(const void* data, size_t length) {
         rcnn_detail::BlobReader r(data, length);
         top_n_ = r.get<int32_t>();
-        anchors_.resize((size_t)r.get<int32_t>());
+        anchors_.resize(r.count<float>(r.get<uint64_t>()));
         for (float& a : anchors_) a = r.get<float>();
         stride_ = r.get<float>();
-        fh_ = r.get<int32_t>();
-        fw_ = r.get<int32_t>();
-        image_h_ = r.get<int32_t>();
-        image_w_ = r.get<int32_t>();
+        fh_ = (int)r.get<uint64_t>();
+        fw_ = (int)r.get<uint64_t>();
+        image_h_ = (int)r.get<uint64_t>();
+        image_w_ = (int)r.get<uint64_t>();
     }
     std::vector<char> pack() const {
         rcnn_detail::BlobWriter w;
         w.put<int32_t>(top_n_);
-        w.put<int32_t>((int32_t)anchors_.size());
+        w.put<uint64_t>(anchors_.size());
         for (float a : anchors_) w.put<float>(a);
         w.put<float>(stride_);
-        w.put<int32_t>(fh_);
-        w.put<int32_t>(fw_);
-        w.put<int32_t>(image_h_);
-        w.put<int32_t>(image_w_);
+        w.put<uint64_t>((uint64_t)fh_);
+        w.put<uint64_t>((uint64_t)fw_);
+        w.put<uint64_t>((uint64_t)image_h_);
+        w.put<uint64_t>((uint64_t)image_w_);
         return w.bytes;
     }
     const char* getPluginType() const noexcept override { return kType; }
@@ -144,7 +152,7 @@ class RpnDecodePlugin : public rcnn_detail::Base<RpnDecodePlugin> {
 };
 
 // inputs : scores {pre, 1}, boxes {pre, 4};  output: boxes {post, 4}
-// blob   : f32 nms_thresh | i32 post_nms_topk | i32 pre_nms_topk
+// blob   : the reference's byte layout (RpnNmsPlugin.h:36-53): f32 nms_thresh | i32 post_nms_topk | u64 pre_nms_topk
 class RpnNmsPlugin : public rcnn_detail::Base<RpnNmsPlugin> {
    public:
     static constexpr const char* kType = "RpnNms";
@@ -153,13 +161,13 @@ class RpnNmsPlugin : public rcnn_detail::Base<RpnNmsPlugin> {
         rcnn_detail::BlobReader r(data, length);
         thresh_ = r.get<float>();
         post_ = r.get<int32_t>();
-        pre_ = r.get<int32_t>();
+        pre_ = (int)r.get<uint64_t>();
     }
     std::vector<char> pack() const {
         rcnn_detail::BlobWriter w;
         w.put<float>(thresh_);
         w.put<int32_t>(post_);
-        w.put<int32_t>(pre_);
+        w.put<uint64_t>((uint64_t)pre_);
         return w.bytes;
     }
     const char* getPluginType() const noexcept override { return kType; }
@@ -181,7 +189,7 @@ class RpnNmsPlugin : public rcnn_detail::Base<RpnNmsPlugin> {
 };
 
 // inputs : boxes {P, 4}, features {C, fh, fw};  output: {P, C, res, res}
-// blob   : i32 res | f32 spatial_scale | i32 sampling_ratio | i32 num_proposals | i32 channels | i32 fh | i32 fw
+// blob   : the reference's byte layout (RoiAlignPlugin.h:39-45): i32 res | f32 spatial_scale | i32 sampling_ratio | i32 num_proposals | i32 channels | i32 fh | i32 fw
 class RoiAlignPlugin : public rcnn_detail::Base<RoiAlignPlugin> {
    public:
     static constexpr const char* kType = "RoiAlign";
@@ -233,7 +241,8 @@ class RoiAlignPlugin : public rcnn_detail::Base<RoiAlignPlugin> {
 
 // inputs : scores {N, C, 1, 1}, deltas {N, 4C, 1, 1}, proposals {N, 4}
 // outputs: scores {N, 1}, boxes {N, 4}, classes {N, 1}
-// blob   : i32 num_boxes | i32 num_classes | i32 image_h | i32 image_w | f32 bbox_reg_weights[4]
+// blob   : the reference's byte layout (PredictorDecodePlugin.h:43-51): u32 num_boxes | u32 num_classes | u32 image_h | u32 image_w |
+//          u64 n_weights | f32 bbox_reg_weights[n]
 class PredictorDecodePlugin : public rcnn_detail::Base<PredictorDecodePlugin> {
    public:
     static constexpr const char* kType = "PredictorDecode";
@@ -247,7 +256,11 @@ class PredictorDecodePlugin : public rcnn_detail::Base<PredictorDecodePlugin> {
         classes_ = r.get<int32_t>();
         image_h_ = r.get<int32_t>();
         image_w_ = r.get<int32_t>();
-        for (float& w : w_) w = r.get<float>();
+        const size_t nw = r.count<float>(r.get<uint64_t>());
+        for (size_t k = 0; k < nw; ++k) {
+            const float v = r.get<float>();
+            if (k < 4) w_[k] = v;
+        }
     }
     std::vector<char> pack() const {
         rcnn_detail::BlobWriter w;
@@ -255,6 +268,7 @@ class PredictorDecodePlugin : public rcnn_detail::Base<PredictorDecodePlugin> {
         w.put<int32_t>(classes_);
         w.put<int32_t>(image_h_);
         w.put<int32_t>(image_w_);
+        w.put<uint64_t>(4);
         for (float v : w_) w.put<float>(v);
         return w.bytes;
     }
@@ -284,7 +298,7 @@ class PredictorDecodePlugin : public rcnn_detail::Base<PredictorDecodePlugin> {
 };
 
 // inputs : scores {N, 1}, boxes {N, 4}, classes {N, 1};  outputs: scores {D, 1}, boxes {D, 4}, classes {D, 1}
-// blob   : i32 nms_method | f32 nms_thresh | i32 detections_per_im | i32 count
+// blob   : the reference's byte layout (BatchedNmsPlugin.h:40-43): i32 nms_method | f32 nms_thresh | i32 detections_per_im | u64 count
 class BatchedNmsPlugin : public rcnn_detail::Base<BatchedNmsPlugin> {
    public:
     static constexpr const char* kType = "BatchedNms";
@@ -295,14 +309,14 @@ class BatchedNmsPlugin : public rcnn_detail::Base<BatchedNmsPlugin> {
         method_ = r.get<int32_t>();
         thresh_ = r.get<float>();
         dets_ = r.get<int32_t>();
-        count_ = r.get<int32_t>();
+        count_ = (int)r.get<uint64_t>();
     }
     std::vector<char> pack() const {
         rcnn_detail::BlobWriter w;
         w.put<int32_t>(method_);
         w.put<float>(thresh_);
         w.put<int32_t>(dets_);
-        w.put<int32_t>(count_);
+        w.put<uint64_t>((uint64_t)count_);
         return w.bytes;
     }
     const char* getPluginType() const noexcept override { return kType; }
@@ -326,7 +340,7 @@ class BatchedNmsPlugin : public rcnn_detail::Base<BatchedNmsPlugin> {
 };
 
 // inputs : labels {D, 1}, masks {D, C, S, S};  output: {D, 1, S, S} = sigmoid of each detection's own class plane
-// blob   : i32 detections_per_im | i32 output_size | i32 num_classes
+// blob   : the reference's byte layout (MaskRcnnInferencePlugin.h:31-35): i32 detections_per_im | i32 output_size | i32 num_classes
 class MaskRcnnInferencePlugin : public rcnn_detail::Base<MaskRcnnInferencePlugin> {
    public:
     static constexpr const char* kType = "MaskRcnnInference";

@@ -176,21 +176,22 @@ def _plugin(l, ins, batch):
         arrs = [np.ascontiguousarray(t.numpy().reshape(batch, 32, -1)) for t in ins]
         out = det_post.retina_decode(arrs, net_h, net_w)
         return [torch.from_numpy(out).reshape(batch, -1, 1, 1)]
-    # R-CNN plugins: blob layouts documented in include/plugins/rcnn_plugins.h
+    # R-CNN plugins: the reference's own blob layouts (rcnn/*Plugin.h deserialize()), size_t = u64
+    u64 = lambda off, n=1: [int(v) for v in np.frombuffer(blob, dtype=np.uint64, count=n, offset=off)]  # noqa: E731
     i32 = lambda off, n=1: [int(v) for v in np.frombuffer(blob, dtype=np.int32, count=n, offset=off)]  # noqa: E731
     f32 = lambda off, n=1: [float(v) for v in np.frombuffer(blob, dtype=np.float32, count=n, offset=off)]  # noqa: E731
     arr = [np.ascontiguousarray(t.numpy()) for t in ins]
     if l["plugin_type"] == "RpnDecode":
-        top_n, na = i32(0, 2)
-        anchors = np.frombuffer(blob, dtype=np.float32, count=na, offset=8).copy()
-        o = 8 + 4 * na
+        top_n, na = i32(0)[0], u64(4)[0]
+        anchors = np.frombuffer(blob, dtype=np.float32, count=na, offset=12).copy()
+        o = 12 + 4 * na
         stride = f32(o)[0]
-        fh, fw, ih, iw = i32(o + 4, 4)
+        fh, fw, ih, iw = u64(o + 4, 4)
         s, b = det_post.rpn_decode(arr[0], arr[1], fh, fw, ih, iw, stride, anchors, top_n)
         return [torch.from_numpy(s).reshape(batch, top_n, 1), torch.from_numpy(b)]
     if l["plugin_type"] == "RpnNms":
         thresh = f32(0)[0]
-        post, pre = i32(4, 2)
+        post, pre = i32(4)[0], u64(8)[0]
         return [torch.from_numpy(det_post.rpn_nms(arr[0].reshape(batch, pre), arr[1], post, thresh))]
     if l["plugin_type"] == "RoiAlign":
         res = i32(0)[0]
@@ -199,13 +200,13 @@ def _plugin(l, ins, batch):
         return [torch.from_numpy(det_post.roi_align(arr[0], arr[1], res, scale, sampling))]
     if l["plugin_type"] == "PredictorDecode":
         n, c, ih, iw = i32(0, 4)
-        w = f32(16, 4)
+        w = f32(24, u64(16)[0])
         s, b, cl = det_post.predictor_decode(arr[0].reshape(batch, n, c), arr[1].reshape(batch, n, 4 * c), arr[2], ih, iw, w)
         return [torch.from_numpy(s).reshape(batch, n, 1), torch.from_numpy(b), torch.from_numpy(cl).reshape(batch, n, 1)]
     if l["plugin_type"] == "BatchedNms":
         method = i32(0)[0]
         thresh = f32(4)[0]
-        dets, count = i32(8, 2)
+        dets, count = i32(8)[0], u64(12)[0]
         s, b, cl = det_post.batched_nms(method, arr[0].reshape(batch, count), arr[1], arr[2].reshape(batch, count), dets, thresh)
         return [torch.from_numpy(s).reshape(batch, dets, 1), torch.from_numpy(b), torch.from_numpy(cl).reshape(batch, dets, 1)]
     if l["plugin_type"] == "MaskRcnnInference":
