@@ -40,12 +40,13 @@ def canon_records(out, rec_floats, keep_floats):
 
 class Case:
     def __init__(self, name, family, plugin, batch, inputs, out_shapes, blob=None, fields=None, canon=None, ref_exact=True,
-                 rtol=0.0, atol=0.0):
+                 rtol=0.0, atol=0.0, per_image=False):
         self.name, self.family, self.plugin, self.batch = name, family, plugin, batch
         self.inputs, self.out_shapes, self.blob, self.fields = inputs, out_shapes, blob, fields
         self.canon = canon or (lambda outs: [np.asarray(o) for o in outs])
         self.ref_exact = ref_exact          # False: the reference kernel itself races (documented per case)
         self.rtol, self.atol = rtol, atol   # tolerance for values that pass through expf (device vs glibc: 1 ulp)
+        self.per_image = per_image          # run the reference one image per enqueue (see rpn_nms_case)
 
 
 def _t(a, dev):
@@ -120,14 +121,19 @@ def rpn_decode_oracle(c):
 
 def rpn_nms_case(batch=2, pre=600, post=64, seed=5):
     """pre <= 1024: the reference launches ceil(pre/1024) blocks that synchronise with a block-level barrier only
-    (RpnNms.cu:93-110), so it is exact greedy NMS for one block and racy beyond."""
+    (RpnNms.cu:93-110), so it is exact greedy NMS for one block and racy beyond.
+    per_image: found by this pin — rpnNms() fills its `indices` iota ONCE before the batch loop (RpnNms.cu:84-88) and the
+    re-sort of image 0 then overwrites it (RpnNms.cu:112-113), so for images >= 1 of a batch the first sort pairs scores
+    with image 0's final permutation and the gathered boxes are wrong.  The reference only ever runs BATCH_SIZE = 1
+    (rcnn.cpp:24); the product implements the batch-0 semantics for every image, and the reference is driven one image
+    per enqueue here."""
     anchors = dp.generate_anchors()
     h, w = 20, 30
     s, d = synth.rcnn_rpn_tensors(batch, 15, h, w, seed=seed)
     rs, rb = dp.rpn_decode(s.reshape(batch, -1), d.reshape(batch, -1), h, w, h * 16, w * 16, 16.0, anchors, pre)
     blob = struct.pack("<fiQ", 0.7, post, pre)
     c = Case(f"rpn_nms_{pre}_{post}", "rcnn_plugins", "RpnNms", batch, [rs.reshape(batch, pre, 1), rb], [(batch, post, 4)], blob=blob,
-             ref_exact=pre <= 1024)
+             ref_exact=pre <= 1024, per_image=True)
     c.p = (pre, post)
     return c
 
@@ -189,13 +195,17 @@ def predictor_decode_oracle(c):
     return [a.reshape(c.batch, n, 1), b, cl.reshape(c.batch, n, 1)]
 
 
-def batched_nms_case(method, batch=2, count=200, dets=50, seed=6):
+def batched_nms_case(method, batch=2, count=200, dets=50, seed=6, class_mod=0):
+    """per_image: batchedNms() has the same `indices` reuse across its batch loop as rpnNms() (BatchedNms.cu:115-119 vs
+    :146-148, see rpn_nms_case).  class_mod folds the 80 classes onto a few so that the class-aware NMS suppresses a lot."""
     s, d, p = synth.rcnn_box_head_tensors(batch, count, 80, seed=seed)
     ps, pb, pc = dp.predictor_decode(s, d, p, 800, 1333)
+    if class_mod:
+        pc = np.mod(pc, class_mod).astype(np.float32)
     blob = struct.pack("<ifiQ", method, 0.5, dets, count)
-    c = Case(f"batched_nms_m{method}_{count}_{dets}", "rcnn_plugins", "BatchedNms", batch,
+    c = Case(f"batched_nms_m{method}_{count}_{dets}_mod{class_mod}", "rcnn_plugins", "BatchedNms", batch,
              [ps.reshape(batch, count, 1), pb, pc.reshape(batch, count, 1)], [(batch, dets, 1), (batch, dets, 4), (batch, dets, 1)], blob=blob,
-             rtol=1e-5 if method == 2 else 0.0, atol=1e-7 if method == 2 else 0.0)
+             rtol=1e-5 if method == 2 else 0.0, atol=1e-7 if method == 2 else 0.0, per_image=True)
     c.p = (method, count, dets)
     return c
 
@@ -248,6 +258,9 @@ def all_cases():
         (batched_nms_case(0), batched_nms_product, batched_nms_oracle),
         (batched_nms_case(1), batched_nms_product, batched_nms_oracle),
         (batched_nms_case(2), batched_nms_product, batched_nms_oracle),
+        (batched_nms_case(0, class_mod=2, seed=16), batched_nms_product, batched_nms_oracle),
+        (batched_nms_case(1, class_mod=2, seed=17), batched_nms_product, batched_nms_oracle),
+        (batched_nms_case(2, class_mod=2, seed=18), batched_nms_product, batched_nms_oracle),
         (mask_case(), mask_product, mask_oracle),
     ]
 
@@ -256,9 +269,16 @@ def run_reference(case, dev):
     """The reference's own plugin on the GPU, through the C-ABI v-table."""
     from oracle import ref
     creators = ref.load_plugins(case.family)
-    v = ref.make_plugin(creators[case.plugin], blob=case.blob, fields=case.fields if case.blob is None else None)
-    outs = ref.run_plugin(v, case.batch, [_t(x, dev) for x in case.inputs], case.out_shapes)
-    return [o.cpu().numpy() for o in outs]
+
+    def once(batch, inputs, out_shapes):
+        v = ref.make_plugin(creators[case.plugin], blob=case.blob, fields=case.fields if case.blob is None else None)
+        outs = ref.run_plugin(v, batch, [_t(x, dev) for x in inputs], out_shapes)
+        return [o.cpu().numpy() for o in outs]
+
+    if not case.per_image:
+        return once(case.batch, case.inputs, case.out_shapes)
+    per = [once(1, [x[b:b + 1] for x in case.inputs], [(1,) + tuple(s[1:]) for s in case.out_shapes]) for b in range(case.batch)]
+    return [np.concatenate([p[k] for p in per], 0) for k in range(len(case.out_shapes))]
 
 
 def compare(case, got, want, what):
