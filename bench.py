@@ -1,57 +1,82 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the YOLOv8n detection hot path (fp16 conv backbone -> YoloLayer decode
--> NMS) at batch 32, 640x640, on N MI355X GPUs of one node (BASELINE.json metric; config C3).
+"""Headline benchmark: images/sec of the detection hot path on N MI355X GPUs of one node (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of 32 synthetic images already resident in HBM:
-IExecutionContext::enqueue (63 fused MFMA convolutions + pools/resizes + DFL tail + YoloLayer plugin)
-followed by the GPU NMS.  Independent image streams are sharded over the ranks (one process per GPU, one
-engine replica each, no data-path collective) -> weak scaling.
+Default workload (config C3, BASELINE configs[2]): YOLOv8n fp16, 640x640, batch 32 per GPU: one "step" = one pass of
+the hot path over one batch of synthetic images already resident in HBM = IExecutionContext::enqueue (fused MFMA
+convolutions + pools/resizes + DFL tail + YoloLayer decode) followed by the GPU NMS.  Independent image streams are
+sharded over the ranks (one process per GPU, one engine replica each, no data-path collective).
 
-Prints ONE JSON line (rank 0) with the driver contract fields plus `roofline` and `cpu_baseline`.
+  python bench.py                                  1 GPU, C3, weak scaling unit
+  python bench.py --gpus 8                         spawns 8 ranks itself (torch.distributed.run, RCCL barrier/all-reduce for timing)
+  python -m torch.distributed.run ... bench.py --gpus 8     (how the driver launches it; same code path)
+  python bench.py --gpus 8 --mode strong           global batch fixed at 32 -> 4 images per GPU
+  python bench.py --config retinaface_r50 --gpus 8 C4: RetinaFace-R50 1280x1280, global batch 8, image-sharded (1 per GPU at N=8)
+  python bench.py --config resnet50 | rcnn_r50c4   C2 / C5 lines (conv backbone only / full plugin chain)
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus `roofline`, `cpu_baseline` (+ `parity`, C3 at N=1).
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 32
-SIZE = 640
-GFLOP_PER_IMAGE = 8.743          # conv FLOP of YOLOv8n @640 (2*MAC), re-derived by the lowering pass
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming copy reaches)
-# HBM traffic of the conv kernels per launch, measured in a separate `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum`
-# pass over this same command (profiles/r01_pmc_conv_traffic.txt): (2 x RDREQ + WRREQ) x 64 B summed over the conv
-# launches of a step / launches (reads doubled per the gfx950 note in MI355X_MICROARCH.md "HBM").  None = not measured.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 39352748  # profiles/r01_pmc_conv_traffic.txt (algorithmic: 34.46 MB -> 1.14x)
+N_INPUT_SETS = 8                 # rotating input batches: a step never re-reads the batch the previous step left in the caches
+
+# model -> (BASELINE config, per-GPU batch at weak scaling, H, W, input scale, global batch of the "strong" partition)
+CONFIGS = {
+    "yolov8n": dict(tag="C3 (BASELINE configs[2])", batch=32, h=640, w=640, scale=1.0, inp="images", nms=True),
+    "resnet50": dict(tag="C2 (BASELINE configs[1])", batch=32, h=224, w=224, scale=1.0, inp="data", nms=False),
+    "retinaface_r50": dict(tag="C4 (BASELINE configs[3])", batch=8, h=1280, w=1280, scale=255.0, inp="data", nms=False, strong_default=True),
+    "rcnn_r50c4": dict(tag="C5 (BASELINE configs[4]; the reference implements R50-C4, SURVEY 8 note)", batch=4, h=800, w=1333, scale=255.0,
+                       inp="images", nms=False),
+}
 
 
-def cpu_baseline(path, seconds_budget=20.0):
-    """The oracle (PyTorch-CPU fp32 restatement of the reference graph + C decode/NMS) timed on the host cores
-    on a bounded sample of the same workload.  Reported next to the GPU number; never the thing measured."""
+def _traffic_from_profile(model):
+    """HBM bytes per conv launch from the L2 fabric counters: measured by a SEPARATE `rocprofv3 --pmc` pass over this same
+    command (tools/pmc_bench_traffic.sh) and committed under profiles/; read from there so that the number printed is the
+    number on file (None when no pass has been recorded for this model)."""
+    p = os.path.join(ROOT, "profiles", "pmc_conv_traffic.json")
+    try:
+        rec = json.load(open(p)).get(model)
+        return (rec["bytes_per_launch"], rec["source"]) if rec else (None, None)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0):
+    """The oracle (PyTorch-CPU fp32 restatement of the reference graph + C decode/NMS) timed on the host cores on a bounded
+    sample of the same workload: reported next to the GPU number, never the thing measured.  The same oracle outputs are
+    compared with what the GPU produced for the same images -> `parity` (what the fp16 engine is off by)."""
     import numpy as np
     import torch
 
     from oracle import models_torch as mt
     from oracle import wts as owts
     from oracle import yolo_post as yp
-    from tensorrtx_amd import synth
 
-    # small-channel convolutions stop scaling (and oversubscribe badly) past a few dozen threads
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(os.cpu_count() or 1, 32)  # small-channel convolutions stop scaling (and oversubscribe) past a few dozen threads
     torch.set_num_threads(cores)
     params = owts.load_wts(path)
     nb = 4
-    x = torch.from_numpy(synth.images(nb, SIZE, SIZE, seed=11))
+    x = torch.from_numpy(images[:nb])
+    keep = {}
 
     def once():
         with torch.inference_mode():
             heads, strides = mt.yolov8_det(mt.Params(params), x)
-        dec = yp.decode_c([h.numpy() for h in heads], 80, SIZE, SIZE, strides)
-        yp.batch_nms_c(dec)
+        dec = yp.decode_c([h.numpy() for h in heads], 80, x.shape[2], x.shape[3], strides)
+        keep["heads"], keep["dec"] = heads, dec
+        keep["nms"] = yp.batch_nms_c(dec)
 
     once()  # warm-up
     t0 = time.perf_counter()
@@ -62,8 +87,45 @@ def cpu_baseline(path, seconds_budget=20.0):
         if time.perf_counter() - t0 > seconds_budget or n >= 64:
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} images ({nb}/iter) 640x640 fp32, PyTorch-CPU restatement of the reference graph + C decode/NMS"}
+    # parity of the fp16 engine vs the fp32 oracle on those same images: head logits and decoded boxes
+    logit_err = max(float((g[:nb] - h.numpy().reshape(g[:nb].shape)).__abs__().max()) for g, h in zip(gpu_heads, keep["heads"]))
+    ious, matched, total = [], 0, 0
+    for b in range(nb):
+        nr, ng = int(keep["dec"][b, 0]), int(gpu_dec[b, 0])
+        r = keep["dec"][b, 1:1 + nr * 90].reshape(nr, 90)
+        g = gpu_dec[b, 1:1 + ng * 90].reshape(ng, 90)
+        for rec in r[r[:, 4] > 0.25]:
+            total += 1
+            cand = g[g[:, 5] == rec[5]]
+            if not len(cand):
+                continue
+            ix = np.maximum(0, np.minimum(cand[:, 2], rec[2]) - np.maximum(cand[:, 0], rec[0]))
+            iy = np.maximum(0, np.minimum(cand[:, 3], rec[3]) - np.maximum(cand[:, 1], rec[1]))
+            inter = ix * iy
+            iou = inter / ((cand[:, 2] - cand[:, 0]) * (cand[:, 3] - cand[:, 1]) + (rec[2] - rec[0]) * (rec[3] - rec[1]) - inter)
+            if iou.max() > 0.9:
+                matched += 1
+                ious.append(float(iou.max()))
+    parity = {"vs": "fp32 PyTorch-CPU oracle, same weights and images", "images": nb, "head_logit_max_abs_err": logit_err,
+              "oracle_candidates_conf>0.25": total, "matched_same_class_iou>0.9": matched,
+              "min_box_iou": min(ious) if ious else None,
+              "north_star_tolerance": "1e-4 logit / 1e-3 IoU: met by the fp32 build (tests), NOT by this fp16 build (fp16 storage of 63 layers)",
+              "nms_kept_indices": "bit-exact vs the oracle on identical decode buffers (tests/test_gpu_yolo_plugins.py, test_ref_pinning.py)"}
+    return base, parity
+
+
+def _spawn_self(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run and relay the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -71,9 +133,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="yolov8n", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=None, choices=["weak", "strong"],
+                    help="weak: fixed per-GPU batch (default); strong: the config's global batch is split over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent timing table (JSON) to this path")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_self(args)
 
     import numpy as np
     import torch
@@ -83,6 +151,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if torch.cuda.device_count() < (local + 1):
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -96,104 +168,170 @@ def main():
     from tensorrtx_amd import capi, engine, replicas, synth
     from tensorrtx_amd import wts as wts_writer
 
-    # seeded synthetic YOLOv8n weights (no trained weights offline), written once per box in the reference's .wts format
-    path = os.path.join(os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache"), "bench_yolov8n_seed0.wts")
-    if not os.path.exists(path):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        tmp = f"{path}.{os.getpid()}.tmp"
-        wts_writer.write_wts(tmp, synth.yolov8n_state(seed=0), dialect="double")
-        os.replace(tmp, path)
-    plan = engine.build_plan("yolov8n", path, batch=BATCH, h=SIZE, w=SIZE, fp16=1)
+    cfg = CONFIGS[args.config]
+    mode = args.mode or ("strong" if cfg.get("strong_default") else "weak")
+    if mode == "strong":
+        mine = replicas.partition(cfg["batch"], world, rank)
+        batch = len(mine)
+        if batch == 0:
+            raise SystemExit(f"strong scaling of global batch {cfg['batch']} over {world} GPUs leaves rank {rank} empty")
+        global_batch = cfg["batch"]
+    else:
+        batch = cfg["batch"]
+        global_batch = batch * world
+    H, W = cfg["h"], cfg["w"]
+
+    cache = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
+    os.makedirs(cache, exist_ok=True)
+    if args.config == "yolov8n":
+        # seeded synthetic YOLOv8n weights (no trained weights offline), written once per box in the reference's .wts format
+        path = os.path.join(cache, "bench_yolov8n_seed0.wts")
+        if not os.path.exists(path):
+            tmp = f"{path}.{os.getpid()}.tmp"
+            wts_writer.write_wts(tmp, synth.yolov8n_state(seed=0), dialect="double")
+            os.replace(tmp, path)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import synth_wts  # seeded synthetic weights through the product-side writer
+        path, _ = synth_wts(args.config)
+    plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1)
     low = engine.describe_plan(plan, lowered=True)
     eng = engine.Engine(plan)
-    x = torch.from_numpy(synth.images(BATCH, SIZE, SIZE, seed=100 + rank)).to(dev)  # resident in HBM
-    out = torch.empty((BATCH, 1 + 1000 * 90), dtype=torch.float32, device=dev)
-    bindings = [x, out]
+
+    # bindings: N_INPUT_SETS rotating input batches (resident in HBM), one set of outputs
+    rng_imgs = [synth.images(batch, H, W, seed=100 + 17 * rank + k) * cfg["scale"] for k in range(N_INPUT_SETS if args.config == "yolov8n" else 2)]
+    nhwc_input = args.config == "rcnn_r50c4"  # DataPreprocess takes HWC images (rcnn.cpp:80-100)
+    inputs = [torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1)) if nhwc_input else x).to(dev) for x in rng_imgs]
+    outs = {}
+    for i in range(eng.nb_bindings):
+        if not eng.is_input[i]:
+            outs[i] = torch.empty(batch * int(np.prod(eng.dims[i])), dtype=torch.float32, device=dev)
+    in_idx = [i for i in range(eng.nb_bindings) if eng.is_input[i]][0]
+    binding_sets = [[inputs[k] if i == in_idx else outs[i] for i in range(eng.nb_bindings)] for k in range(len(inputs))]
+
     L = capi.lib()
-    keep_idx = torch.empty((BATCH, 1000), dtype=torch.int32, device=dev)
-    keep_cnt = torch.empty((BATCH,), dtype=torch.int32, device=dev)
-    keep_det = torch.empty((BATCH, 1000, 6), dtype=torch.float32, device=dev)
-    import ctypes
     stream = capi._stream()
-    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
-    nms_ws_bytes = L.trtx_yolo_nms_workspace(BATCH)
-    nms_ws = torch.empty((nms_ws_bytes,), dtype=torch.uint8, device=dev)
+    if cfg["nms"]:
+        out = outs[eng.names.index("output")].reshape(batch, 1 + 1000 * 90)
+        keep_idx = torch.empty((batch, 1000), dtype=torch.int32, device=dev)
+        keep_cnt = torch.empty((batch,), dtype=torch.int32, device=dev)
+        keep_det = torch.empty((batch, 1000, 6), dtype=torch.float32, device=dev)
+        L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+        nms_ws_bytes = L.trtx_yolo_nms_workspace(batch)
+        nms_ws = torch.empty((nms_ws_bytes,), dtype=torch.uint8, device=dev)
+        host_cnt = torch.empty((batch,), dtype=torch.int32).pin_memory()
+        host_det = torch.empty((batch, 100, 6), dtype=torch.float32).pin_memory()
 
-    def step():
-        eng.enqueue(BATCH, bindings)
-        capi.check(L.trtx_yolo_nms(capi._p(out), BATCH, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(keep_idx),
-                                   capi._p(keep_cnt), capi._p(keep_det), capi._p(nms_ws), ctypes.c_size_t(nms_ws_bytes), stream),
-                   "trtx_yolo_nms")
+    def step(k):
+        eng.enqueue(batch, binding_sets[k % len(binding_sets)])
+        if cfg["nms"]:
+            capi.check(L.trtx_yolo_nms(capi._p(out), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(keep_idx),
+                                       capi._p(keep_cnt), capi._p(keep_det), capi._p(nms_ws), ctypes.c_size_t(nms_ws_bytes), stream),
+                       "trtx_yolo_nms")
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = replicas.max_over_ranks(dt, dist, dev)
+    def timed(n_steps, with_d2h=False):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(k)
+            if with_d2h:  # what the reference's timer includes: results back on the host (yolov8_det.cpp:97-104)
+                host_cnt.copy_(keep_cnt, non_blocking=True)
+                host_det.copy_(keep_det[:, :100], non_blocking=True)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return replicas.max_over_ranks(time.perf_counter() - t0, dist, dev)
+
+    for k in range(args.warmup):
+        step(k)
+    dt = timed(args.steps)
+    dt_d2h = timed(args.steps, with_d2h=True) if cfg["nms"] else None
 
     # per-kernel timing with HIP events on the launch stream (IProfiler analogue): roofline of the dominant kernel
     prof_runs = 5
-    conv_ms = 0.0
-    tot_ms = 0.0
+    conv_ms = tot_ms = 0.0
     n_conv = 0
     for _ in range(prof_runs):
-        rows = eng.profile(BATCH, bindings)
+        rows = eng.profile(batch, binding_sets[0])
         conv = [r for r, o in zip(rows, low["ops"]) if o["kind"] == "conv" and o.get("igemm")]
         n_conv = len(conv)
         conv_ms += sum(r["ms"] for r in conv)
         tot_ms += sum(r["ms"] for r in rows)
     if args.dump_ops and rank == 0:
-        json.dump(rows, open(args.dump_ops, "w"), indent=0)
+        json.dump([dict(r, **{k: o.get(k) for k in ("cin", "cout", "k", "hw_in", "hw_out", "residual", "flops", "kernel")})
+                   for r, o in zip(rows, low["ops"])], open(args.dump_ops, "w"), indent=0)
     conv_ms /= prof_runs
     tot_ms /= prof_runs
-    # Dominant kernel = the fused implicit-GEMM convolution (62 launches per step).  Every YOLOv8n layer sits below the
-    # MFMA/HBM ridge (arithmetic intensity 16..290 FLOP/B against 312), so the bound that applies is HBM: achieved =
-    # ALGORITHMIC bytes per launch (fp16 activations in + out (+ residual) at batch 32, + the layer's packed weights once;
-    # DESIGN.md "Measurement") / average launch duration from the per-op HIP events above.  The MFMA view is reported too.
+    # Dominant kernel family = the fused MFMA convolutions.  ALGORITHMIC bytes per launch = fp16 activations in + out
+    # (+ residual) at this batch + the layer's packed weights once (DESIGN.md "Measurement"); duration = per-op HIP events.
+    # YOLOv8n layers sit below the MFMA/HBM ridge (arithmetic intensity 16..290 FLOP/B against 312) -> bound "hbm";
+    # ResNet-50 / RetinaFace / R-CNN are dominated by layers above it -> bound "mfma".  Both views are always printed.
     igemm_ops = [o for o in low["ops"] if o["kind"] == "conv" and o.get("igemm")]
     alg_bytes = 0.0
+    flop_per_step = 0.0
     for o in igemm_ops:
+        nb = o.get("nfix") or batch              # images per launch = nb * nmul (nmul: RoIs per image in the R-CNN head)
         act = o["hw_in"][0] * o["hw_in"][1] * o["cin"] + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (2 if o["residual"] else 1)
-        alg_bytes += 2.0 * act * BATCH + 2.0 * o["cout"] * o["cin"] * o["k"][0] * o["k"][1]
-    flop_per_step = sum(o["flops"] for o in igemm_ops) * BATCH
+        alg_bytes += 2.0 * act * nb * o.get("nmul", 1) + 2.0 * o["cout"] * o["cin"] * o["k"][0] * o["k"][1]
+        flop_per_step += o["flops"] * nb          # plan flops are per sample and already include nmul
     avg_launch_s = conv_ms * 1e-3 / max(n_conv, 1)
     achieved_gbps = alg_bytes / max(n_conv, 1) / avg_launch_s / 1e9
     achieved_tflops = flop_per_step / (conv_ms * 1e-3) / 1e12
-    roofline = {"bound": "hbm", "kernel": "conv_igemm_f16_kernel / conv_igemm_wsk_f16_kernel (fused implicit-GEMM conv, all instantiations)",
+    hbm_view = {"bytes_per_launch": alg_bytes / max(n_conv, 1), "achieved_GBps": achieved_gbps, "peak_GBps": HBM_PEAK_GBPS,
+                "frac": achieved_gbps / HBM_PEAK_GBPS}
+    mfma_view = {"flop_per_launch": flop_per_step / max(n_conv, 1), "achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                 "frac": achieved_tflops / MFMA_PEAK_TFLOPS}
+    intensity = flop_per_step / max(alg_bytes, 1.0)
+    bound = "hbm" if intensity < MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS else "mfma"
+    traffic, traffic_src = _traffic_from_profile(args.config)
+    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_ws_f16 / conv_igemm_f16 / conv_igemm_wsk_f16, all instantiations)",
                 "launches_per_step": n_conv, "avg_launch_us": avg_launch_s * 1e6,
-                "bytes_per_launch": alg_bytes / max(n_conv, 1), "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS,
-                # HBM bytes per launch from the L2 fabric counters (separate rocprofv3 --pmc pass, gfx950 read correction
-                # applied): see PMC_TRAFFIC_BYTES_PER_LAUNCH
-                "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH,
-                "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms,
-                "mfma_view": {"flop_per_launch": flop_per_step / max(n_conv, 1), "achieved_TFLOPs": achieved_tflops,
-                              "peak_TFLOPs": MFMA_PEAK_TFLOPS, "frac": achieved_tflops / MFMA_PEAK_TFLOPS},
-                "whole_step_hbm_view": {"algorithmic_bytes_per_step": alg_bytes,
-                                        "GBps_at_measured_step": alg_bytes / (dt / args.steps) / 1e9}}
+                "achieved": achieved_gbps if bound == "hbm" else achieved_tflops, "peak": HBM_PEAK_GBPS if bound == "hbm" else MFMA_PEAK_TFLOPS,
+                "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "frac": (achieved_gbps / HBM_PEAK_GBPS) if bound == "hbm" else (achieved_tflops / MFMA_PEAK_TFLOPS),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "arithmetic_intensity_flop_per_byte": intensity,
+                "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms, "hbm_view": hbm_view, "mfma_view": mfma_view,
+                "whole_step_hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": alg_bytes / (dt / args.steps) / 1e9}}
     res = {
-        "metric": "images/sec @ batch=32 640x640 fp16 (YOLOv8n conv backbone + YoloLayer decode + NMS)",
-        "value": world * BATCH * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": f"images/sec @ batch={cfg['batch']} {W}x{H} fp16 ({args.config}" + (" conv backbone + YoloLayer decode + NMS)" if cfg["nms"] else ", IExecutionContext::enqueue)"),
+        "value": (global_batch if mode == "strong" else world * batch) * args.steps / dt, "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": mode,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "yolov8n fp16 640x640 batch=32 per GPU (BASELINE configs[2]): enqueue + GPU NMS, inputs resident in HBM",
-                   "global_batch": world * BATCH, "parallelism": f"replica-per-GPU x{world} (image-sharded, no collective)",
+        "config": {"workload": f"{args.config} fp16 {W}x{H}, {cfg['tag']}: per-GPU batch {batch}, " +
+                               ("enqueue + GPU NMS" if cfg["nms"] else "enqueue (all plugins inside the engine)") +
+                               f", {len(binding_sets)} rotating input batches resident in HBM",
+                   "global_batch": global_batch, "parallelism": f"replica-per-GPU x{world} (image-sharded, no data-path collective; RCCL only brackets the timed region)",
                    "weights": "seeded synthetic .wts (no trained weights offline)"},
         "roofline": roofline,
     }
+    if cfg["nms"]:
+        res["d2h_inclusive"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_d2h, "unit": "images/sec",
+                                "ms_per_step": dt_d2h / args.steps * 1e3,
+                                "what": "same steps + async copy of kept counts and top-100 detections to pinned host memory each step (the reference's timer includes D2H, yolov8_det.cpp:97-104)"}
+        torch.cuda.synchronize()
+        res["detections"] = {"decode_candidates_per_image": float(out[:, 0].float().mean().item()),
+                             "kept_after_nms_per_image": float(keep_cnt.float().mean().item()),
+                             "note": "seeded random weights: candidate counts are not those of a trained model"}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(path)
+        if world == 1 and args.config == "yolov8n" and not args.no_cpu_baseline and mode == "weak":
+            # GPU outputs for the oracle's sample images (a separate small engine run, outside every timed region)
+            nb = 4
+            plan_h = engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=1, mark_heads=1)
+            eh = engine.Engine(plan_h)
+            imgs = synth.images(nb, H, W, seed=11)
+            bufs = [torch.from_numpy(imgs).to(dev)] + [torch.empty(nb * int(np.prod(eh.dims[i])), dtype=torch.float32, device=dev)
+                                                       for i in range(1, eh.nb_bindings)]
+            eh.enqueue(nb, bufs)
+            torch.cuda.synchronize()
+            heads = [bufs[eh.names.index(f"head{i}")].cpu().numpy().reshape(nb, -1) for i in range(3)]
+            dec = bufs[eh.names.index("output")].cpu().numpy().reshape(nb, -1)
+            eh.close()
+            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(path, heads, dec, imgs)
         print(json.dumps(res), flush=True)
     eng.close()
     if dist:

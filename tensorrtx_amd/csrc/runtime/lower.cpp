@@ -1412,7 +1412,8 @@ std::string Plan::describe_json() const {
               << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
               << ",\"act2\":" << a.act2 << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
-              << ",\"ld_out\":" << a.ld_out;
+              << ",\"ld_out\":" << a.ld_out << ",\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
+              << (op.stem ? 0 : tensors[op.in[0]].nfix);
         }
         o << ",\"lane\":" << op.lane << ",\"waits\":[";
         for (size_t j = 0; j < op.wait_ops.size(); ++j) o << (j ? "," : "") << op.wait_ops[j];
