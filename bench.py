@@ -220,7 +220,7 @@ def main():
         nms_ws_bytes = L.trtx_yolo_nms_workspace(batch)
         nms_ws = torch.empty((nms_ws_bytes,), dtype=torch.uint8, device=dev)
         host_cnt = torch.empty((batch,), dtype=torch.int32).pin_memory()
-        host_det = torch.empty((batch, 100, 6), dtype=torch.float32).pin_memory()
+        host_det = torch.empty((batch, 1000, 6), dtype=torch.float32).pin_memory()
 
     def step(k):
         eng.enqueue(batch, binding_sets[k % len(binding_sets)])
@@ -239,7 +239,7 @@ def main():
             step(k)
             if with_d2h:  # what the reference's timer includes: results back on the host (yolov8_det.cpp:97-104)
                 host_cnt.copy_(keep_cnt, non_blocking=True)
-                host_det.copy_(keep_det[:, :100], non_blocking=True)
+                host_det.copy_(keep_det, non_blocking=True)  # contiguous 768 KB: two DMA copies per step
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -312,7 +312,7 @@ def main():
     if cfg["nms"]:
         res["d2h_inclusive"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_d2h, "unit": "images/sec",
                                 "ms_per_step": dt_d2h / args.steps * 1e3,
-                                "what": "same steps + async copy of kept counts and top-100 detections to pinned host memory each step (the reference's timer includes D2H, yolov8_det.cpp:97-104)"}
+                                "what": "same steps + async copy of the kept counts and the compacted detection buffer [B,1000,6] to pinned host memory each step (the reference's timer includes D2H, yolov8_det.cpp:97-104)"}
         torch.cuda.synchronize()
         res["detections"] = {"decode_candidates_per_image": float(out[:, 0].float().mean().item()),
                              "kept_after_nms_per_image": float(keep_cnt.float().mean().item()),

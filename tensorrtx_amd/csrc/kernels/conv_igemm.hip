@@ -708,6 +708,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
 
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     if (!conv_igemm_supported(a0)) return TRTX_ERR_UNSUPPORTED;
+    if (conv_ws_supported(a0)) return conv_ws_f16(a0, s);  // small-channel 3x3 / 1x1: weight-stationary persistent kernel
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);

@@ -41,6 +41,10 @@ int conv_igemm_pick_bk(int cin, int taps);  // k-step width for a (padded-to-8) 
 int conv_igemm_pick_cink(int cin, int bk);  // per-tap stride of the packed K axis
 bool conv_igemm_supported(const ConvArgs& a);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
+// registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
+bool conv_ws_supported(const ConvArgs& a);
+int32_t conv_ws_f16(const ConvArgs& a, hipStream_t s);
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);

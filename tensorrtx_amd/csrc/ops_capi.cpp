@@ -86,7 +86,11 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.M = N * a.Ho * a.Wo;
     a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
     a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
-    return conv_igemm_f16(a, stream);
+    // TRTX_OP_REPS=n (timing tools only): n back-to-back launches per call, so that the device — not the Python caller — sets the pace
+    static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;
+    int32_t st = TRTX_OK;
+    for (int r = 0; r < reps && st == TRTX_OK; ++r) st = conv_igemm_f16(a, stream);
+    return st;
 }
 
 extern "C" int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad,

@@ -274,6 +274,9 @@ bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
     return true;
 }
 
+// built-in plugins only enqueue kernels and stream-ordered memsets on the caller's stream: safe inside a stream capture
+bool builtin_plugin_capturable(const trtx_plugin_vtbl& v) { return v.enqueue == yolo_enqueue || v.enqueue == rdec_enqueue; }
+
 void register_builtin_plugins(PluginRegistry& r) {
     trtx_creator_vtbl c{};
     c.plugin_name = yolo_creator_name;

@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "plan.h"
 
 struct trtx_engine {
@@ -26,6 +28,18 @@ struct trtx_context {
     std::vector<hipStream_t> lane_stream;
     std::vector<hipEvent_t> op_event, lane_done;
     hipEvent_t start_event = nullptr;
+    // hipGraph replay of the lane schedule (one graph per (batch, binding pointers) seen; see trtx_context_enqueue)
+    struct CapturedGraph {
+        int batch = 0;
+        std::vector<void*> bindings;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::vector<CapturedGraph> graphs;
+    std::vector<CapturedGraph> seen;   // combinations enqueued once (eagerly) so far
+    uint64_t enqueue_count = 0;
+    int graph_state = 0;   // 0 undecided, 1 eligible, -1 never (user plugins, capture failed once, disabled)
     ~trtx_context();
 };
 

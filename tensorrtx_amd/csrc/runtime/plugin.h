@@ -81,5 +81,8 @@ struct YoloLayerParams {
     bool det_only;
 };
 bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out);
+// true for the built-in HIP plugins (kernels + stream-ordered memsets only): their enqueue may run inside a hipGraph capture.
+// A user IPluginV2 may synchronise, allocate or copy from pageable memory (the reference's R-CNN plugins do all three).
+bool builtin_plugin_capturable(const trtx_plugin_vtbl& v);
 
 }  // namespace trtx

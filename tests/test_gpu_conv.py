@@ -37,6 +37,26 @@ CASES = [
     (1, 14, 14, 256, 64, 1, 1, 0, "none", True, "relu"),     # resnet bottleneck tail: relu(conv + shortcut)
     (1, 17, 13, 48, 64, 3, 1, 1, "relu", False, "none"),     # ragged M (221 pixels), Cin 48
     (1, 9, 9, 24, 40, 5, 1, 2, "leaky", False, "none"),      # 5x5, Cout 40 (padded to 48 -> bn 16)
+    # --- shapes served by the weight-stationary persistent kernel (conv_ws.hip): several tiles per workgroup, image borders,
+    # ragged last tiles, every wave split (WC 1/2/4), both tile sizes, row-aligned and whole-row tile geometry
+    (3, 80, 80, 64, 64, 3, 1, 1, "silu", False, "none"),     # 16-px row tiles (ROWS), WC=2, 150 tiles
+    (3, 80, 80, 32, 32, 3, 1, 1, "silu", True, "none"),      # KC=1, residual
+    (2, 40, 40, 64, 64, 3, 1, 1, "silu", True, "none"),      # W=40: whole-row tiles 3x40, fragments cross rows
+    (5, 20, 20, 64, 64, 3, 1, 1, "silu", False, "none"),     # W=20: 64-pixel tiles
+    (2, 80, 80, 64, 80, 3, 1, 1, "silu", False, "none"),     # Cout 80 on 8 column fragments (WC=4)
+    (2, 40, 40, 128, 64, 3, 1, 1, "silu", False, "none"),    # KC=4, one column fragment per wave
+    (2, 23, 37, 64, 64, 3, 1, 1, "relu", False, "none"),     # odd map: partial tiles in both directions
+    (4, 160, 160, 32, 32, 1, 1, 0, "silu", False, "none"),   # 1x1 streaming, 800 tiles
+    (2, 160, 160, 48, 32, 1, 1, 0, "silu", False, "none"),   # Cin 48 in a 64-wide k-slice (zero-filled chunk tail)
+    (2, 80, 80, 128, 64, 1, 1, 0, "silu", False, "none"),
+    (2, 80, 80, 192, 64, 1, 1, 0, "silu", False, "none"),    # KC=6
+    (2, 80, 80, 96, 64, 1, 1, 0, "silu", False, "none"),     # KC=3
+    (3, 40, 40, 256, 128, 1, 1, 0, "silu", False, "none"),   # KC=8, WC=2
+    (3, 40, 40, 384, 128, 1, 1, 0, "silu", False, "none"),   # KC=12, WC=4, 64-pixel tiles
+    (3, 40, 40, 192, 128, 1, 1, 0, "silu", False, "none"),
+    (7, 20, 20, 256, 256, 1, 1, 0, "silu", False, "none"),   # WC=4, NFW=4
+    (3, 80, 80, 80, 80, 1, 1, 0, "none", False, "none"),     # head 1x1, 5 column fragments, bias only
+    (1, 7, 9, 64, 64, 1, 1, 0, "none", True, "relu"),        # 63 pixels: a single ragged tile, residual + relu
 ]
 
 
