@@ -91,6 +91,23 @@ int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float con
 
 
 /*
+ * Anchor-based YoloLayer (YOLOv5 / v7 / v3 / v4 family) - the reference's yolov5/plugin/yololayer.cu:161-227.
+ *   inputs     n_levels device pointers, fp32 [batch][3 * (5 + classes (+ 32 if is_segmentation))][grid_h * grid_w]
+ *   grid_w/h   per level (YoloKernel::width / height, yolov5/src/types.h:5-9); anchors: n_levels x 6 floats (w0,h0,w1,h1,w2,h2)
+ *   output     device, fp32 [batch][1 + max_out * 38]: count (clamped to max_out), then Detection records of 38 floats
+ *              (yolov5/src/types.h:11-16): cx, cy, w, h, conf = obj * cls, class_id, mask[32]
+ * Candidates with sigmoid(obj) >= 0.1 (kIgnoreThresh) in canonical (level, cell, anchor) order (the reference: atomicAdd race).
+ */
+size_t trtx_yolov5_decode_workspace(int batch, const int* grid_w, const int* grid_h, int n_levels);
+int32_t trtx_yolov5_decode(const float* const* inputs, int n_levels, int batch, int classes, int net_h, int net_w,
+                           const int* grid_w, const int* grid_h, const float* anchors, int max_out, int is_segmentation,
+                           float* output, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+/* YOLOv5 host nms() / batch_nms() on the GPU (yolov5/src/postprocess.cpp:30-80): centre-format IoU, conf <= thresh dropped,
+ * class-wise greedy suppression in conf-descending order.  Same outputs / workspace as trtx_yolo_nms; records are 38 floats. */
+int32_t trtx_yolov5_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh, int32_t* keep_idx,
+                        int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+
+/*
  * The reference's optional GPU post-processing mode "g": cuda_decode + cuda_nms (yolov8/src/postprocess.cu:42-111, call
  * site yolov8/yolov8_det.cpp:105-112; batch 1 only there, any batch here).  NOT the same result as trtx_yolo_nms: the
  * suppression is non-greedy (a box is dropped if any same-class box with higher confidence overlaps it).

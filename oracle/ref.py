@@ -205,10 +205,12 @@ def make_plugin(creator, blob=None, fields=None):
         buf = ctypes.create_string_buffer(bytes(blob), len(blob))
         rc = creator.deserialize(creator.self, name, ctypes.cast(buf, _V), len(blob), ctypes.byref(v))
     else:
-        keep = [np.ascontiguousarray(a) for _, a in fields]
-        arr = (PluginField * len(fields))()
-        for i, ((n, _), a) in enumerate(zip(fields, keep)):
-            arr[i] = PluginField(n.encode(), a.ctypes.data_as(_V), 5 if a.dtype == np.int32 else 1, a.size)
+        # a field is (name, array) or (name, array, length) when the creator counts elements of a struct type (e.g. YoloKernel)
+        keep = [np.ascontiguousarray(f[1]) for f in fields]
+        arr = (PluginField * max(len(fields), 1))()
+        for i, (f, a) in enumerate(zip(fields, keep)):
+            arr[i] = PluginField(f[0].encode(), a.ctypes.data_as(_V), 5 if a.dtype == np.int32 else (1 if a.dtype == np.float32 else 8),
+                                 f[2] if len(f) > 2 else a.size)
         rc = creator.create(creator.self, name, arr, len(fields), ctypes.byref(v))
     assert rc == 0, "plugin construction failed"
     return v

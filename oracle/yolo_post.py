@@ -166,3 +166,35 @@ def gpu_postprocess_py(row, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
                     break
     rec[:, 6] = keep
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- YOLOv5 (anchor based)
+DET5_FLOATS = 38  # yolov5/src/types.h:11-16
+
+
+def v5_decode_c(inputs, classes, net_h, net_w, grids, anchors, max_out=1000, is_seg=False):
+    """yolov5/plugin/yololayer.cu:161-227, C restatement.  inputs: [B, 3*(5+classes(+32)), gh*gw] per level; grids [(gw, gh)]."""
+    ins = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+    B, n = ins[0].shape[0], len(ins)
+    out = np.zeros((B, 1 + max_out * DET5_FLOATS), dtype=np.float32)
+    ptrs = (ctypes.POINTER(ctypes.c_float) * n)(*[_fp(x) for x in ins])
+    gw = (ctypes.c_int * n)(*[g[0] for g in grids])
+    gh = (ctypes.c_int * n)(*[g[1] for g in grids])
+    an = np.ascontiguousarray(anchors, dtype=np.float32).reshape(n, 6)
+    lib().yolov5_decode_ref(ptrs, n, B, classes, net_h, net_w, gw, gh, _fp(an), max_out, 1 if is_seg else 0, _fp(out))
+    return out
+
+
+def v5_batch_nms_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """yolov5/src/postprocess.cpp:30-80, C restatement -> keep_idx [B, max_out], keep_cnt [B], keep_det [B, max_out, 6]."""
+    output = np.ascontiguousarray(output, dtype=np.float32)
+    B = output.shape[0]
+    keep_idx = np.full((B, max_out), -1, dtype=np.int32)
+    keep_cnt = np.zeros((B,), dtype=np.int32)
+    keep_det = np.zeros((B, max_out, 6), dtype=np.float32)
+    L = lib()
+    L.yolov5_nms_ref.restype = ctypes.c_int
+    for b in range(B):
+        keep_cnt[b] = L.yolov5_nms_ref(_fp(output[b]), max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+                                       keep_idx[b].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(keep_det[b]))
+    return keep_idx, keep_cnt, keep_det

@@ -114,6 +114,47 @@ def yolo_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45, with_de
     return keep_idx, keep_cnt, keep_det
 
 
+DET5_FLOATS = 38  # yolov5/src/types.h:11-16
+
+
+def yolov5_decode(inputs, classes, net_h, net_w, grids, anchors, max_out=1000, is_seg=False):
+    """Anchor-based YoloLayerPlugin::enqueue replacement (yolov5/plugin/yololayer.cu:161-233).
+    inputs: CUDA fp32 [B, 3*(5+classes(+32)), gh*gw] per level; grids: [(gw, gh)]; anchors: [n_levels][6].  -> [B, 1+max_out*38]"""
+    import numpy as np
+    import torch
+    L = lib()
+    n = len(inputs)
+    ins = [x.contiguous() for x in inputs]
+    B, dev = ins[0].shape[0], ins[0].device
+    arr = (ctypes.c_void_p * n)(*[x.data_ptr() for x in ins])
+    gw = (ctypes.c_int * n)(*[g[0] for g in grids])
+    gh = (ctypes.c_int * n)(*[g[1] for g in grids])
+    an = np.ascontiguousarray(anchors, dtype=np.float32).reshape(n, 6)
+    L.trtx_yolov5_decode_workspace.restype = ctypes.c_size_t
+    ws_bytes = L.trtx_yolov5_decode_workspace(B, gw, gh, n)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    out = torch.zeros((B, 1 + max_out * DET5_FLOATS), dtype=torch.float32, device=dev)
+    check(L.trtx_yolov5_decode(arr, n, B, classes, net_h, net_w, gw, gh, an.ctypes.data_as(ctypes.c_void_p), max_out, 1 if is_seg else 0,
+                               _p(out), _p(ws), ctypes.c_size_t(ws_bytes), _stream()), "trtx_yolov5_decode")
+    return out
+
+
+def yolov5_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """yolov5 batch_nms replacement (yolov5/src/postprocess.cpp:30-80). Returns keep_idx, keep_cnt, keep_det [B, max_out, 6]."""
+    import torch
+    L = lib()
+    B, dev = decode_out.shape[0], decode_out.device
+    keep_idx = torch.full((B, max_out), -1, dtype=torch.int32, device=dev)
+    keep_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    keep_det = torch.zeros((B, max_out, 6), dtype=torch.float32, device=dev)
+    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    ws_bytes = L.trtx_yolo_nms_workspace(B)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    check(L.trtx_yolov5_nms(_p(decode_out), B, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh), _p(keep_idx), _p(keep_cnt),
+                            _p(keep_det), _p(ws), ctypes.c_size_t(ws_bytes), _stream()), "trtx_yolov5_nms")
+    return keep_idx, keep_cnt, keep_det
+
+
 def yolo_postprocess_gpu(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
     """The reference's GPU post-processing mode "g" (yolov8/src/postprocess.cu:42-111): [B, 1 + max_out*7]."""
     import torch

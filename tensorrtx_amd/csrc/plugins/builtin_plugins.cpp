@@ -144,8 +144,143 @@ void yolo_fill(trtx_plugin_vtbl* v, YoloLayer* y) {
     v->destroy = yolo_destroy;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The anchor-based form of "YoloLayer_TRT"/"1" (yolov5/plugin/yololayer.{h,cu}; same registered name as the YOLOv8 plugin in
+// the reference, a different parameter set): creator fields "netinfo" = int32[5] {classes, W, H, maxOut, isSeg} and "kernels" =
+// YoloKernel[n] {int width, height; float anchors[6]} (yolov5/src/model.cpp:246-275, yololayer.cu:250-266); blob
+// int classCount, threadCount, kernelCount, netW, netH, maxOut, bool isSeg, YoloKernel[n] (yololayer.cu:49-89).
+struct Yolo5Kernel {
+    int width, height;
+    float anchors[6];
+};
+struct Yolo5Layer {
+    int class_count = 80, thread_count = 256, net_w = 640, net_h = 640, max_out = 1000;
+    bool seg = false;
+    std::vector<Yolo5Kernel> kernels;
+
+    std::vector<uint8_t> blob() const {
+        std::vector<uint8_t> b;
+        put(b, class_count);
+        put(b, thread_count);
+        put(b, (int)kernels.size());
+        put(b, net_w);
+        put(b, net_h);
+        put(b, max_out);
+        put(b, seg);
+        for (const auto& k : kernels) put(b, k);
+        return b;
+    }
+    static Yolo5Layer* from_blob(const void* data, size_t len) {
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        const uint8_t* end = p + len;
+        auto* y = new Yolo5Layer();
+        int nk = 0;
+        bool ok = get(p, end, y->class_count) && get(p, end, y->thread_count) && get(p, end, nk) && get(p, end, y->net_w) &&
+                  get(p, end, y->net_h) && get(p, end, y->max_out) && get(p, end, y->seg) && nk >= 1 && nk <= 8 &&
+                  (size_t)(end - p) == (size_t)nk * sizeof(Yolo5Kernel);
+        for (int i = 0; ok && i < nk; ++i) {
+            Yolo5Kernel k{};
+            ok = get(p, end, k) && k.width > 0 && k.height > 0;
+            y->kernels.push_back(k);
+        }
+        if (!ok || y->class_count < 1 || y->max_out < 1) {
+            delete y;
+            return nullptr;
+        }
+        return y;
+    }
+    void geometry(std::vector<int>* gw, std::vector<int>* gh, std::vector<float>* an) const {
+        for (const auto& k : kernels) {
+            gw->push_back(k.width);
+            gh->push_back(k.height);
+            an->insert(an->end(), k.anchors, k.anchors + 6);
+        }
+    }
+};
+
+void yolo5_fill(trtx_plugin_vtbl* v, Yolo5Layer* y);
+int32_t yolo5_output_dims(void* s, int32_t, const trtx_dims*, int32_t, trtx_dims* out) {
+    auto* y = static_cast<Yolo5Layer*>(s);
+    out->nb = 3;  // Dims3(maxOut * sizeof(Detection) / 4 + 1, 1, 1), yololayer.cu:101-105
+    out->d[0] = (int64_t)y->max_out * 38 + 1;
+    out->d[1] = 1;
+    out->d[2] = 1;
+    return 0;
+}
+int32_t yolo5_configure(void* s, const trtx_dims* in, int32_t nb_in, const trtx_dims*, int32_t, int32_t) {
+    auto* y = static_cast<Yolo5Layer*>(s);
+    if (nb_in != (int)y->kernels.size()) return 1;
+    const int info = 5 + y->class_count + (y->seg ? 32 : 0);
+    for (int i = 0; i < nb_in; ++i) {
+        int64_t vol = 1;
+        for (int k = 0; k < in[i].nb; ++k) vol *= in[i].d[k];
+        if (vol != (int64_t)3 * info * y->kernels[i].width * y->kernels[i].height) return 1;
+    }
+    return 0;
+}
+int32_t yolo5_initialize(void*) { return 0; }
+size_t yolo5_workspace(void* s, int32_t max_batch) {
+    auto* y = static_cast<Yolo5Layer*>(s);
+    std::vector<int> gw, gh;
+    std::vector<float> an;
+    y->geometry(&gw, &gh, &an);
+    return trtx_yolov5_decode_workspace(max_batch, gw.data(), gh.data(), (int)gw.size());
+}
+int32_t yolo5_enqueue(void* s, int32_t batch, const void* const* inputs, void* const* outputs, void* ws, trtx_stream_t stream) {
+    auto* y = static_cast<Yolo5Layer*>(s);
+    std::vector<int> gw, gh;
+    std::vector<float> an;
+    y->geometry(&gw, &gh, &an);
+    const size_t ws_bytes = trtx_yolov5_decode_workspace(batch, gw.data(), gh.data(), (int)gw.size());
+    return trtx_yolov5_decode(reinterpret_cast<const float* const*>(inputs), (int)gw.size(), batch, y->class_count, y->net_h, y->net_w,
+                              gw.data(), gh.data(), an.data(), y->max_out, y->seg ? 1 : 0, static_cast<float*>(outputs[0]), ws, ws_bytes,
+                              stream);
+}
+size_t yolo5_ser_size(void* s) { return static_cast<Yolo5Layer*>(s)->blob().size(); }
+void yolo5_serialize(void* s, void* buf) {
+    const auto b = static_cast<Yolo5Layer*>(s)->blob();
+    memcpy(buf, b.data(), b.size());
+}
+int32_t yolo5_clone(void* s, trtx_plugin_vtbl* out) {
+    yolo5_fill(out, new Yolo5Layer(*static_cast<Yolo5Layer*>(s)));
+    return 0;
+}
+void yolo5_destroy(void* s) { delete static_cast<Yolo5Layer*>(s); }
+void yolo5_fill(trtx_plugin_vtbl* v, Yolo5Layer* y) {
+    v->self = y;
+    v->get_nb_outputs = yolo_nb_outputs;
+    v->get_output_dims = yolo5_output_dims;
+    v->configure = yolo5_configure;
+    v->initialize = yolo5_initialize;
+    v->terminate = yolo_terminate;
+    v->workspace_size = yolo5_workspace;
+    v->enqueue = yolo5_enqueue;
+    v->serialization_size = yolo5_ser_size;
+    v->serialize = yolo5_serialize;
+    v->plugin_type = yolo_type;
+    v->plugin_version = yolo_version;
+    v->clone = yolo5_clone;
+    v->destroy = yolo5_destroy;
+}
+int32_t yolo5_create(const trtx_plugin_field* f, trtx_plugin_vtbl* out) {
+    if (!f[0].data || !f[1].data || f[0].length < 5 || f[1].length < 1 || f[1].length > 8) return 1;
+    const int* ni = static_cast<const int*>(f[0].data);
+    auto* y = new Yolo5Layer();
+    y->class_count = ni[0];
+    y->net_w = ni[1];
+    y->net_h = ni[2];
+    y->max_out = ni[3];
+    y->seg = ni[4] != 0;
+    y->kernels.resize(f[1].length);  // the reference counts this field in YoloKernel elements (model.cpp:272-273)
+    memcpy(y->kernels.data(), f[1].data, sizeof(Yolo5Kernel) * f[1].length);
+    yolo5_fill(out, y);
+    return 0;
+}
+
 // creator: one field "combinedInfo" = int32[9 + nStrides] (yolov8/src/block.cpp:267-293, yololayer.cu:339-360)
 int32_t yolo_create(void*, const char*, const trtx_plugin_field* f, int32_t nb, trtx_plugin_vtbl* out) {
+    // the anchor-based plugin shares the registered name: told apart by its two fields "netinfo" + "kernels"
+    if (nb == 2 && f && f[0].name && f[1].name && !strcmp(f[0].name, "netinfo") && !strcmp(f[1].name, "kernels")) return yolo5_create(f, out);
     if (nb != 1 || !f || !f[0].name || strcmp(f[0].name, "combinedInfo") != 0 || f[0].length < 10) return 1;
     const int* ci = static_cast<const int*>(f[0].data);
     auto* y = new YoloLayer();
@@ -164,8 +299,14 @@ int32_t yolo_create(void*, const char*, const trtx_plugin_field* f, int32_t nb, 
 }
 int32_t yolo_deserialize(void*, const char*, const void* data, size_t len, trtx_plugin_vtbl* out) {
     YoloLayer* y = YoloLayer::from_blob(data, len);
-    if (!y) return 1;
-    yolo_fill(out, y);
+    if (y) {
+        yolo_fill(out, y);
+        return 0;
+    }
+    // not the YOLOv8 layout (both parsers check the exact length): the anchor-based blob
+    Yolo5Layer* y5 = Yolo5Layer::from_blob(data, len);
+    if (!y5) return 1;
+    yolo5_fill(out, y5);
     return 0;
 }
 const char* yolo_creator_name(void*) { return "YoloLayer_TRT"; }
@@ -275,7 +416,9 @@ bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
 }
 
 // built-in plugins only enqueue kernels and stream-ordered memsets on the caller's stream: safe inside a stream capture
-bool builtin_plugin_capturable(const trtx_plugin_vtbl& v) { return v.enqueue == yolo_enqueue || v.enqueue == rdec_enqueue; }
+bool builtin_plugin_capturable(const trtx_plugin_vtbl& v) {
+    return v.enqueue == yolo_enqueue || v.enqueue == yolo5_enqueue || v.enqueue == rdec_enqueue;
+}
 
 void register_builtin_plugins(PluginRegistry& r) {
     trtx_creator_vtbl c{};

@@ -49,6 +49,21 @@ __device__ __forceinline__ float iou_xyxy(const float4 l, const float4 r) {
     return inter / uni;
 }
 
+// yolov5/src/postprocess.cpp:30-44: centre-format boxes (cx, cy, w, h), operation for operation.
+__device__ __forceinline__ float iou_cxcywh(const float4 l, const float4 r) {
+    const float a0 = l.x - l.z / 2.f, b0 = r.x - r.z / 2.f;
+    const float a1 = l.x + l.z / 2.f, b1 = r.x + r.z / 2.f;
+    const float a2 = l.y - l.w / 2.f, b2 = r.y - r.w / 2.f;
+    const float a3 = l.y + l.w / 2.f, b3 = r.y + r.w / 2.f;
+    const float ib0 = a0 < b0 ? b0 : a0;  // max
+    const float ib1 = b1 < a1 ? b1 : a1;  // min
+    const float ib2 = a2 < b2 ? b2 : a2;
+    const float ib3 = b3 < a3 ? b3 : a3;
+    if (ib2 > ib3 || ib0 > ib1) return 0.0f;
+    const float inter = (ib1 - ib0) * (ib3 - ib2);
+    return inter / (l.z * l.w + r.z * r.w - inter);
+}
+
 // workspace layout (per batch; every array is [batch][kCap] unless noted)
 struct NmsWs {
     float4* box;     // sorted boxes
@@ -80,6 +95,10 @@ inline NmsWs nms_ws_carve(void* base, int batch) {
     return w;
 }
 
+// MODE 0: YOLOv8 host nms() (postprocess.cpp:94-121): xyxy boxes, "conf <= thresh || isnan" dropped, ties by bbox[0] then slot.
+// MODE 1: YOLOv5 host nms() (yolov5/src/postprocess.cpp:50-73): centre-format boxes, "conf <= thresh" dropped (a NaN stays),
+//         cmp() orders by conf only -> ties by slot (the reference's unstable std::sort leaves them unspecified).
+template <int MODE>
 __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __restrict__ decode, int out_elem, int det_floats,
                                                              int max_out, float conf_thresh, NmsWs ws) {
     __shared__ uint64_t s_hi[kCap];
@@ -97,9 +116,10 @@ __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __rest
     if (tid < count) {
         const float* det = img + 1 + (size_t)tid * det_floats;
         const float conf = det[4];
-        if (conf > conf_thresh) {  // false for NaN, as "conf <= thresh || isnan" drops (postprocess.cpp:99)
+        // MODE 0: false for NaN, as "conf <= thresh || isnan" drops (postprocess.cpp:99); MODE 1: only "conf <= thresh" drops
+        if (MODE == 0 ? (conf > conf_thresh) : !(conf <= conf_thresh)) {
             hi = ((uint64_t)trtx::ord_f32(det[5]) << 32) | (uint32_t)~trtx::ord_f32(conf);
-            lo = ((uint64_t)trtx::ord_f32(det[0]) << 32) | (uint32_t)tid;
+            lo = ((uint64_t)(MODE == 0 ? trtx::ord_f32(det[0]) : 0u) << 32) | (uint32_t)tid;
         }
     }
     // bitonic sort, ascending, 1024 keys
@@ -154,6 +174,7 @@ __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __rest
 }
 
 // grid (row block, image); wave c of the workgroup computes tile (c, r) for c <= r, the other waves leave at once
+template <int MODE>
 __global__ __launch_bounds__(kCap) void yolo_nms_mask_kernel(NmsWs ws, float nms_thresh) {
     const int r = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -174,7 +195,8 @@ __global__ __launch_bounds__(kCap) void yolo_nms_mask_kernel(NmsWs ws, float nms
             const float my_cls = ws.cls[base + i];
             const int kend = (c == r) ? lane : 64;  // only earlier boxes suppress
             for (int k = 0; k < kend; ++k)
-                if (s_cls[c][k] == my_cls && iou_xyxy(s_box[c][k], mine) > nms_thresh) bits |= 1ull << k;
+                if (s_cls[c][k] == my_cls && (MODE == 0 ? iou_xyxy(s_box[c][k], mine) : iou_cxcywh(s_box[c][k], mine)) > nms_thresh)
+                    bits |= 1ull << k;
         }
     }
     ws.mask[(base + i) * kBlocks + c] = bits;
@@ -336,18 +358,34 @@ extern "C" size_t trtx_yolo_nms_workspace(int batch) {
     return batch < 1 ? 0 : nms_ws_bytes(batch);
 }
 
-extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
-                                 int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace,
-                                 size_t workspace_bytes, hipStream_t stream) {
+namespace {
+template <int MODE>
+int32_t run_nms(const float* decode_out, int batch, int max_out, int det_floats, float conf_thresh, float nms_thresh, int32_t* keep_idx,
+                int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes, hipStream_t stream, const char* what) {
     if (!decode_out || !keep_idx || !keep_cnt || batch < 1 || max_out < 1) return TRTX_ERR_INVALID;
     if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < nms_ws_bytes(batch)) return TRTX_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return TRTX_ERR_INVALID;
     const NmsWs ws = nms_ws_carve(workspace, batch);
-    const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
-    hipLaunchKernelGGL(yolo_nms_sort_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, trtx::kYoloDetFloats,
-                       max_out, conf_thresh, ws);
-    hipLaunchKernelGGL(yolo_nms_mask_kernel, dim3(kBlocks, batch), dim3(kCap), 0, stream, ws, nms_thresh);
+    const int out_elem = 1 + max_out * det_floats;
+    hipLaunchKernelGGL(yolo_nms_sort_kernel<MODE>, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, det_floats, max_out,
+                       conf_thresh, ws);
+    hipLaunchKernelGGL(yolo_nms_mask_kernel<MODE>, dim3(kBlocks, batch), dim3(kCap), 0, stream, ws, nms_thresh);
     hipLaunchKernelGGL(yolo_nms_scan_kernel, dim3(batch), dim3(kCap), 0, stream, ws, max_out, keep_idx, keep_cnt, keep_det);
-    return trtx::check_launch("trtx_yolo_nms");
+    return trtx::check_launch(what);
+}
+}  // namespace
+
+extern "C" int32_t trtx_yolo_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                 int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+    return run_nms<0>(decode_out, batch, max_out, trtx::kYoloDetFloats, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, workspace,
+                      workspace_bytes, stream, "trtx_yolo_nms");
+}
+
+extern "C" int32_t trtx_yolov5_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                   int32_t* keep_idx, int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes,
+                                   hipStream_t stream) {
+    return run_nms<1>(decode_out, batch, max_out, 38, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, workspace, workspace_bytes,
+                      stream, "trtx_yolov5_nms");
 }

@@ -172,3 +172,34 @@ def yolov8n_state(seed=0, num_class=80):
         if lv == 0:
             sd["model.22.dfl.conv.weight"] = torch.arange(16.0).reshape(1, 16, 1, 1)
     return OrderedDict((k, v.numpy()) for k, v in sd.items())
+
+
+YOLOV5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yolov5s P3/P4/P5 (ultralytics yaml)
+
+
+def yolov5_head_tensors(batch, classes=80, net_h=640, net_w=640, strides=(8, 16, 32), objects=(40, 160), seed=0, seg=False):
+    """Planted-object inputs of the anchor-based YoloLayer: list of [B, 3*(5+classes(+32)), gh*gw] fp32 (channel-major, as the
+    detect convolutions emit them, yolov5/src/model.cpp:331-343).  Objectness logits ~ N(-6, 1.5^2) with `objects` planted
+    anchors per image (obj +2..+6, one class +3..+7, small clusters of neighbouring cells so that NMS has work)."""
+    rng = np.random.default_rng(seed)
+    info = 5 + classes + (32 if seg else 0)
+    outs = []
+    for s in strides:
+        gh, gw = net_h // s, net_w // s
+        x = rng.normal(0.0, 1.0, size=(batch, 3, info, gh * gw)).astype(np.float32)
+        x[:, :, 4] = rng.normal(-6.0, 1.5, size=(batch, 3, gh * gw))
+        x[:, :, 5:5 + classes] = rng.normal(-4.0, 1.5, size=(batch, 3, classes, gh * gw))
+        outs.append(x)
+    for b in range(batch):
+        for _ in range(int(rng.integers(*objects))):
+            l = int(rng.integers(0, len(strides)))
+            gh, gw = net_h // strides[l], net_w // strides[l]
+            cy, cx, k, c = int(rng.integers(0, gh)), int(rng.integers(0, gw)), int(rng.integers(0, 3)), int(rng.integers(0, classes))
+            for dy, dx in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                if rng.uniform() < 0.35 and (dy, dx) != (0, 0):
+                    continue
+                e = min(cy + dy, gh - 1) * gw + min(cx + dx, gw - 1)
+                outs[l][b, k, 4, e] = rng.uniform(2.0, 6.0)
+                outs[l][b, k, 5 + c, e] = rng.uniform(3.0, 7.0)
+                outs[l][b, k, 0:4, e] = rng.normal(0, 0.4, size=4)
+    return [x.reshape(batch, 3 * info, -1) for x in outs]

@@ -30,6 +30,9 @@ def host(out_dir):
     for name, rows in hc.retina_cases().items():
         for b, row in enumerate(rows):
             res[f"retina/{name}/{b}"] = ref.retina_nms(row, 0.4)
+    for name, rows in hc.yolov5_cases().items():
+        for b, row in enumerate(rows):
+            res[f"yolov5/{name}/{b}"] = ref.yolov5_nms(row, 0.5, 0.45)[:, :6]
     np.savez_compressed(os.path.join(out_dir, "ref_host_nms.npz"), **res)
     print("wrote", len(res), "arrays")
 

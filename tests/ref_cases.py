@@ -73,6 +73,36 @@ def yolov8_oracle(c):
     return [yp.decode_c(c.inputs, 80, c.size, c.size, [8, 16, 32])]
 
 
+# ------------------------------------------------------------------------------------------------------ yolov5 (anchor based)
+YOLO5_KERNEL = np.dtype([("width", "<i4"), ("height", "<i4"), ("anchors", "<f4", 6)])  # YoloKernel, yolov5/src/types.h:5-9
+
+
+def yolov5_decode_case(batch=2, seed=12, size=640, seg=False):
+    ins = synth.yolov5_head_tensors(batch, net_h=size, net_w=size, seed=seed, seg=seg)
+    grids = [(size // s, size // s) for s in (8, 16, 32)]
+    kern = np.zeros(3, dtype=YOLO5_KERNEL)
+    for i, (gw, gh) in enumerate(grids):
+        kern[i] = (gw, gh, synth.YOLOV5_ANCHORS[i])
+    netinfo = np.array([80, size, size, 1000, 1 if seg else 0], dtype=np.int32)  # yolov5/src/model.cpp:250-256
+    keepf = 38 if seg else 6
+    c = Case(f"yolov5_decode_b{batch}_{size}" + ("_seg" if seg else ""), "yolov5_plugin", "YoloLayer_TRT", batch, ins, [(batch, 1 + 1000 * 38)],
+             fields=[("netinfo", netinfo), ("kernels", kern.view(np.uint8), 3)],
+             canon=lambda outs: canon_records(np.asarray(outs[0]), 38, keepf), rtol=2e-6, atol=2e-6)
+    c.p = (size, grids, seg)
+    return c
+
+
+def yolov5_product(c, dev):
+    from tensorrtx_amd import capi
+    size, grids, seg = c.p
+    return [capi.yolov5_decode([_t(x, dev) for x in c.inputs], 80, size, size, grids, synth.YOLOV5_ANCHORS, 1000, seg).cpu().numpy()]
+
+
+def yolov5_oracle(c):
+    size, grids, seg = c.p
+    return [yp.v5_decode_c(c.inputs, 80, size, size, grids, synth.YOLOV5_ANCHORS, 1000, seg)]
+
+
 # ------------------------------------------------------------------------------------------------------ retinaface
 def retina_decode_case(batch=1, seed=13):
     H, W = 480, 640  # compile-time INPUT_H / INPUT_W of the reference plugin (retinaface/decode.h:16-17)
@@ -262,6 +292,8 @@ def all_cases():
         (batched_nms_case(1, class_mod=2, seed=17), batched_nms_product, batched_nms_oracle),
         (batched_nms_case(2, class_mod=2, seed=18), batched_nms_product, batched_nms_oracle),
         (mask_case(), mask_product, mask_oracle),
+        (yolov5_decode_case(), yolov5_product, yolov5_oracle),
+        (yolov5_decode_case(batch=1, seed=14, size=320, seg=True), yolov5_product, yolov5_oracle),
     ]
 
 

@@ -59,3 +59,22 @@ def retina_cases():
     hand[1, 0] = 6
     cases["hand"] = hand
     return cases
+
+
+def yolov5_cases():
+    """Decode buffers of the anchor-based YoloLayer (38-float records, centre-format boxes) for yolov5/src/postprocess.cpp:30-80."""
+    grids = [(80, 80), (40, 40), (20, 20)]
+    cases = {"seeded": yp.v5_decode_c(synth.yolov5_head_tensors(3, seed=22), 80, 640, 640, grids, synth.YOLOV5_ANCHORS)}
+
+    def rows(dets, max_out=1000):
+        row = np.zeros((1, 1 + max_out * 38), np.float32)
+        row[0, 0] = len(dets)
+        for i, d in enumerate(dets):
+            row[0, 1 + i * 38:1 + i * 38 + 6] = d
+        return row
+    half = np.float32(0.5)
+    cases["thresholds_empty"] = np.concatenate([rows([]), rows([[50, 50, 20, 20, half, 1], [150, 50, 20, 20, np.nextafter(half, np.float32(1)), 1],
+                                                                [250, 50, 20, 20, 0.9, 2]])])
+    cases["chain_degenerate"] = rows([[50, 50, 100, 100, 0.9, 3], [90, 50, 100, 100, 0.8, 3], [145, 50, 100, 100, 0.7, 3],
+                                      [90, 50, 100, 100, 0.85, 4], [300, 300, 0, 0, 0.95, 3], [300, 300, 0, 0, 0.6, 3]])
+    return cases

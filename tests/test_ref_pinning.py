@@ -64,6 +64,18 @@ def test_oracle_retina_nms_equals_reference_outputs():
             assert np.array_equal(rec, want), (name, b)
 
 
+def test_oracle_yolov5_nms_equals_reference_outputs():
+    """oracle/csrc/yolov5_post_ref.c vs what yolov5/src/postprocess.cpp:50-73 itself returned (committed golden)."""
+    z = np.load(os.path.join(GOLD, "ref_host_nms.npz"))
+    for name, rows in hc.yolov5_cases().items():
+        ki, kc, kd = yp.v5_batch_nms_c(rows)
+        for b in range(rows.shape[0]):
+            want = z[f"yolov5/{name}/{b}"]
+            assert kc[b] == len(want), (name, b, kc[b], len(want))
+            assert np.array_equal(kd[b, :kc[b]], want, equal_nan=True), (name, b)
+            assert np.array_equal(rows[b, 1:].reshape(-1, 38)[ki[b, :kc[b]], :6], want, equal_nan=True)
+
+
 def test_reference_host_code_reproduces_the_goldens():
     """The committed fixture really is the reference's output: rerun libref_host.so (built from /root/reference)."""
     _need_ref("libref_host.so")
@@ -76,6 +88,9 @@ def test_reference_host_code_reproduces_the_goldens():
     for name, rows in hc.retina_cases().items():
         for b in range(rows.shape[0]):
             assert np.array_equal(ref.retina_nms(rows[b]), z[f"retina/{name}/{b}"])
+    for name, rows in hc.yolov5_cases().items():
+        for b in range(rows.shape[0]):
+            assert np.array_equal(ref.yolov5_nms(rows[b])[:, :6], z[f"yolov5/{name}/{b}"], equal_nan=True)
 
 
 def test_reference_yolov8_nms_random_sweep_against_oracle():
