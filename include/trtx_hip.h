@@ -159,6 +159,12 @@ int32_t trtx_rpn_nms(int batch, const float* scores, const float* boxes, int pre
 int32_t trtx_roi_align(int batch, const float* boxes, const float* features, int pooler_resolution, float spatial_scale,
                        int sampling_ratio, int num_proposals, int channels, int feature_h, int feature_w, float* out,
                        trtx_stream_t stream);
+/* The same operator on the engine's native layout: features NHWC fp16 [batch][fh][fw][ld_in] (channels % 8 == 0), out NHWC fp16
+ * [batch * P][res][res][ld_out] - what the RoI head's convolutions consume.  Used by the fp16 engine in place of the fp32
+ * plugin edge + two layout passes. */
+int32_t trtx_roi_align_nhwc_f16(int batch, const float* boxes, const void* features, int ld_in, int pooler_resolution,
+                                float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
+                                int feature_w, void* out, int ld_out, trtx_stream_t stream);
 /* predictorDecode (rcnn/PredictorDecode.cu:24-110): sort N*C scores, top N (n, cls) pairs, weighted delta decode.
  * The reference clips y2 with image_width (line 99); kept for parity. */
 size_t trtx_predictor_decode_workspace(int batch, int num_boxes, int num_classes);

@@ -112,6 +112,96 @@ int32_t sort_keys(uint64_t* keys, int batch, int n_pad, hipStream_t s) {
     return trtx::check_launch("sort_keys");
 }
 
+// ---------------------------------------------------------------------------------------------- top-k selection
+// RpnDecode keeps the top_n = 6000 of 63 000 objectness logits (rcnn/RpnDecode.cu:71-88 sorts all of them with cub).  Here one
+// workgroup per image finds the top_n-th key with a 3-pass MSD radix select over the 32-bit order-preserving score keys
+// (11 + 11 + 10 bits, histograms in LDS, the scores are read three times from L2), then compacts the selected elements IN INDEX
+// ORDER (ties of the pivot score go to the lowest indices, which is what the stable descending sort would keep), emitting the
+// same 64-bit (key, index) words as make_keys_kernel.  Only those <= top_n keys (padded to a power of two) are sorted.
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, int n, int top_n, int n_sel_pad,
+                                                           uint64_t* __restrict__ sel_keys) {
+    __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_prefix, s_remaining;
+    __shared__ int s_wsel[16], s_weq[16];
+    __shared__ int s_base_sel, s_base_eq;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = scores + (size_t)b * n;
+    if (tid == 0) {
+        s_prefix = 0;
+        s_remaining = (unsigned)top_n;
+    }
+    const int shifts[3] = {21, 10, 0};
+    const int bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const int hi_shift = pass == 0 ? 32 : shifts[pass - 1];
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned key = ~ord_f32(sc[i]);
+            if (pass > 0 && (key >> hi_shift) != prefix) continue;
+            atomicAdd(&s_hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1u)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = s_remaining, cum = 0;
+            int bin = 0;
+            const int nb = 1 << bits[pass];
+            for (; bin < nb; ++bin) {
+                if (cum + s_hist[bin] >= rem) break;
+                cum += s_hist[bin];
+            }
+            s_prefix = (prefix << bits[pass]) | (unsigned)bin;
+            s_remaining = rem - cum;  // how many of the elements inside this bin are still to be taken
+        }
+        __syncthreads();
+    }
+    const unsigned pivot = s_prefix;      // the top_n-th smallest key (32-bit score part)
+    const int take_eq = (int)s_remaining;  // elements with key == pivot to keep, lowest indices first
+    if (tid == 0) {
+        s_base_sel = 0;
+        s_base_eq = 0;
+    }
+    __syncthreads();
+    uint64_t* dst = sel_keys + (size_t)b * n_sel_pad;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        unsigned key = 0xffffffffu;
+        bool eq = false, less = false;
+        if (i < n) {
+            key = ~ord_f32(sc[i]);
+            eq = key == pivot;
+            less = key < pivot;
+        }
+        const unsigned long long meq = __ballot(eq);
+        const int eq_in_wave = __popcll(meq & ((1ull << lane) - 1ull));
+        if (lane == 0) s_weq[wave] = __popcll(meq);
+        __syncthreads();
+        int eq_rank = s_base_eq + eq_in_wave;
+        for (int w = 0; w < wave; ++w) eq_rank += s_weq[w];
+        const bool sel = less || (eq && eq_rank < take_eq);
+        const unsigned long long msel = __ballot(sel);
+        const int sel_in_wave = __popcll(msel & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wsel[wave] = __popcll(msel);
+        __syncthreads();
+        int pos = s_base_sel + sel_in_wave;
+        int tot_sel = 0, tot_eq = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) pos += s_wsel[w];
+            tot_sel += s_wsel[w];
+            tot_eq += s_weq[w];
+        }
+        if (sel) dst[pos] = ((uint64_t)key << 32) | (uint32_t)i;
+        __syncthreads();
+        if (tid == 0) {
+            s_base_sel += tot_sel;
+            s_base_eq += tot_eq;
+        }
+        __syncthreads();
+    }
+    for (int i = top_n + tid; i < n_sel_pad; i += 1024) dst[i] = ~0ull;
+}
+
 // keys[b][i] = (~ord(score) << 32) | i for i < n (descending score, ascending index), ~0 for padding
 __global__ void make_keys_kernel(const float* __restrict__ scores, int n, int n_pad, uint64_t* __restrict__ keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -668,69 +758,6 @@ __global__ void gather_after_nms_kernel(const uint64_t* __restrict__ keys2, int 
     if (out_classes) out_classes[(size_t)b * n_out + d] = cl;
 }
 
-// RoiAlign.cu:29-80
-__device__ float bilinear_interpolate(const float* __restrict__ data, int height, int width, float y, float x) {
-    if (y < -1.0 || y > height || x < -1.0 || x > width) return 0;
-    if (y <= 0) y = 0;
-    if (x <= 0) x = 0;
-    int y_low = (int)y, x_low = (int)x, y_high, x_high;
-    if (y_low >= height - 1) {
-        y_high = y_low = height - 1;
-        y = (float)y_low;
-    } else {
-        y_high = y_low + 1;
-    }
-    if (x_low >= width - 1) {
-        x_high = x_low = width - 1;
-        x = (float)x_low;
-    } else {
-        x_high = x_low + 1;
-    }
-    const float ly = y - y_low, lx = x - x_low;
-    const float hy = (float)(1. - ly), hx = (float)(1. - lx);
-    const float v1 = data[y_low * width + x_low], v2 = data[y_low * width + x_high];
-    const float v3 = data[y_high * width + x_low], v4 = data[y_high * width + x_high];
-    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-}
-
-// RoiAlign.cu:83-153; one thread per output element (n, c, ph, pw); pw fastest => coalesced stores
-__global__ void roi_align_kernel(long nthreads, const float* __restrict__ features, float spatial_scale, int channels,
-                                 int height, int width, int res, int sampling_ratio, const float* __restrict__ rois,
-                                 int num_proposals, float* __restrict__ top) {
-    for (long index = blockIdx.x * (long)blockDim.x + threadIdx.x; index < nthreads; index += (long)blockDim.x * gridDim.x) {
-        const int pw = (int)(index % res);
-        const int ph = (int)((index / res) % res);
-        const int c = (int)((index / res / res) % channels);
-        const long n = index / res / res / channels;  // proposal index across the batch
-        const long b = n / num_proposals;
-        const float* r = rois + n * 4;
-        const float roi_offset = 0.5f;
-        const float roi_start_w = r[0] * spatial_scale - roi_offset;
-        const float roi_start_h = r[1] * spatial_scale - roi_offset;
-        const float roi_end_w = r[2] * spatial_scale - roi_offset;
-        const float roi_end_h = r[3] * spatial_scale - roi_offset;
-        const float roi_width = roi_end_w - roi_start_w;
-        const float roi_height = roi_end_h - roi_start_h;
-        const float bin_size_h = roi_height / (float)res;
-        const float bin_size_w = roi_width / (float)res;
-        const float* plane = features + ((size_t)b * channels + c) * height * width;
-        const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / res);
-        const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / res);
-        const float count = grid_h * grid_w;
-        float acc = 0.f;
-        for (int iy = 0; iy < grid_h; iy++) {
-            const float y = roi_start_h + ph * bin_size_h + (float)(iy + .5f) * bin_size_h / (float)grid_h;
-            for (int ix = 0; ix < grid_w; ix++) {
-                const float x = roi_start_w + pw * bin_size_w + (float)(ix + .5f) * bin_size_w / (float)grid_w;
-                acc += bilinear_interpolate(plane, height, width, y, x);
-            }
-        }
-        acc /= count;
-        top[index] = acc;
-    }
-}
-
 // PredictorDecode.cu:79-106
 __global__ void predictor_decode_kernel(const int* __restrict__ order, int n_order, const float* __restrict__ scores,
                                         const float* __restrict__ deltas, const float* __restrict__ proposals, int num_boxes,
@@ -875,6 +902,7 @@ extern "C" int32_t trtx_retina_nms(const float* decode_out, int batch, int net_h
 
 // ---- rpnDecode (RpnDecode.cu:27-143)
 extern "C" size_t trtx_rpn_decode_workspace(int batch, int num_anchors, int height, int width) {
+    // sized for the worst case top_n >= n (keys of every anchor); with top_n < n only next_pow2(top_n) of them are used
     const size_t n = (size_t)num_anchors * height * width, n_pad = next_pow2((int)n);
     return align_up(batch * n_pad * 8, 256) + align_up(batch * n_pad * 4, 256) + align_up((size_t)num_anchors * 16, 256);
 }
@@ -886,7 +914,8 @@ extern "C" int32_t trtx_rpn_decode(int batch, const float* scores, const float* 
     if (!scores || !deltas || !anchors_host || !out_scores || !out_boxes || !workspace || batch < 1 || top_n < 1)
         return TRTX_ERR_INVALID;
     const int n = num_anchors * height * width;
-    const int n_pad = next_pow2(n);
+    // keys that take part in the sort: the top_n selected ones (radix select), or all of them when nothing is dropped
+    const int n_pad = n > top_n ? next_pow2(top_n) : next_pow2(n);
     Carver c{static_cast<char*>(workspace), workspace_bytes};
     uint64_t* keys = c.take<uint64_t>((size_t)batch * n_pad);
     int* order = c.take<int>((size_t)batch * n_pad);
@@ -896,7 +925,7 @@ extern "C" int32_t trtx_rpn_decode(int batch, const float* scores, const float* 
     int num = n;
     const int* order_arg = nullptr;
     if (n > top_n) {
-        hipLaunchKernelGGL(make_keys_kernel, grid1(n_pad, batch), dim3(256), 0, stream, scores, n, n_pad, keys);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, stream, scores, n, top_n, n_pad, keys);
         const int32_t st = sort_keys(keys, batch, n_pad, stream);
         if (st != TRTX_OK) return st;
         hipLaunchKernelGGL(unpack_keys_kernel, grid1(n_pad, batch), dim3(256), 0, stream, keys, n_pad, scores, n, n_pad, order,
@@ -983,18 +1012,6 @@ extern "C" int32_t trtx_batched_nms(int nms_method, int batch, const float* scor
 }
 
 // roiAlign (RoiAlign.cu:155-182)
-extern "C" int32_t trtx_roi_align(int batch, const float* boxes, const float* features, int pooler_resolution,
-                                  float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
-                                  int feature_w, float* out, hipStream_t stream) {
-    if (!boxes || !features || !out || batch < 1 || pooler_resolution < 1) return TRTX_ERR_INVALID;
-    const long nthreads = (long)batch * num_proposals * channels * pooler_resolution * pooler_resolution;
-    long blocks = (nthreads + 255) / 256;
-    if (blocks > 256L * 64) blocks = 256L * 64;
-    hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, nthreads, features, spatial_scale, channels,
-                       feature_h, feature_w, pooler_resolution, sampling_ratio, boxes, num_proposals, out);
-    return trtx::check_launch("trtx_roi_align");
-}
-
 // predictorDecode (PredictorDecode.cu:24-110)
 extern "C" size_t trtx_predictor_decode_workspace(int batch, int num_boxes, int num_classes) {
     const size_t n_pad = next_pow2(num_boxes * num_classes);
@@ -1010,12 +1027,18 @@ extern "C" int32_t trtx_predictor_decode(int batch, const float* scores, const f
         batch < 1)
         return TRTX_ERR_INVALID;
     const int n = num_boxes * num_classes;
-    const int n_pad = next_pow2(n);
+    // only the best num_boxes of the num_boxes * num_classes (box, class) scores survive (PredictorDecode.cu:65-78 sorts all of
+    // them): radix select first, sort just the survivors
+    const bool select = n > num_boxes && num_classes > 1;
+    const int n_pad = select ? next_pow2(num_boxes) : next_pow2(n);
     Carver c{static_cast<char*>(workspace), workspace_bytes};
     uint64_t* keys = c.take<uint64_t>((size_t)batch * n_pad);
     int* order = c.take<int>((size_t)batch * n_pad);
     if (!c.ok) return TRTX_ERR_WORKSPACE;
-    hipLaunchKernelGGL(make_keys_kernel, grid1(n_pad, batch), dim3(256), 0, stream, scores, n, n_pad, keys);
+    if (select)
+        hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, stream, scores, n, num_boxes, n_pad, keys);
+    else
+        hipLaunchKernelGGL(make_keys_kernel, grid1(n_pad, batch), dim3(256), 0, stream, scores, n, n_pad, keys);
     const int32_t st = sort_keys(keys, batch, n_pad, stream);
     if (st != TRTX_OK) return st;
     hipLaunchKernelGGL(unpack_keys_kernel, grid1(n_pad, batch), dim3(256), 0, stream, keys, n_pad, scores, n, n_pad, order,

@@ -277,6 +277,12 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                                                 static_cast<char*>(c->d_arena) + op.ws_off, op.ws_bytes, stream);
                 break;
             }
+            case OP_ROI_ALIGN: {
+                const PTensor& ft = plan.tensors[op.in[1]];
+                st = trtx_roi_align_nhwc_f16(batch, static_cast<const float*>(R.ptr(op.in[0])), R.ptr(op.in[1]), ft.ld, op.i[0], op.f[0], op.i[1],
+                                             op.i[2], ft.C, ft.H, ft.W, R.ptr(op.out[0]), to.ld, stream);
+                break;
+            }
             case OP_COPY_LIN: {
                 const size_t bytes = (size_t)(to.batched ? batch : 1) * to.dims.volume() * 4;
                 if (hipMemcpyAsync(R.ptr(op.out[0]), R.ptr(op.in[0]), bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)

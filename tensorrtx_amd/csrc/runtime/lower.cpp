@@ -1,5 +1,6 @@
 // Network -> Plan lowering.  See plan.h for what this stands in for.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -15,8 +16,8 @@ const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
                               "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head",
-                              "pool_chain", "depth_to_space"};
-    return (k >= 0 && k <= OP_D2S) ? n[k] : "?";
+                              "pool_chain", "depth_to_space", "roi_align"};
+    return (k >= 0 && k <= OP_ROI_ALIGN) ? n[k] : "?";
 }
 
 namespace {
@@ -748,6 +749,36 @@ struct Lowerer {
                 return true;
             }
             case L_PLUGIN: {
+                // "RoiAlign" (rcnn/RoiAlignPlugin.h; blob int res, float scale, int ratio, int nProp, int C, int fh, int fw) in an fp16
+                // engine whose feature map already lives in NHWC fp16: run the engine-native kernel on it and emit the NHWC
+                // [P][res][res][C] tensor the res5 convolutions read, instead of fp32 LINEAR in / out plus two layout passes
+                // (803 MB fp32 written, re-read and re-written as fp16 per image at C5).  Same detectron2 ROIAlign(aligned=True)
+                // arithmetic as the plugin (pinned on the reference's kernel in tests/test_ref_pinning.py); fp32 engines and
+                // TRTX_ROIALIGN_PLUGIN=1 keep the plugin route.
+                static const bool keep_plugin = getenv("TRTX_ROIALIGN_PLUGIN") != nullptr;
+                if (!keep_plugin && dt == DT_F16 && !net.explicit_batch && l.plugin && l.plugin->type() == "RoiAlign" && l.plugin->version() == "1" &&
+                    l.inputs.size() == 2 && l.outputs.size() == 1 && plan.tensors[pt_of[l.inputs[1]]].layout == LAY_NHWC) {
+                    const std::vector<uint8_t> blob = l.plugin->serialize();
+                    const PTensor& feat = plan.tensors[pt_of[l.inputs[1]]];
+                    int32_t iv[7];
+                    if (blob.size() == 28) {
+                        memcpy(iv, blob.data(), 28);
+                        float scale;
+                        memcpy(&scale, blob.data() + 4, 4);
+                        const Dims& od = net.tensors[l.outputs[0]].dims;
+                        if (iv[0] > 0 && iv[3] > 0 && iv[4] == feat.C && iv[5] == feat.H && iv[6] == feat.W && feat.nmul == 1 && feat.C % 8 == 0 &&
+                            od.nb == 4 && od.d[0] == iv[3] && od.d[1] == iv[4] && od.d[2] == iv[0] && od.d[3] == iv[0]) {
+                            const int boxes = need_lin(l.inputs[0]);
+                            const int out = new_tensor(l.outputs[0], od, LAY_NHWC, true);
+                            POp& op = add_op(OP_ROI_ALIGN, l.name + " [native NHWC]", {boxes, pt_of[l.inputs[1]]}, {out});
+                            op.i[0] = iv[0]; op.i[1] = iv[2]; op.i[2] = iv[3];
+                            op.f[0] = scale;
+                            op.bytes = 2.0 * (double)od.volume() + 2.0 * (double)feat.C * feat.H * feat.W;
+                            pt_of[l.outputs[0]] = out;
+                            return true;
+                        }
+                    }
+                }
                 std::vector<int> ins, outs;
                 for (int t : l.inputs) ins.push_back(need_lin(t));
                 for (size_t s = 0; s < l.outputs.size(); ++s) {

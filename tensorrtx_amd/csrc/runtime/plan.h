@@ -43,6 +43,7 @@ enum OpKind : int {
     OP_YOLO_HEAD,     // fused DFL + YoloLayer decode on the NHWC head tensors
     OP_POOL_CHAIN,    // three chained k x k stride-1 'same' max-pools (SPPF) in one launch, three outputs
     OP_D2S,           // depth-to-space: [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c] (second half of a kernel == stride deconvolution)
+    OP_ROI_ALIGN,     // detectron2 ROIAlign on the NHWC feature map, NHWC [P][res][res][C] out (fused form of the "RoiAlign" plugin)
 };
 const char* op_kind_name(int k);
 

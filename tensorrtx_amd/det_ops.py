@@ -81,6 +81,18 @@ def roi_align(boxes, feats, res, scale, sampling_ratio=0):
     return out
 
 
+def roi_align_nhwc_f16(boxes, feats_nhwc, res, scale, sampling_ratio=0):
+    """Engine-native RoIAlign: feats_nhwc CUDA fp16 [B, fh, fw, C] -> fp16 [B*P, res, res, C]."""
+    import torch
+    L = _L()
+    B, P = boxes.shape[:2]
+    fh, fw, C = feats_nhwc.shape[1:]
+    out = torch.empty((B * P, res, res, C), dtype=torch.float16, device=boxes.device)
+    check(L.trtx_roi_align_nhwc_f16(B, _p(boxes), _p(feats_nhwc), feats_nhwc.stride(2), res, ctypes.c_float(scale), sampling_ratio, P, C, fh, fw,
+                                    _p(out), C, _stream()), "trtx_roi_align_nhwc_f16")
+    return out
+
+
 def predictor_decode(scores, deltas, proposals, img_h, img_w, weights=(10.0, 10.0, 5.0, 5.0)):
     import numpy as np
     import torch

@@ -113,6 +113,41 @@ def test_roi_align(gpu):
     assert np.array_equal(got2, ref2)
 
 
+def test_roi_align_full_size_and_degenerate_boxes(gpu):
+    """C5 geometry (1000 proposals on a 50x84 map, 64 of the 1024 channels) + boxes outside / larger than the image, zero-area
+    and inverted boxes (count = 0 -> NaN, as the reference computes 0/0)."""
+    rng = np.random.default_rng(11)
+    feats = rng.normal(size=(1, 64, 50, 84)).astype(np.float32)
+    x1 = rng.uniform(0, 1300, size=(1, 1000)); y1 = rng.uniform(0, 780, size=(1, 1000))
+    boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(2, 900, size=(1, 1000)), 1333), np.minimum(y1 + rng.uniform(2, 700, size=(1, 1000)), 800)], -1)
+    boxes = boxes.astype(np.float32)
+    boxes[0, 0] = [-500, -500, 2500, 2500]     # far larger than the map: 13x13 samples per bin, most of them outside
+    boxes[0, 1] = [100, 100, 100, 100]         # zero area: grid 0 -> 0/0
+    boxes[0, 2] = [300, 300, 200, 250]         # inverted
+    boxes[0, 3] = [-4000, 10, -3000, 60]       # entirely left of the map: every sample invalid -> 0
+    ref = dp.roi_align(boxes, feats, 14, 1 / 16.0, 0)
+    got = det_ops.roi_align(_t(boxes, gpu), _t(feats, gpu), 14, 1 / 16.0, 0).cpu().numpy()
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert np.isnan(ref[0, 1]).all() and (ref[0, 3] == 0).all()
+
+
+def test_roi_align_native_nhwc_f16(gpu):
+    """The engine-native form (NHWC fp16 in / out) against the fp32 oracle on the fp16-rounded feature map."""
+    import torch
+    rng = np.random.default_rng(12)
+    feats = rng.normal(size=(2, 128, 25, 42)).astype(np.float16)
+    x1 = rng.uniform(-20, 600, size=(2, 40)); y1 = rng.uniform(-20, 360, size=(2, 40))
+    boxes = np.stack([x1, y1, x1 + rng.uniform(1, 400, size=(2, 40)), y1 + rng.uniform(1, 300, size=(2, 40))], -1).astype(np.float32)
+    ref = dp.roi_align(boxes, feats.astype(np.float32), 14, 1 / 16.0, 0)              # [B, P, C, 14, 14]
+    nhwc = torch.from_numpy(np.ascontiguousarray(feats.transpose(0, 2, 3, 1))).to(gpu)
+    got = det_ops.roi_align_nhwc_f16(_t(boxes, gpu), nhwc, 14, 1 / 16.0, 0).float().cpu().numpy()  # [B*P, 14, 14, C]
+    got = got.reshape(2, 40, 14, 14, 128).transpose(0, 1, 4, 2, 3)
+    assert np.abs(got - ref).max() < 4e-3   # one fp16 rounding of O(1) values
+    ref2 = dp.roi_align(boxes, feats.astype(np.float32), 7, 1 / 16.0, 2)
+    got2 = det_ops.roi_align_nhwc_f16(_t(boxes, gpu), nhwc, 7, 1 / 16.0, 2).float().cpu().numpy().reshape(2, 40, 7, 7, 128).transpose(0, 1, 4, 2, 3)
+    assert np.abs(got2 - ref2).max() < 4e-3
+
+
 def test_predictor_decode(gpu):
     s, d, p = synth.rcnn_box_head_tensors(4, 1000, 80, seed=5)
     rs, rb, rc = dp.predictor_decode(s, d, p, 800, 1333)

@@ -66,7 +66,8 @@ def test_rcnn_fp32_engine_end_to_end(gpu):
 
 
 @pytest.mark.parametrize("hw,batch,cfg", [((320, 416), 2, dict(pre_nms_topk=2000, post_nms_topk=200, detections=50)),
-                                           ((800, 1067), 1, dict())])
+                                           ((800, 1067), 1, dict()),
+                                           ((800, 1333), 4, dict())])  # BASELINE configs[4]: 1333x800, batch 4
 def test_rcnn_fp16_engine_stagewise(gpu, hw, batch, cfg):
     H, W = hw
     path, _ = synth_wts("rcnn_r50c4")

@@ -222,7 +222,9 @@ def test_rcnn_lowering_at_reference_size():
     convs = [o for o in low["ops"] if o["kind"] == "conv"]
     # stem + 42 backbone + 3 RPN + 10 res5 + 2 FC, all but the stem on the MFMA implicit-GEMM kernel
     assert len(convs) == 58 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 57
-    assert kinds.count("plugin") == 5 and "act_nhwc" not in kinds and "ew_nhwc" not in kinds
+    # four plugins through the trampoline + RoIAlign as the engine-native NHWC op (fp16 engines), no layout pass on the RoI tensor
+    assert kinds.count("plugin") == 4 and kinds.count("roi_align") == 1 and "act_nhwc" not in kinds and "ew_nhwc" not in kinds
+    assert kinds.count("to_nhwc") == 0
     e = engine.describe_plan(plan)
     out_dims = {t["name"]: t["dims"] for t in e["tensors"] if t["is_output"]}
     assert out_dims == {"scores": [100, 1], "boxes": [100, 4], "labels": [100, 1]}
@@ -348,3 +350,17 @@ def test_single_hip_runtime_whatever_the_import_order(order):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_rcnn_fp16_plan_runs_roi_align_natively():
+    """fp16 R-CNN engines replace the RoiAlign plugin edge (fp32 LINEAR in/out + two layout passes) by the NHWC kernel; fp32 engines
+    keep the plugin."""
+    path, _ = synth_wts("rcnn_r50c4")
+    kinds = {}
+    for fp16 in (1, 0):
+        plan = engine.build_plan("rcnn_r50c4", path, batch=1, fp16=fp16, h=320, w=416, mask=1)
+        ops = engine.describe_plan(plan, lowered=True)["ops"]
+        kinds[fp16] = [o["kind"] for o in ops]
+    assert kinds[1].count("roi_align") == 2 and kinds[0].count("roi_align") == 0   # box head + mask head
+    assert kinds[1].count("plugin") == kinds[0].count("plugin") - 2
+    assert kinds[1].count("to_nhwc") < kinds[0].count("to_nhwc") or kinds[1].count("to_nhwc") <= 2
