@@ -108,6 +108,23 @@ int32_t trtx_yolov5_nms(const float* decode_out, int batch, int max_out, float c
                         int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
 
 /*
+ * Letterbox pre-processing (the reference's cuda_preprocess / cuda_batch_preprocess, yolov8/src/preprocess.cu:7-127):
+ * uint8 HWC BGR image -> fp32 CHW RGB / 255, bilinear warp-affine about the image centres, border 128.
+ *   trtx_letterbox_batch   sources already on the device: src[i] device pointer, tightly packed src_w[i] x src_h[i] x 3;
+ *                          dst device fp32 [batch][3][dst_h][dst_w]; ONE launch for the batch, nothing synchronises.
+ *   trtx_preprocess_init / _destroy / trtx_batch_preprocess   host images (cuda_preprocess_init(max_image_size), :129-139):
+ *                          pinned ring + device ring + copy stream; batch <= ring_depth.
+ *   trtx_letterbox_matrix  the dst->src map the kernel uses (s2d about the centres, inverted as cv::invertAffineTransform does).
+ */
+void trtx_letterbox_matrix(int src_w, int src_h, int dst_w, int dst_h, float* d2s_out /* 6 floats */);
+int32_t trtx_letterbox_batch(const void* const* src, const int* src_w, const int* src_h, int batch, float* dst, int dst_w, int dst_h,
+                             trtx_stream_t stream);
+int32_t trtx_preprocess_init(int max_image_size, int ring_depth);
+void trtx_preprocess_destroy(void);
+int32_t trtx_batch_preprocess(const void* const* src_host, const int* src_w, const int* src_h, int batch, float* dst, int dst_w, int dst_h,
+                              trtx_stream_t stream);
+
+/*
  * The reference's optional GPU post-processing mode "g": cuda_decode + cuda_nms (yolov8/src/postprocess.cu:42-111, call
  * site yolov8/yolov8_det.cpp:105-112; batch 1 only there, any batch here).  NOT the same result as trtx_yolo_nms: the
  * suppression is non-greedy (a box is dropped if any same-class box with higher confidence overlaps it).

@@ -1,0 +1,93 @@
+"""f2: letterbox pre-processing (reference yolov8/src/preprocess.cu:7-127).  Product HIP kernel == C oracle == the reference's own
+warpaffine kernel (oracle/_ref/libref_yolov8_post.so, compiled unmodified by hipcc), bit for bit."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import preproc as opre
+from oracle import ref
+from tensorrtx_amd import preproc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIZES = [((480, 640), (640, 640)), ((640, 480), (640, 640)), ((37, 53), (64, 64)), ((1080, 1920), (640, 640)), ((100, 100), (96, 127)),
+         ((33, 200), (640, 384))]  # (src h, w) -> (dst h, w): landscape, portrait, up-scaling, odd destination width
+
+
+def _img(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+def test_letterbox_matrix_matches_oracle():
+    for (sh, sw), (dh, dw) in SIZES + [((3000, 3000), (640, 640)), ((1, 1), (32, 32))]:
+        assert np.array_equal(preproc.letterbox_matrix(sw, sh, dw, dh), opre.letterbox_matrix(sw, sh, dw, dh))
+
+
+def test_oracle_letterbox_equals_reference_kernel_output():
+    """committed output of the reference's own kernel (run on the MI355X) for a small image"""
+    p = os.path.join(GOLD, "ref_letterbox.npz")
+    if not os.path.exists(p):
+        pytest.skip("tests/golden/ref_letterbox.npz not generated yet")
+    z = np.load(p)
+    assert np.array_equal(opre.letterbox(z["img"], 64, 64), z["out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", SIZES)
+def test_letterbox_bit_exact_vs_oracle(gpu, src, dst):
+    import torch
+    img = _img(src[0], src[1], seed=src[0] + dst[1])
+    got = preproc.letterbox_batch([torch.from_numpy(img).to(gpu)], dst[1], dst[0]).cpu().numpy()[0]
+    want = opre.letterbox(img, dst[1], dst[0])
+    assert np.array_equal(got, want)
+    assert (want == np.float32(128) / np.float32(255)).any() or src[0] * dst[1] == src[1] * dst[0]  # a border exists unless aspect ratios match
+
+
+@pytest.mark.gpu
+def test_letterbox_mixed_batch_one_launch_and_host_fed_ring(gpu):
+    import torch
+    imgs = [_img(h, w, seed=h) for (h, w), _ in SIZES[:5]] * 3      # 15 images of five sizes
+    want = np.stack([opre.letterbox(im, 320, 256) for im in imgs])
+    got = preproc.letterbox_batch([torch.from_numpy(im).to(gpu) for im in imgs], 320, 256).cpu().numpy()
+    assert np.array_equal(got, want)
+    preproc.preprocess_init(1920 * 1080, ring_depth=6)
+    try:
+        out = torch.empty((5, 3, 256, 320), dtype=torch.float32, device=gpu)
+        for rep in range(4):  # the ring wraps around: slots are reused only after their warp has finished
+            chunk = imgs[rep * 3:rep * 3 + 5]
+            preproc.batch_preprocess(chunk, 320, 256, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), np.stack([opre.letterbox(im, 320, 256) for im in chunk]))
+    finally:
+        preproc.preprocess_destroy()
+
+
+@pytest.mark.gpu
+def test_letterbox_equals_the_reference_kernel(gpu):
+    """the reference's cuda_preprocess (memcpy to its pinned buffer, H2D, warpaffine_kernel) vs trtx_letterbox_batch"""
+    import torch
+    if not ref.available("libref_yolov8_post.so"):
+        pytest.skip("oracle/_ref/libref_yolov8_post.so not present")
+    L = ref.family_lib("yolov8_post")
+    L.ref_yolov8_preprocess_init(1920 * 1080)
+    try:
+        for (sh, sw), (dh, dw) in SIZES:
+            img = _img(sh, sw, seed=7 + sh)
+            want = torch.zeros((3, dh, dw), dtype=torch.float32, device=gpu)
+            L.ref_yolov8_preprocess(img.ctypes.data_as(ctypes.c_void_p), sw, sh, ctypes.c_void_p(want.data_ptr()), dw, dh,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            got = preproc.letterbox_batch([torch.from_numpy(img).to(gpu)], dw, dh)[0]
+            assert torch.equal(got, want), ((sh, sw), (dh, dw))
+            assert np.array_equal(want.cpu().numpy(), opre.letterbox(img, dw, dh))
+        if os.environ.get("TRTX_WRITE_GOLDEN"):
+            img = _img(37, 53, seed=99)
+            want = torch.zeros((3, 64, 64), dtype=torch.float32, device=gpu)
+            L.ref_yolov8_preprocess(img.ctypes.data_as(ctypes.c_void_p), 53, 37, ctypes.c_void_p(want.data_ptr()), 64, 64,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez_compressed("gpurun_out/ref_letterbox.npz", img=img, out=want.cpu().numpy())
+    finally:
+        L.ref_yolov8_preprocess_destroy()
