@@ -60,6 +60,13 @@ int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, in
                          const int* strides, int max_out, float* output, void* workspace, size_t workspace_bytes,
                          trtx_stream_t stream);
 
+/* trtx_yolo_decode with the optional branches of CalDetection (yololayer.cu:222-279): inputs [batch][4 + classes (+32 seg)
+ * (+3*n_kpt pose) (+1 obb)][cells]; seg copies the 32 mask coefficients into Detection::mask, pose decodes n_kpt keypoints
+ * ((2*v + col|row) * stride, sigmoid confidence, -1 triple when below kpt_conf or outside the box), obb rotates the box
+ * centre by (sigmoid(a) - 0.25) * pi and stores cx, cy, w, h + Detection::angle. */
+int32_t trtx_yolo_decode_ex(const float* const* inputs, int n_levels, int batch, int classes, int net_h, int net_w,
+                            const int* strides, int max_out, int n_kpt, float kpt_conf, int is_seg, int is_pose, int is_obb,
+                            float* output, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
 /*
  * Fused DFL + YOLOv8 decode on the detect head's own NHWC fp16 output (what the engine uses instead of the
  * shuffle/slice/softmax/conv/concat chain of yolov8/src/block.cpp:239-257 + model.cpp:263-303 followed by
@@ -102,6 +109,13 @@ size_t trtx_yolov5_decode_workspace(int batch, const int* grid_w, const int* gri
 int32_t trtx_yolov5_decode(const float* const* inputs, int n_levels, int batch, int classes, int net_h, int net_w,
                            const int* grid_w, const int* grid_h, const float* anchors, int max_out, int is_segmentation,
                            float* output, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+/* Oriented boxes (yolov8 obb): host nms_obb() on the GPU (yolov8/src/postprocess.cpp:303-393, ProbIoU, "conf <= thresh" dropped,
+ * erased when probiou >= nms_thresh); keep_det is [batch][max_out][7] = cx, cy, w, h, conf, class, angle.  And the reference's
+ * GPU mode for oriented boxes, cuda_decode_obb + cuda_nms_obb (yolov8/src/postprocess.cu:7-40, 113-166): out [batch][1 + max_out*8]. */
+int32_t trtx_yolo_nms_obb(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh, int32_t* keep_idx,
+                          int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes, trtx_stream_t stream);
+int32_t trtx_yolo_postprocess_gpu_obb(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh, float* out,
+                                      trtx_stream_t stream);
 /* YOLOv5 host nms() / batch_nms() on the GPU (yolov5/src/postprocess.cpp:30-80): centre-format IoU, conf <= thresh dropped,
  * class-wise greedy suppression in conf-descending order.  Same outputs / workspace as trtx_yolo_nms; records are 38 floats. */
 int32_t trtx_yolov5_nms(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh, int32_t* keep_idx,

@@ -65,6 +65,15 @@ def yolov8_batch_nms(output, conf_thresh=0.5, nms_thresh=0.45, cap=1024):
     return [out[b, :min(cnt[b], cap)] for b in range(B)]
 
 
+def yolov8_nms_obb(output_row, conf_thresh=0.5, nms_thresh=0.45, cap=4096):
+    """nms_obb() of yolov8/src/postprocess.cpp:357-385 (ProbIoU) -> kept detections [n, 90]."""
+    L = host()
+    row = np.ascontiguousarray(output_row, dtype=np.float32).copy()
+    out = np.zeros((cap, 90), dtype=np.float32)
+    n = L.ref_yolov8_nms_obb(_fp(row), ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh), _fp(out), cap)
+    return out[:n]
+
+
 def yolov5_nms(output_row, conf_thresh=0.5, nms_thresh=0.45, cap=4096):
     """nms() of yolov5/src/postprocess.cpp:50-73 (centre-format boxes) -> kept detections [n, 38]."""
     L = host()

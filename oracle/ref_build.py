@@ -36,6 +36,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (output .inc, reference file, first line regex, regex of the first line NOT taken)
 REGIONS = [
     ("yolov8_nms.inc", "yolov8/src/postprocess.cpp", r"^static float iou\(", r"^void process_decode_ptr_host\("),
+    ("yolov8_nms_obb.inc", "yolov8/src/postprocess.cpp", r"^std::tuple<float, float, float> convariance_matrix\(", r"^static std::vector<cv::Point> get_corner\("),
     ("yolov5_nms.inc", "yolov5/src/postprocess.cpp", r"^static float iou\(", r"^void draw_bbox\("),
     ("retina_nms.inc", "retinaface/common.hpp", r"^static float iou\(", r"^// Load weights from files"),
     ("retina_types.inc", "retinaface/decode.h", r"^namespace decodeplugin", r"^namespace nvinfer1"),

@@ -5,12 +5,14 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <vector>
 #include <math.h>
 
 namespace ref_yolov8 {
 #include "yolov8/include/types.h"  // the reference's Detection (90 floats), read in place from /root/reference
 #include "yolov8_nms.inc"          // yolov8/src/postprocess.cpp: iou, cmp, nms, batch_nms
+#include "yolov8_nms_obb.inc"      // yolov8/src/postprocess.cpp: convariance_matrix, probiou, nms_obb, batch_nms_obb
 }  // namespace ref_yolov8
 
 namespace ref_yolov5 {
@@ -47,6 +49,11 @@ void ref_yolov8_batch_nms(float* output, int batch, int output_size, float conf_
     ref_yolov8::batch_nms(res, output, batch, output_size, conf_thresh, nms_thresh);
     const size_t det = sizeof(ref_yolov8::Detection) / sizeof(float);
     for (int b = 0; b < batch; ++b) counts[b] = copy_out(res[b], out + (size_t)b * cap * det, cap);
+}
+int ref_yolov8_nms_obb(float* output, float conf_thresh, float nms_thresh, float* out, int cap) {
+    std::vector<ref_yolov8::Detection> res;
+    ref_yolov8::nms_obb(res, output, conf_thresh, nms_thresh);
+    return copy_out(res, out, cap);
 }
 int ref_yolov5_nms(float* output, float conf_thresh, float nms_thresh, float* out, int cap) {
     std::vector<ref_yolov5::Detection> res;

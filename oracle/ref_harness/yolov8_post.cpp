@@ -15,6 +15,15 @@ REF_API void ref_yolov8_gpu_postprocess(float* decode_dev, int model_bboxes, flo
     cuda_nms(parray_dev, nms_thresh, max_objects, s);
 }
 
+// yolov8_obb.cpp mode "g": memset, cuda_decode_obb, cuda_nms_obb
+REF_API void ref_yolov8_gpu_postprocess_obb(float* decode_dev, int model_bboxes, float conf_thresh, float nms_thresh, float* parray_dev,
+                                            int max_objects, void* stream) {
+    cudaStream_t s = static_cast<cudaStream_t>(stream);
+    cudaMemsetAsync(parray_dev, 0, sizeof(float) * (1 + max_objects * 8), s);
+    cuda_decode_obb(decode_dev, model_bboxes, conf_thresh, parray_dev, max_objects, s);
+    cuda_nms_obb(parray_dev, nms_thresh, max_objects, s);
+}
+
 // yolov8/src/preprocess.cu:89-117 + init/destroy: host BGR uint8 image -> device CHW fp32 RGB /255 letterboxed
 REF_API void ref_yolov8_preprocess_init(int max_image_size) { cuda_preprocess_init(max_image_size); }
 REF_API void ref_yolov8_preprocess_destroy() { cuda_preprocess_destroy(); }

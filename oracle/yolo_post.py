@@ -198,3 +198,39 @@ def v5_batch_nms_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
         keep_cnt[b] = L.yolov5_nms_ref(_fp(output[b]), max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
                                        keep_idx[b].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(keep_det[b]))
     return keep_idx, keep_cnt, keep_det
+
+
+# ---------------------------------------------------------------------------------------------------- YOLOv8 seg / pose / obb
+def decode_ex_c(inputs, classes, net_h, net_w, strides, max_out=1000, nk=17, kpt_conf=0.0, seg=False, pose=False, obb=False):
+    """yolov8/plugin/yololayer.cu:178-279 with the optional branches; inputs [B, 4+classes(+32)(+3nk)(+1), cells] per level."""
+    ins = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+    batch = ins[0].shape[0]
+    out = np.zeros((batch, 1 + max_out * DET_FLOATS), dtype=np.float32)
+    ptrs = (ctypes.POINTER(ctypes.c_float) * len(ins))(*[_fp(x) for x in ins])
+    st = (ctypes.c_int * len(strides))(*strides)
+    lib().yolo_decode_ex_ref(ptrs, batch, classes, net_h, net_w, st, len(strides), max_out, nk, ctypes.c_float(kpt_conf), int(seg), int(pose),
+                             int(obb), _fp(out))
+    return out
+
+
+def batch_nms_obb_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """yolov8/src/postprocess.cpp:303-393 (ProbIoU) -> keep_idx [B, max_out], keep_cnt [B], keep_det [B, max_out, 7]."""
+    output = np.ascontiguousarray(output, dtype=np.float32)
+    B = output.shape[0]
+    keep_idx = np.full((B, max_out), -1, dtype=np.int32)
+    keep_cnt = np.zeros((B,), dtype=np.int32)
+    keep_det = np.zeros((B, max_out, 7), dtype=np.float32)
+    L = lib()
+    L.yolo_nms_obb_ref.restype = ctypes.c_int
+    for b in range(B):
+        keep_cnt[b] = L.yolo_nms_obb_ref(_fp(output[b]), max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+                                         keep_idx[b].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(keep_det[b]))
+    return keep_idx, keep_cnt, keep_det
+
+
+def gpu_postprocess_obb_c(output, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """cuda_decode_obb + cuda_nms_obb (yolov8/src/postprocess.cu), C restatement: [B, 1 + max_out*8]."""
+    output = np.ascontiguousarray(output, dtype=np.float32)
+    out = np.zeros((output.shape[0], 1 + max_out * 8), dtype=np.float32)
+    lib().yolo_gpu_postprocess_obb_ref(_fp(output), output.shape[0], max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh), _fp(out))
+    return out

@@ -114,6 +114,47 @@ def yolo_nms(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45, with_de
     return keep_idx, keep_cnt, keep_det
 
 
+def yolo_decode_ex(inputs, classes, net_h, net_w, strides, max_out=1000, nk=17, kpt_conf=0.0, seg=False, pose=False, obb=False):
+    """YoloLayerPlugin::enqueue with the seg / pose / obb branches (yolov8/plugin/yololayer.cu:178-279)."""
+    import torch
+    L = lib()
+    B, n = inputs[0].shape[0], len(inputs)
+    ins = [x.contiguous() for x in inputs]
+    arr = (ctypes.c_void_p * n)(*[x.data_ptr() for x in ins])
+    st = (ctypes.c_int * n)(*strides)
+    ws_bytes = L.trtx_yolo_decode_workspace(B, net_h, net_w, st, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=ins[0].device)
+    out = torch.zeros((B, 1 + max_out * DET_FLOATS), dtype=torch.float32, device=ins[0].device)
+    check(L.trtx_yolo_decode_ex(arr, n, B, classes, net_h, net_w, st, max_out, nk, ctypes.c_float(kpt_conf), int(seg), int(pose), int(obb),
+                                _p(out), _p(ws), ctypes.c_size_t(ws_bytes), _stream()), "trtx_yolo_decode_ex")
+    return out
+
+
+def yolo_nms_obb(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """nms_obb replacement (yolov8/src/postprocess.cpp:303-393).  keep_det: [B, max_out, 7] = cx, cy, w, h, conf, cls, angle."""
+    import torch
+    L = lib()
+    B, dev = decode_out.shape[0], decode_out.device
+    keep_idx = torch.full((B, max_out), -1, dtype=torch.int32, device=dev)
+    keep_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    keep_det = torch.zeros((B, max_out, 7), dtype=torch.float32, device=dev)
+    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    ws_bytes = L.trtx_yolo_nms_workspace(B)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    check(L.trtx_yolo_nms_obb(_p(decode_out), B, max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh), _p(keep_idx), _p(keep_cnt),
+                              _p(keep_det), _p(ws), ctypes.c_size_t(ws_bytes), _stream()), "trtx_yolo_nms_obb")
+    return keep_idx, keep_cnt, keep_det
+
+
+def yolo_postprocess_gpu_obb(decode_out, max_out=1000, conf_thresh=0.5, nms_thresh=0.45):
+    """The reference's GPU mode for oriented boxes (yolov8/src/postprocess.cu: decode_kernel_obb + nms_kernel_obb): [B, 1 + max_out*8]."""
+    import torch
+    out = torch.empty((decode_out.shape[0], 1 + max_out * 8), dtype=torch.float32, device=decode_out.device)
+    check(lib().trtx_yolo_postprocess_gpu_obb(_p(decode_out), decode_out.shape[0], max_out, ctypes.c_float(conf_thresh), ctypes.c_float(nms_thresh),
+                                              _p(out), _stream()), "trtx_yolo_postprocess_gpu_obb")
+    return out
+
+
 DET5_FLOATS = 38  # yolov5/src/types.h:11-16
 
 

@@ -92,13 +92,14 @@ int32_t yolo_configure(void* s, const trtx_dims* in, int32_t nb_in, const trtx_d
         const int64_t cells = (int64_t)(y->net_h / y->strides[i]) * (y->net_w / y->strides[i]);
         int64_t vol = 1;
         for (int k = 0; k < in[i].nb; ++k) vol *= in[i].d[k];
-        if (vol != cells * (4 + y->class_count)) return 1;  // det only: [4+classes, cells]
+        const int info = 4 + y->class_count + (y->seg ? 32 : 0) + (y->pose ? y->n_kpt * 3 : 0) + (y->obb ? 1 : 0);
+        if (vol != cells * info) return 1;  // [4 + classes (+32) (+3*nk) (+1), cells]
     }
     return 0;
 }
 int32_t yolo_initialize(void* s) {
     auto* y = static_cast<YoloLayer*>(s);
-    return (y->seg || y->pose || y->obb) ? 1 : 0;  // only the det branch is implemented
+    return (y->n_kpt < 0 || y->n_kpt > 17) ? 1 : 0;  // Detection::keypoints holds kNumberOfPoints = 17 triples
 }
 void yolo_terminate(void*) {}
 size_t yolo_workspace(void* s, int32_t max_batch) {
@@ -110,9 +111,9 @@ int32_t yolo_enqueue(void* s, int32_t batch, const void* const* inputs, void* co
     auto* y = static_cast<YoloLayer*>(s);
     const size_t ws_bytes =
             trtx_yolo_decode_workspace(batch, y->net_h, y->net_w, y->strides.data(), (int)y->strides.size());
-    return trtx_yolo_decode(reinterpret_cast<const float* const*>(inputs), (int)y->strides.size(), batch,
-                            y->class_count, y->net_h, y->net_w, y->strides.data(), y->max_out,
-                            static_cast<float*>(outputs[0]), ws, ws_bytes, stream);
+    return trtx_yolo_decode_ex(reinterpret_cast<const float* const*>(inputs), (int)y->strides.size(), batch, y->class_count, y->net_h,
+                               y->net_w, y->strides.data(), y->max_out, y->n_kpt, y->kpt_conf, y->seg, y->pose, y->obb,
+                               static_cast<float*>(outputs[0]), ws, ws_bytes, stream);
 }
 size_t yolo_ser_size(void* s) { return static_cast<YoloLayer*>(s)->blob().size(); }
 void yolo_serialize(void* s, void* buf) {

@@ -21,6 +21,12 @@ namespace {
 constexpr int kMaxLevels = 8;
 constexpr int kChunk = 512;  // cells per workgroup in both passes
 
+// which optional branches of the YOLOv8 Detection record are decoded (yololayer.cu:222-279)
+struct YoloBranches {
+    int seg, pose, obb, nk;
+    float kpt_conf;
+};
+
 struct LevelTable {
     const float* in[kMaxLevels];  // device pointers, [batch][4+classes][cells]
     int cell_off[kMaxLevels + 1];  // cumulative cell offsets
@@ -44,7 +50,7 @@ __device__ __forceinline__ int find_level(const LevelTable& t, int g) {
 
 // Pass 1: per cell best class/prob.  VEC cells per thread (VEC = 4 -> 16-byte loads).
 template <int VEC>
-__global__ __launch_bounds__(kChunk / VEC) void yolo_score_kernel(LevelTable t, int classes, int total_cells,
+__global__ __launch_bounds__(kChunk / VEC) void yolo_score_kernel(LevelTable t, int classes, int info_len, int total_cells,
                                                                   float* __restrict__ score,
                                                                   int* __restrict__ cls_out,
                                                                   int* __restrict__ chunk_cnt, int n_chunks) {
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(kChunk / VEC) void yolo_score_kernel(LevelTable t, 
         const int l = find_level(t, g0);
         const int cells = t.cell_off[l + 1] - t.cell_off[l];
         const int e0 = g0 - t.cell_off[l];
-        const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e0;
+        const float* cur = t.in[l] + (size_t)b * cells * info_len + e0;
         float best[VEC];
         int bcls[VEC];
 #pragma unroll
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
                                                            const int* __restrict__ cls_in,
                                                            const int* __restrict__ chunk_cnt, int n_chunks,
                                                            int max_out, int out_elem, float* __restrict__ output,
-                                                           const float4* __restrict__ boxes) {
+                                                           const float4* __restrict__ boxes, YoloBranches br) {
     const int b = blockIdx.y;
     const int chunk = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -152,10 +158,11 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
         const int gw = t.grid_w[l];
         const float stride = (float)t.stride[l];
         float4 d;
+        const int info_len = 4 + classes + (br.seg ? 32 : 0) + (br.pose ? br.nk * 3 : 0) + (br.obb ? 1 : 0);
+        const float* cur = boxes ? nullptr : t.in[l] + (size_t)b * cells * info_len + e;
         if (boxes) {
             d = boxes[(size_t)b * total_cells + g];
         } else {
-            const float* cur = t.in[l] + (size_t)b * cells * (4 + classes) + e;
             d = make_float4(cur[0], cur[(size_t)cells], cur[(size_t)2 * cells], cur[(size_t)3 * cells]);
         }
         const int row = e / gw, col = e - row * gw;
@@ -166,6 +173,47 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
         det[3] = (row + 0.5f + d.w) * stride;
         det[4] = sc;
         det[5] = (float)cls_in[(size_t)b * total_cells + g];
+        // ---- the seg / pose / obb branches of CalDetection (yololayer.cu:222-279); plugin-ABI form only
+        if (cur && br.seg) {
+            const float* m = cur + (size_t)(4 + classes + (br.pose ? br.nk * 3 : 0) + (br.obb ? 1 : 0)) * cells;
+            for (int k = 0; k < 32; ++k) det[6 + k] = m[(size_t)k * cells];
+        }
+        if (cur && br.pose) {
+            const int istride = t.stride[l];
+            const float* kp = cur + (size_t)(4 + classes + (br.seg ? 32 : 0) + (br.obb ? 1 : 0)) * cells;
+            for (int k = 0; k < br.nk; ++k) {
+                const float kconf = 1.0f / (1.0f + expf(-kp[(size_t)(k * 3 + 2) * cells]));
+                // "(in * 2.0 + col) * stride": double arithmetic, rounded once to float (yololayer.cu:236-237)
+                const float kx = (float)((kp[(size_t)(k * 3) * cells] * 2.0 + col) * istride);
+                const float ky = (float)((kp[(size_t)(k * 3 + 1) * cells] * 2.0 + row) * istride);
+                const bool inside = kx >= det[0] && kx <= det[2] && ky >= det[1] && ky <= det[3];
+                float* o = det + 38 + k * 3;
+                if (kconf < br.kpt_conf || !inside) {
+                    o[0] = -1;
+                    o[1] = -1;
+                    o[2] = -1;
+                } else {
+                    o[0] = kx;
+                    o[1] = ky;
+                    o[2] = kconf;
+                }
+            }
+        }
+        if (cur && br.obb) {
+            const int istride = t.stride[l];
+            const double pi = 3.14159265358979323846;  // M_PI
+            const float ain = cur[(size_t)(4 + classes + (br.seg ? 32 : 0) + (br.pose ? br.nk * 3 : 0)) * cells];
+            const double angle = ((1.0f / (1.0f + expf(-ain))) - 0.25f) * pi;  // float difference times double pi (:259)
+            const double cos1 = cos(angle), sin1 = sin(angle);
+            const float xf = (d.z - d.x) / 2, yf = (d.w - d.y) / 2;
+            const double x = xf * cos1 - yf * sin1;
+            const double y = xf * sin1 + yf * cos1;
+            det[0] = (float)((col + 0.5f + x) * istride);
+            det[1] = (float)((row + 0.5f + y) * istride);
+            det[2] = (d.x + d.z) * istride;
+            det[3] = (d.y + d.w) * istride;
+            det[trtx::kYoloDetFloats - 1] = (float)angle;
+        }
     }
     if (chunk == n_chunks - 1 && threadIdx.x == kChunk - 1) {
         int total = before + in_wave + (keep ? 1 : 0);  // last thread of the last chunk sees the full count
@@ -308,13 +356,15 @@ extern "C" size_t trtx_yolo_decode_workspace(int batch, int net_h, int net_w, co
            trtx::align_up((size_t)batch * n_chunks * sizeof(int), 256);
 }
 
-extern "C" int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, int classes, int net_h,
-                                    int net_w, const int* strides, int max_out, float* output, void* workspace,
-                                    size_t workspace_bytes, hipStream_t stream) {
+extern "C" int32_t trtx_yolo_decode_ex(const float* const* inputs, int n_levels, int batch, int classes, int net_h, int net_w,
+                                       const int* strides, int max_out, int n_kpt, float kpt_conf, int is_seg, int is_pose, int is_obb,
+                                       float* output, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (n_levels < 1 || n_levels > kMaxLevels || batch < 1 || classes < 1 || max_out < 1 || !inputs || !output ||
-        !workspace)
+        !workspace || n_kpt < 0 || n_kpt > 17)
         return TRTX_ERR_INVALID;
     if (workspace_bytes < trtx_yolo_decode_workspace(batch, net_h, net_w, strides, n_levels)) return TRTX_ERR_WORKSPACE;
+    const YoloBranches br{is_seg ? 1 : 0, is_pose ? 1 : 0, is_obb ? 1 : 0, n_kpt, kpt_conf};
+    const int info_len = 4 + classes + (br.seg ? 32 : 0) + (br.pose ? n_kpt * 3 : 0) + (br.obb ? 1 : 0);
     LevelTable t{};
     t.n_levels = n_levels;
     bool vec4 = true;
@@ -340,14 +390,21 @@ extern "C" int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, in
     const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
     dim3 grid(n_chunks, batch);
     if (vec4)
-        hipLaunchKernelGGL(yolo_score_kernel<4>, grid, dim3(kChunk / 4), 0, stream, t, classes, total_cells, score,
+        hipLaunchKernelGGL(yolo_score_kernel<4>, grid, dim3(kChunk / 4), 0, stream, t, classes, info_len, total_cells, score,
                            cls, chunk_cnt, n_chunks);
     else
-        hipLaunchKernelGGL(yolo_score_kernel<1>, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
+        hipLaunchKernelGGL(yolo_score_kernel<1>, grid, dim3(kChunk), 0, stream, t, classes, info_len, total_cells, score, cls,
                            chunk_cnt, n_chunks);
     hipLaunchKernelGGL(yolo_emit_kernel, grid, dim3(kChunk), 0, stream, t, classes, total_cells, score, cls,
-                       chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)nullptr);
+                       chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)nullptr, br);
     return trtx::check_launch("trtx_yolo_decode");
+}
+
+extern "C" int32_t trtx_yolo_decode(const float* const* inputs, int n_levels, int batch, int classes, int net_h,
+                                    int net_w, const int* strides, int max_out, float* output, void* workspace,
+                                    size_t workspace_bytes, hipStream_t stream) {
+    return trtx_yolo_decode_ex(inputs, n_levels, batch, classes, net_h, net_w, strides, max_out, 0, 0.f, 0, 0, 0, output, workspace,
+                               workspace_bytes, stream);
 }
 
 
@@ -399,6 +456,6 @@ extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const in
     hipLaunchKernelGGL(yolo_head_score_kernel, dim3((total_cells + 255) / 256, batch), dim3(256), 0, stream, h, classes,
                        total_cells, dfl_weights, score, cls, boxes, chunk_cnt, n_chunks);
     hipLaunchKernelGGL(yolo_emit_kernel, dim3(n_chunks, batch), dim3(kChunk), 0, stream, t, classes, total_cells, score,
-                       cls, chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)boxes);
+                       cls, chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)boxes, YoloBranches{0, 0, 0, 0, 0.f});
     return trtx::check_launch("trtx_yolo_head_decode_nhwc");
 }

@@ -64,6 +64,39 @@ __device__ __forceinline__ float iou_cxcywh(const float4 l, const float4 r) {
     return inter / (l.z * l.w + r.z * r.w - inter);
 }
 
+// probiou() of the host NMS for oriented boxes (yolov8/src/postprocess.cpp:303-355): the reference mixes float and double
+// (std::pow(float, int) and the 12.0 / 1.0 literals promote to double, std::cos/sin/sqrt/exp(float) stay float); the same
+// promotions are written out here.  pow(x, 2) is x * x in double (exact up to the final rounding either way).
+__device__ __forceinline__ void obb_cov(const float4 box, float angle, float& a_val, float& b_val, float& c_val) {
+    const float w = box.z, h = box.w;
+    const float a = (float)(w * w / 12.0);
+    const float b = (float)(h * h / 12.0);
+    const float cos_r = cosf(angle), sin_r = sinf(angle);
+    const float cos_r2 = cos_r * cos_r, sin_r2 = sin_r * sin_r;
+    a_val = a * cos_r2 + b * sin_r2;
+    b_val = a * sin_r2 + b * cos_r2;
+    c_val = (a - b) * cos_r * sin_r;
+}
+__device__ __forceinline__ float probiou_host(const float4 r1, float ang1, const float4 r2, float ang2) {
+    const float eps = 1e-7f;
+    float a1, b1, c1, a2, b2, c2;
+    obb_cov(r1, ang1, a1, b1, c1);
+    obb_cov(r2, ang2, a2, b2, c2);
+    const float x1 = r1.x, y1 = r1.y, x2 = r2.x, y2 = r2.y;
+    const double dy = (double)(y1 - y2), dx = (double)(x1 - x2), cc = (double)(c1 + c2);
+    const double den = (double)((a1 + a2) * (b1 + b2)) - cc * cc + (double)eps;
+    const float t1 = (float)(((double)(a1 + a2) * (dy * dy) + (double)(b1 + b2) * (dx * dx)) / den);
+    const float t2 = (float)((double)((c1 + c2) * (x2 - x1) * (y1 - y2)) / den);
+    const float s1 = a1 * b1 - c1 * c1, s2 = a2 * b2 - c2 * c2;
+    const float den3 = 4 * sqrtf(s1 > 0.0f ? s1 : 0.0f) * sqrtf(s2 > 0.0f ? s2 : 0.0f) + eps;
+    const float t3 = (float)log(((double)((a1 + a2) * (b1 + b2)) - cc * cc) / (double)den3 + (double)eps);
+    float bd = 0.25f * t1 + 0.5f * t2 + 0.5f * t3;
+    bd = bd < 100.0f ? bd : 100.0f;
+    bd = bd > eps ? bd : eps;
+    const float hd = (float)sqrt(1.0 - (double)expf(-bd) + (double)eps);
+    return 1 - hd;
+}
+
 // workspace layout (per batch; every array is [batch][kCap] unless noted)
 struct NmsWs {
     float4* box;     // sorted boxes
@@ -71,6 +104,7 @@ struct NmsWs {
     float* conf;
     int* orig;       // decode slot of the sorted record
     int* n;          // [batch] number of valid (thresholded) records
+    float* ang;      // sorted box angles (oriented boxes)
     uint64_t* mask;  // [batch][kCap][kBlocks]
 };
 
@@ -78,7 +112,7 @@ __host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size
 
 inline size_t nms_ws_bytes(int batch) {
     const size_t rec = (size_t)batch * kCap;
-    return align256(rec * sizeof(float4)) + 3 * align256(rec * 4) + align256((size_t)batch * 4) +
+    return align256(rec * sizeof(float4)) + 4 * align256(rec * 4) + align256((size_t)batch * 4) +
            align256(rec * kBlocks * sizeof(uint64_t));
 }
 
@@ -91,6 +125,7 @@ inline NmsWs nms_ws_carve(void* base, int batch) {
     w.conf = reinterpret_cast<float*>(p); p += align256(rec * 4);
     w.orig = reinterpret_cast<int*>(p); p += align256(rec * 4);
     w.n = reinterpret_cast<int*>(p); p += align256((size_t)batch * 4);
+    w.ang = reinterpret_cast<float*>(p); p += align256(rec * 4);
     w.mask = reinterpret_cast<uint64_t*>(p);
     return w;
 }
@@ -98,6 +133,8 @@ inline NmsWs nms_ws_carve(void* base, int batch) {
 // MODE 0: YOLOv8 host nms() (postprocess.cpp:94-121): xyxy boxes, "conf <= thresh || isnan" dropped, ties by bbox[0] then slot.
 // MODE 1: YOLOv5 host nms() (yolov5/src/postprocess.cpp:50-73): centre-format boxes, "conf <= thresh" dropped (a NaN stays),
 //         cmp() orders by conf only -> ties by slot (the reference's unstable std::sort leaves them unspecified).
+// MODE 2: YOLOv8 host nms_obb() (postprocess.cpp:357-385): (cx, cy, w, h, angle) boxes, "conf <= thresh" dropped, same cmp() as
+//         MODE 0, a later box is erased when probiou(item, box) >= thresh.
 template <int MODE>
 __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __restrict__ decode, int out_elem, int det_floats,
                                                              int max_out, float conf_thresh, NmsWs ws) {
@@ -119,7 +156,7 @@ __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __rest
         // MODE 0: false for NaN, as "conf <= thresh || isnan" drops (postprocess.cpp:99); MODE 1: only "conf <= thresh" drops
         if (MODE == 0 ? (conf > conf_thresh) : !(conf <= conf_thresh)) {
             hi = ((uint64_t)trtx::ord_f32(det[5]) << 32) | (uint32_t)~trtx::ord_f32(conf);
-            lo = ((uint64_t)(MODE == 0 ? trtx::ord_f32(det[0]) : 0u) << 32) | (uint32_t)tid;
+            lo = ((uint64_t)(MODE != 1 ? trtx::ord_f32(det[0]) : 0u) << 32) | (uint32_t)tid;
         }
     }
     // bitonic sort, ascending, 1024 keys
@@ -151,14 +188,16 @@ __global__ __launch_bounds__(kCap) void yolo_nms_sort_kernel(const float* __rest
     const bool valid = !(hi == ~0ull && lo == ~0ull);
     const int orig = valid ? (int)(uint32_t)lo : 0;
     float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cls = -1.0f, conf = 0.0f;
+    float cls = -1.0f, conf = 0.0f, ang = 0.0f;
     if (valid) {
         const float* det = img + 1 + (size_t)orig * det_floats;
         box = make_float4(det[0], det[1], det[2], det[3]);
         conf = det[4];
         cls = det[5];
+        if (MODE == 2) ang = det[det_floats - 1];  // Detection::angle is the last float of the record
     }
     const size_t r = (size_t)b * kCap + tid;
+    if (MODE == 2) ws.ang[r] = ang;
     ws.box[r] = box;
     ws.cls[r] = cls;
     ws.conf[r] = conf;
@@ -188,22 +227,30 @@ __global__ __launch_bounds__(kCap) void yolo_nms_mask_kernel(NmsWs ws, float nms
     if (r * 64 < n && !(c < r && ws.cls[base + c * 64 + 63] < ws.cls[base + r * 64])) {
         __shared__ float4 s_box[kBlocks][64];  // wave-private rows: a wave's own LDS accesses are ordered
         __shared__ float s_cls[kBlocks][64];
+        __shared__ float s_ang[kBlocks][64];
         s_box[c][lane] = ws.box[base + c * 64 + lane];
         s_cls[c][lane] = ws.cls[base + c * 64 + lane];
+        if (MODE == 2) s_ang[c][lane] = ws.ang[base + c * 64 + lane];
         if (i < n) {
             const float4 mine = ws.box[base + i];
             const float my_cls = ws.cls[base + i];
+            const float my_ang = MODE == 2 ? ws.ang[base + i] : 0.0f;
             const int kend = (c == r) ? lane : 64;  // only earlier boxes suppress
-            for (int k = 0; k < kend; ++k)
-                if (s_cls[c][k] == my_cls && (MODE == 0 ? iou_xyxy(s_box[c][k], mine) : iou_cxcywh(s_box[c][k], mine)) > nms_thresh)
-                    bits |= 1ull << k;
+            for (int k = 0; k < kend; ++k) {
+                if (s_cls[c][k] != my_cls) continue;
+                bool hit;
+                if (MODE == 0) hit = iou_xyxy(s_box[c][k], mine) > nms_thresh;
+                else if (MODE == 1) hit = iou_cxcywh(s_box[c][k], mine) > nms_thresh;
+                else hit = probiou_host(s_box[c][k], s_ang[c][k], mine, my_ang) >= nms_thresh;
+                if (hit) bits |= 1ull << k;
+            }
         }
     }
     ws.mask[(base + i) * kBlocks + c] = bits;
 }
 
 __global__ __launch_bounds__(kCap) void yolo_nms_scan_kernel(NmsWs ws, int max_out, int* __restrict__ keep_idx,
-                                                             int* __restrict__ keep_cnt, float* __restrict__ keep_det) {
+                                                             int* __restrict__ keep_cnt, float* __restrict__ keep_det, int det_out) {
     __shared__ uint64_t s_kept[kBlocks];
     __shared__ int s_wcnt[kBlocks];
     const int b = blockIdx.x;
@@ -269,7 +316,8 @@ __global__ __launch_bounds__(kCap) void yolo_nms_scan_kernel(NmsWs ws, int max_o
         keep_idx[(size_t)b * max_out + pos] = ws.orig[base + tid];
         if (keep_det) {
             const float4 box = ws.box[base + tid];
-            float* o = keep_det + ((size_t)b * max_out + pos) * 6;
+            float* o = keep_det + ((size_t)b * max_out + pos) * det_out;
+            if (det_out > 6) o[6] = ws.ang[base + tid];
             o[0] = box.x;
             o[1] = box.y;
             o[2] = box.z;
@@ -343,6 +391,71 @@ __global__ __launch_bounds__(kCap) void yolo_gpu_post_kernel(const float* __rest
     }
 }
 
+// ---- the reference's GPU post-processing for oriented boxes (postprocess.cu:7-40 decode_kernel_obb, :113-166 box_probiou /
+// nms_kernel_obb; call sites yolov8_obb.cpp): 8-float records cx, cy, w, h, conf, class, keep, angle; float math throughout.
+__device__ __forceinline__ void cov_g(float w, float h, float r, float& a, float& b, float& c) {  // postprocess.cu:113-122
+    const float a_val = w * w / 12.0f, b_val = h * h / 12.0f;
+    const float cos_r = cosf(r), sin_r = sinf(r);
+    a = a_val * cos_r * cos_r + b_val * sin_r * sin_r;
+    b = a_val * sin_r * sin_r + b_val * cos_r * cos_r;
+    c = (a_val - b_val) * sin_r * cos_r;
+}
+__device__ __forceinline__ float probiou_g(const float* p, const float* q) {  // postprocess.cu:124-142; records: [0..3] box, [7] angle
+    const float eps = 1e-7f;
+    float a1, b1, c1, a2, b2, c2;
+    cov_g(p[2], p[3], p[7], a1, b1, c1);
+    cov_g(q[2], q[3], q[7], a2, b2, c2);
+    const float cx1 = p[0], cy1 = p[1], cx2 = q[0], cy2 = q[1];
+    const float t1 = ((a1 + a2) * powf(cy1 - cy2, 2) + (b1 + b2) * powf(cx1 - cx2, 2)) / ((a1 + a2) * (b1 + b2) - powf(c1 + c2, 2) + eps);
+    const float t2 = ((c1 + c2) * (cx2 - cx1) * (cy1 - cy2)) / ((a1 + a2) * (b1 + b2) - powf(c1 + c2, 2) + eps);
+    const float t3 = logf(((a1 + a2) * (b1 + b2) - powf(c1 + c2, 2)) /
+                                  (4 * sqrtf(fmaxf(a1 * b1 - c1 * c1, 0.0f)) * sqrtf(fmaxf(a2 * b2 - c2 * c2, 0.0f)) + eps) +
+                          eps);
+    float bd = 0.25f * t1 + 0.5f * t2 + 0.5f * t3;
+    bd = fmaxf(fminf(bd, 100.0f), eps);
+    const float hd = sqrtf(1.0f - expf(-bd) + eps);
+    return 1 - hd;
+}
+
+__global__ __launch_bounds__(kCap) void yolo_gpu_post_obb_kernel(const float* __restrict__ decode, int in_elem, int det_floats, int max_out,
+                                                                 float conf_thresh, float nms_thresh, float* __restrict__ out) {
+    __shared__ float s_rec[kCap][9];  // odd stride
+    const int b = blockIdx.x, p = threadIdx.x;
+    const float* img = decode + (size_t)b * in_elem;
+    float* dst = out + (size_t)b * (1 + (size_t)max_out * 8);
+    int count = (int)img[0];
+    count = count < max_out ? count : max_out;
+    float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p < count) {
+        const float* it = img + 1 + (size_t)p * det_floats;
+        if (!(it[4] < conf_thresh)) {
+            rec[0] = it[0]; rec[1] = it[1]; rec[2] = it[2]; rec[3] = it[3]; rec[4] = it[4]; rec[5] = it[5]; rec[6] = 1.0f;
+            rec[7] = it[det_floats - 1];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_rec[p][e] = rec[e];
+    __syncthreads();
+    if (p < count) {
+        for (int i = 0; i < count; ++i) {
+            if (i == p || rec[5] != s_rec[i][5]) continue;
+            const float ci = s_rec[i][4];
+            if (ci >= rec[4]) {
+                if (ci == rec[4] && i < p) continue;
+                if (probiou_g(rec, s_rec[i]) > nms_thresh) {
+                    rec[6] = 0.0f;
+                    break;
+                }
+            }
+        }
+    }
+    if (p == 0) dst[0] = (float)count;
+    if (p < max_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[1 + (size_t)p * 8 + e] = rec[e];
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t trtx_yolo_postprocess_gpu(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
@@ -371,7 +484,7 @@ int32_t run_nms(const float* decode_out, int batch, int max_out, int det_floats,
     hipLaunchKernelGGL(yolo_nms_sort_kernel<MODE>, dim3(batch), dim3(kCap), 0, stream, decode_out, out_elem, det_floats, max_out,
                        conf_thresh, ws);
     hipLaunchKernelGGL(yolo_nms_mask_kernel<MODE>, dim3(kBlocks, batch), dim3(kCap), 0, stream, ws, nms_thresh);
-    hipLaunchKernelGGL(yolo_nms_scan_kernel, dim3(batch), dim3(kCap), 0, stream, ws, max_out, keep_idx, keep_cnt, keep_det);
+    hipLaunchKernelGGL(yolo_nms_scan_kernel, dim3(batch), dim3(kCap), 0, stream, ws, max_out, keep_idx, keep_cnt, keep_det, MODE == 2 ? 7 : 6);
     return trtx::check_launch(what);
 }
 }  // namespace
@@ -388,4 +501,22 @@ extern "C" int32_t trtx_yolov5_nms(const float* decode_out, int batch, int max_o
                                    hipStream_t stream) {
     return run_nms<1>(decode_out, batch, max_out, 38, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, workspace, workspace_bytes,
                       stream, "trtx_yolov5_nms");
+}
+
+// nms_obb / batch_nms_obb (yolov8/src/postprocess.cpp:357-393): oriented boxes, ProbIoU.  keep_det: [batch][max_out][7] =
+// cx, cy, w, h, conf, class, angle.
+extern "C" int32_t trtx_yolo_nms_obb(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh, int32_t* keep_idx,
+                                     int32_t* keep_cnt, float* keep_det, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return run_nms<2>(decode_out, batch, max_out, trtx::kYoloDetFloats, conf_thresh, nms_thresh, keep_idx, keep_cnt, keep_det, workspace,
+                      workspace_bytes, stream, "trtx_yolo_nms_obb");
+}
+
+// cuda_decode_obb + cuda_nms_obb (yolov8/src/postprocess.cu:7-40, 144-166, 181-193): out [batch][1 + max_out * 8]
+extern "C" int32_t trtx_yolo_postprocess_gpu_obb(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
+                                                 float* out, hipStream_t stream) {
+    if (!decode_out || !out || batch < 1 || max_out < 1) return TRTX_ERR_INVALID;
+    if (max_out > kCap) return TRTX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(yolo_gpu_post_obb_kernel, dim3(batch), dim3(kCap), 0, stream, decode_out, 1 + max_out * trtx::kYoloDetFloats,
+                       trtx::kYoloDetFloats, max_out, conf_thresh, nms_thresh, out);
+    return trtx::check_launch("trtx_yolo_postprocess_gpu_obb");
 }
