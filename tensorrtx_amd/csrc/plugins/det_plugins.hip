@@ -406,7 +406,10 @@ __global__ __launch_bounds__(1024) void hard_scan_kernel(const uint64_t* __restr
                                                          int n_blk, int stop_after) {
     constexpr int kSlots = kMaskMaxN / 1024;
     __shared__ uint64_t s_keep[kMaskMaxN / 64];
-    __shared__ int s_kept;
+    // kept count AFTER block c, one slot per block: written once by the wave that owns block c before the barrier of iteration c
+    // and never again, so every thread's stop decision of iteration c reads the same value no matter how far other waves have run
+    // ahead (a single running counter could already hold iteration c+1's update when a slow wave gets to read it)
+    __shared__ int s_cum[kMaskMaxN / 64];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* sc = scores + (size_t)b * n;
@@ -418,7 +421,6 @@ __global__ __launch_bounds__(1024) void hard_scan_kernel(const uint64_t* __restr
         const int i = tid + 1024 * s;
         if (i >= n || !(sc[i] > -FLT_MAX)) rem |= 1u << s;
     }
-    if (tid == 0) s_kept = 0;
     __syncthreads();
     int processed = 0;
     for (int c = 0; c < n_blk; ++c) {
@@ -442,12 +444,12 @@ __global__ __launch_bounds__(1024) void hard_scan_kernel(const uint64_t* __restr
             if ((dead >> lane) & 1ull) rem |= 1u << slot;
             if (lane == 0) {
                 s_keep[c] = ~dead;
-                s_kept += __popcll(~dead);
+                s_cum[c] = (c ? s_cum[c - 1] : 0) + __popcll(~dead);
             }
         }
         __syncthreads();
         processed = c + 1;
-        if (stop_after > 0 && s_kept >= stop_after) break;
+        if (stop_after > 0 && s_cum[c] >= stop_after) break;
         const uint64_t keep = s_keep[c];
         if (keep) {
 #pragma unroll

@@ -263,6 +263,10 @@ extern "C" int32_t trtx_layer_set_ints(trtx_network* n, int32_t layer, int32_t p
         dst[0] = v[0];
         dst[1] = count > 1 ? v[1] : v[0];
     };
+    // reject values that shape inference would divide by (SIGFPE inside the C ABI otherwise)
+    if ((param == TRTX_P_STRIDE || param == TRTX_P_DILATION || param == TRTX_P_KERNEL) && (v[0] < 1 || (count > 1 && v[1] < 1))) return TRTX_ERR_INVALID;
+    if (param == TRTX_P_GROUPS && v[0] < 1) return TRTX_ERR_INVALID;
+    if (param == TRTX_P_PADDING && (v[0] < 0 || (count > 1 && v[1] < 0))) return TRTX_ERR_INVALID;
     switch (param) {
         case TRTX_P_STRIDE: two(l.stride); break;
         case TRTX_P_PADDING: two(l.padding); break;

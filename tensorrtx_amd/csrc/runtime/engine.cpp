@@ -11,9 +11,9 @@
 using namespace trtx;
 
 trtx_engine::~trtx_engine() {
-    if (plugins_initialized)
-        for (auto& op : plan.ops)
-            if (op.kind == OP_PLUGIN && op.plugin->v.terminate) op.plugin->v.terminate(op.plugin->v.self);
+    int left = plugins_initialized;  // initialize() ran on the first `plugins_initialized` plugin ops, in plan order
+    for (auto& op : plan.ops)
+        if (op.kind == OP_PLUGIN && left-- > 0 && op.plugin->v.terminate) op.plugin->v.terminate(op.plugin->v.self);
     if (d_weights) (void)hipFree(d_weights);
 }
 
@@ -295,6 +295,13 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         if (st != TRTX_OK) {
             fprintf(stderr, "[trtx_hip] op %zu (%s, %s) failed: %s\n", k, op_kind_name(op.kind), op.name.c_str(),
                     trtx_status_string(st));
+            // leave nothing running behind the caller's back: every lane that was started joins the caller's stream, and the
+            // profiling events are released
+            if (lanes)
+                for (int l = 1; l < plan.num_lanes; ++l)
+                    if (lane_started[l] && hipEventRecord(c->lane_done[l], c->lane_stream[l]) == hipSuccess)
+                        (void)hipStreamWaitEvent(user_stream, c->lane_done[l], 0);
+            for (auto& ev : evs) (void)hipEventDestroy(ev);
             return st;
         }
         if (prof) TRTX_HIP_TRY(hipEventRecord(evs[k + 1], stream));
@@ -385,12 +392,14 @@ extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, t
     }
     e->plan.weight_blob.clear();
     e->plan.weight_blob.shrink_to_fit();
-    for (auto& op : e->plan.ops)
-        if (op.kind == OP_PLUGIN && op.plugin->v.initialize && op.plugin->v.initialize(op.plugin->v.self) != 0) {
+    for (auto& op : e->plan.ops) {
+        if (op.kind != OP_PLUGIN) continue;
+        if (op.plugin->v.initialize && op.plugin->v.initialize(op.plugin->v.self) != 0) {
             fprintf(stderr, "[trtx_hip] plugin %s: initialize() failed\n", op.name.c_str());
-            return TRTX_ERR_UNSUPPORTED;
+            return TRTX_ERR_UNSUPPORTED;  // ~trtx_engine terminates exactly the plugins counted so far
         }
-    e->plugins_initialized = true;
+        ++e->plugins_initialized;
+    }
     *out = e.release();
     return TRTX_OK;
 }

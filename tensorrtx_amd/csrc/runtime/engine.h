@@ -15,7 +15,7 @@ struct trtx_engine {
     trtx::Plan plan;
     std::vector<uint8_t> blob;  // the serialized plan this engine was created from
     void* d_weights = nullptr;
-    bool plugins_initialized = false;
+    int plugins_initialized = 0;  // number of plugin ops (in plan order) whose initialize() succeeded
     ~trtx_engine();
 };
 

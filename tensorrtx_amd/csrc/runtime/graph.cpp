@@ -110,6 +110,9 @@ bool Network::infer(int li) {
             if (x.nb < 3) return fail(this, l.name + ": needs a CHW tensor");
             Dims o = x;
             const int c = x.nb - 3, h = x.nb - 2;
+            for (int a = 0; a < 2; ++a)
+                if (l.stride[a] < 1 || l.kernel[a] < 1 || l.dilation[a] < 1 || l.padding[a] < 0) return fail(this, l.name + ": stride, kernel and dilation must be >= 1, padding >= 0");
+            if ((l.kind == L_CONV || l.kind == L_DECONV) && l.groups < 1) return fail(this, l.name + ": groups must be >= 1");
             for (int a = 0; a < 2; ++a) {
                 const int64_t sz = x.d[h + a];
                 int64_t r;
@@ -372,7 +375,7 @@ struct Reader {
         const uint64_t k = pod<uint64_t>();
         while (pos % 16) ++pos;
         if (off_out) *off_out = pos;
-        if (!ok || pos + k * 4 > n) {
+        if (!ok || pos > n || k > (n - pos) / 4) {  // k * 4 must not wrap
             ok = false;
             return {};
         }
@@ -509,7 +512,7 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
         if (r.ok && l.kind == L_PLUGIN) {
             const std::string type = r.str(), ver = r.str();
             const uint64_t len = r.pod<uint64_t>();
-            if (!r.ok || r.pos + len > r.n) {
+            if (!r.ok || r.pos > r.n || len > r.n - r.pos) {
                 r.ok = false;
                 break;
             }
@@ -528,6 +531,12 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
     }
     if (!r.ok) {
         if (err) *err = "truncated or corrupt plan";
+        return nullptr;
+    }
+    // a plan is data from outside: re-run shape inference so that weight counts, strides and dims are consistent before anything
+    // sizes a buffer from them
+    if (!n->validate()) {
+        if (err) *err = "plan fails validation: " + n->error;
         return nullptr;
     }
     return n;

@@ -1364,17 +1364,24 @@ bool pack_weights(const Network& net, Plan* plan) {
                 for (int co = 0; co < cout; ++co)
                     for (int t = 0; t < cin_logical * a.kh * a.kw; ++t)
                         dst[(size_t)t * cout + co] = l.w0[(size_t)co * cin_logical * a.kh * a.kw + t] * sc[co];
-            } else if (op.igemm && op.from_deconv) {
-                // CKRS [Cin][Cout][kh][kw] -> KCRS of the stand-in 1x1 conv: output channel (r*kw + q)*Cout + co
+            } else if (op.from_deconv) {
+                // CKRS [Cin][Cout][kh][kw] -> KCRS of the stand-in 1x1 conv: output channel (r*kw + q)*Cout + co.  The re-layout
+                // (and the per-sub-position bias) does not depend on which conv kernel runs the stand-in: finalize() may refuse
+                // the MFMA path (kh*kw*Cin < 32, > 2 GB images) and the direct kernel must then see the same KCRS weights.
                 const int taps = l.kernel[0] * l.kernel[1], dc = l.nb_out;
                 std::vector<float> w2((size_t)cout * cin_logical);
                 for (int ci = 0; ci < cin_logical; ++ci)
                     for (int co = 0; co < dc; ++co)
                         for (int t = 0; t < taps; ++t) w2[(size_t)(t * dc + co) * cin_logical + ci] = l.w0[((size_t)ci * dc + co) * taps + t];
                 for (int c = 0; c < cout; ++c) bias[c] = l.w1.empty() ? 0.f : l.w1[c % dc];
-                op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
-                pack_conv_weights_f16(w2.data(), cout, cin_logical, 1, 1, a.CinK, a.bk, sc.data(),
-                                      reinterpret_cast<uint16_t*>(blob.data() + op.w_off));
+                if (op.igemm) {
+                    op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
+                    pack_conv_weights_f16(w2.data(), cout, cin_logical, 1, 1, a.CinK, a.bk, sc.data(),
+                                          reinterpret_cast<uint16_t*>(blob.data() + op.w_off));
+                } else {
+                    op.w_off = reserve((size_t)cout * cin_logical * 4);
+                    pack_conv_weights_f32(w2.data(), cout, cin_logical, 1, 1, sc.data(), reinterpret_cast<float*>(blob.data() + op.w_off));
+                }
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
                 pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.bk, sc.data(),

@@ -74,7 +74,9 @@ extern "C" int32_t trtx_wts_load(const char* path, trtx_wts** out) {
             return TRTX_ERR_IO;
         }
         const long size = strtol(std::string(s, n).c_str(), nullptr, 10);
-        if (size < 0) {
+        // every value takes at least two characters ("0 "): a count the rest of the file cannot hold is a corrupt header, not an
+        // allocation request
+        if (size < 0 || (size_t)size > (size_t)(buf.data() + buf.size() - s) / 2 + 1) {
             delete w;
             return TRTX_ERR_IO;
         }

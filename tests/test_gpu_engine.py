@@ -258,3 +258,24 @@ def test_retinaface_r50_fp16_engine(gpu, hw, batch):
     assert np.array_equal(gc_.cpu().numpy(), rc_)
     for b in range(batch):
         assert np.array_equal(gi_.cpu().numpy()[b, :rc_[b]], ri_[b, :rc_[b]])
+
+
+@pytest.mark.parametrize("cin,cout,fp16", [(16, 8, 1), (24, 16, 1), (64, 32, 1), (16, 8, 0)])
+def test_kernel_equals_stride_deconvolution_small_channel_counts(gpu, cin, cout, fp16):
+    """a 2x2/2 ConvTranspose is lowered to a 1x1 conv + depth-to-space; with Cin 16 / 24 the stand-in conv
+    (K = Cin < 32) does not take the MFMA path and the direct kernel must still see the re-laid-out weights and bias."""
+    import torch.nn.functional as F
+    from tensorrtx_amd import builder
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(2, cin, 9, 7, generator=g)
+    w = torch.randn(cin, cout, 2, 2, generator=g) * 0.2   # CKRS
+    b = torch.randn(cout, generator=g)
+    net = builder.Network(max_batch=2, fp16=bool(fp16))
+    t = net.input("data", (cin, 9, 7))
+    l = net.conv(t, w.numpy(), b.numpy(), stride=2, deconv=True)
+    net.mark_output(net.out(l), "out")
+    plan = net.build()
+    net.close()
+    got = _run(plan, {"data": x.numpy()}, 2, gpu)["out"].reshape(2, cout, 18, 14)
+    ref = F.conv_transpose2d(x.half().float() if fp16 else x, w.half().float() if fp16 else w, b, stride=2)
+    assert (got - ref).abs().max().item() < (2e-2 if fp16 else 1e-4)
