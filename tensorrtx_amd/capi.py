@@ -245,3 +245,37 @@ def conv2d_nhwc_f16(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", re
                                     residual.stride(2) if residual is not None else 0, ACT[act2], _stream()),
           "trtx_op_conv2d_nhwc_f16")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- kINT8 conv (tests / tools)
+def pack_conv_weights_i8(w_kcrs, ch_scale=None):
+    """Host: KCRS fp32 numpy -> (packed int8 [Cout_pad, Kpad], wscale [Cout_pad]) with per-output-channel symmetric scales."""
+    import numpy as np
+    L = lib()
+    w = np.ascontiguousarray(w_kcrs, dtype=np.float32)
+    cout, cin, kh, kw = w.shape
+    cp, kp = ctypes.c_int32(), ctypes.c_int32()
+    check(L.trtx_conv_pack_weights_i8(w.ctypes.data_as(ctypes.c_void_p), cout, cin, kh, kw, None, None, None, ctypes.byref(cp), ctypes.byref(kp)),
+          "trtx_conv_pack_weights_i8 (dims)")
+    packed = np.zeros((cp.value, kp.value), dtype=np.int8)
+    wscale = np.zeros((cp.value,), dtype=np.float32)
+    sc = None if ch_scale is None else np.ascontiguousarray(ch_scale, dtype=np.float32)
+    check(L.trtx_conv_pack_weights_i8(w.ctypes.data_as(ctypes.c_void_p), cout, cin, kh, kw,
+                                      sc.ctypes.data_as(ctypes.c_void_p) if sc is not None else None, packed.ctypes.data_as(ctypes.c_void_p),
+                                      wscale.ctypes.data_as(ctypes.c_void_p), ctypes.byref(cp), ctypes.byref(kp)), "trtx_conv_pack_weights_i8")
+    return packed, wscale
+
+
+def conv2d_nhwc_i8(x_i8, wpacked, cscale, bias, cout, kh, kw, stride, pad, act1="none", out_scale=None, residual=None, res_scale=1.0,
+                   act2="none"):
+    """int8 MFMA conv: x_i8 CUDA int8 [N,H,W,Cin]; returns int8 (out_scale given: quantised with 1/out_scale) or fp16 NHWC."""
+    import torch
+    N, H, W, Cin = x_i8.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.empty((N, Ho, Wo, cout), dtype=torch.int8 if out_scale else torch.float16, device=x_i8.device)
+    res_i8 = residual is not None and residual.dtype == torch.int8
+    check(lib().trtx_op_conv2d_nhwc_i8(_p(x_i8), N, H, W, Cin, x_i8.stride(2), _p(wpacked), _p(cscale), _p(bias), _p(out), 1 if out_scale else 0,
+                                       ctypes.c_float(1.0 / out_scale if out_scale else 0.0), cout, cout, kh, kw, stride, stride, pad, pad, ACT[act1],
+                                       _p(residual), 1 if res_i8 else 0, ctypes.c_float(res_scale), residual.stride(2) if residual is not None else 0,
+                                       ACT[act2], _stream()), "trtx_op_conv2d_nhwc_i8")
+    return out

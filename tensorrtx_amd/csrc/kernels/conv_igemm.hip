@@ -49,6 +49,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int BM = 128;
@@ -105,7 +106,10 @@ __device__ __forceinline__ int swz(int row) {
 
 // TPS = filter taps per k-step: 1 normally; 2 for Cin <= 16 (CinK = 16), where one 32-wide step covers taps 2kt and 2kt+1
 // and the tap a lane fetches depends on which half of the row it fills.
-template <int NFRAG, int BKT, int TPS>
+// I8: int8 activations / weights on v_mfma_i32_16x16x64_i8 (kINT8 engines).  A 64-byte LDS row then holds 64 int8 channels
+// instead of 32 halfs; the host passes the input-side geometry in 2-byte units (see ConvArgs), so the whole operand path
+// below is byte-for-byte the fp16 one - only the MFMA and the epilogue's dequantise / requantise differ.
+template <int NFRAG, int BKT, int TPS, bool I8 = false>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
@@ -276,10 +280,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     };
 
     floatx4 acc[2][NFRAG];
+    intx4 acci[2][NFRAG];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NFRAG; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NFRAG; ++j) {
+            acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            acci[i][j] = intx4{0, 0, 0, 0};
+        }
 
     // fragment read offsets inside a stage: row (lane & 15), logical chunk (lane >> 4) [+ 4 for the second k-slice]
     const int frow = lane & 15;
@@ -293,14 +301,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int h = 0; h < KSUB; ++h) {
-            half8 af[2];
+            if constexpr (I8) {
+                intx4 af[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const intx4*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
-            for (int j = 0; j < NFRAG; ++j) {
-                const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
+                for (int j = 0; j < NFRAG; ++j) {
+                    const intx4 bf = *reinterpret_cast<const intx4*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) acci[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf, af[i], acci[i][j], 0, 0, 0);
+                }
+            } else {
+                half8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
     };
@@ -345,6 +365,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     const int ch_in = (lane >> 4) * 4;
     const bool second = res || p.act2 != ACT_NONE;
     if (dbg & 8) return;
+    if constexpr (I8) {  // int32 sums -> real values: acc * (input scale * weight scale of the channel)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) {
+            const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
+            const float c4[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = (float)acci[i][j][e] * c4[e];
+        }
+    }
     if (!p.scalar_out) {
         constexpr int RS = BN * 2 + 16;  // padded row stride: 16 consecutive rows start in distinct bank groups
         static_assert(4 * 32 * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
@@ -382,11 +413,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
                 half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
                 if (second) {
                     half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                    if (res) {
+                        if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
+                            const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rv[e] = (_Float16)((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
+                        } else {
+                            rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (_Float16)act_fixed<ACT>((float)v[e] + (float)rv[e], p.act2, p.alpha2);
                 }
-                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+                if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
+                    unsigned long long q = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = rintf((float)v[e] * p.out_inv_scale);
+                        t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+                        q |= (unsigned long long)(unsigned char)(int8_t)(int)t << (8 * e);
+                    }
+                    *reinterpret_cast<unsigned long long*>(static_cast<int8_t*>(p.out) + (size_t)m * p.ld_out + co) = q;
+                } else {
+                    *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+                }
             }
         };
         dispatch_act(p.act2, stage2);
@@ -645,7 +695,7 @@ void launch_wsk(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStrea
                        chunk);
 }
 
-template <int NFRAG, int BKT, int TPS>
+template <int NFRAG, int BKT, int TPS, bool I8 = false>
 void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int BN = 16 * NFRAG;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
@@ -653,18 +703,18 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
     const int chunk = plain ? 0 : (total + 7) / 8;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes,
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes,
                        tiles_n, total, chunk, dbg);
 }
 
-template <int BKT, int TPS>
+template <int BKT, int TPS, bool I8 = false>
 int32_t launch_bn(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     switch (a.bn) {
-        case 16: launch<1, BKT, TPS>(a, in_bytes, w_bytes, s); break;
-        case 32: launch<2, BKT, TPS>(a, in_bytes, w_bytes, s); break;
-        case 64: launch<4, BKT, TPS>(a, in_bytes, w_bytes, s); break;
-        case 80: launch<5, BKT, TPS>(a, in_bytes, w_bytes, s); break;
-        case 128: launch<8, BKT, TPS>(a, in_bytes, w_bytes, s); break;
+        case 16: launch<1, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
+        case 32: launch<2, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
+        case 64: launch<4, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
+        case 80: launch<5, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
+        case 128: launch<8, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return TRTX_OK;
@@ -698,6 +748,8 @@ int conv_igemm_pick_cink(int cin, int bk) {
 }
 
 bool conv_igemm_supported(const ConvArgs& a) {
+    if (a.in_i8 && (a.bk != 32 || a.CinK % 32 || a.scalar_out || !a.cscale)) return false;  // int8: 64-channel k-steps, vector epilogue
+    if ((a.out_i8 || a.res_i8) && a.scalar_out) return false;
     const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
     const int bk = a.CinK % 64 == 0 && a.bk == 64 ? 64 : 32;
     const bool cink_ok = a.CinK % bk == 0 || (a.CinK == 16 && bk == 32);
@@ -708,7 +760,8 @@ bool conv_igemm_supported(const ConvArgs& a) {
 
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     if (!conv_igemm_supported(a0)) return TRTX_ERR_UNSUPPORTED;
-    if (conv_ws_supported(a0)) return conv_ws_f16(a0, s);  // small-channel 3x3 / 1x1: weight-stationary persistent kernel
+    // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel
+    if (!a0.in_i8 && !a0.out_i8 && !a0.res_i8 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
@@ -718,15 +771,17 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         a.N = std::min(per, a0.N - n0);
         a.M = a.N * a.Ho * a.Wo;
         a.in = static_cast<const char*>(a0.in) + (size_t)n0 * img_in;
-        a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * 2;
-        if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * 2;
+        a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * (a0.out_i8 ? 1 : 2);
+        if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * (a0.res_i8 ? 1 : 2);
         // extent of the addressed slice: last pixel's first byte + the channels this conv reads
         const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 2);
         // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel)
         static const bool no_wsk = getenv("TRTX_CONV_NOWSK") != nullptr;  // A/B switch for the micro-benchmarks
         const int tiles128 = ((a.M + BM - 1) / BM) * (a.Cout_pad / a.bn);
         int32_t st = TRTX_OK;
-        if (!no_wsk && a.bk == 32 && a.CinK % 32 == 0 && tiles128 <= 256 && a.Kpad / 32 >= 16 && (a.bn == 64 || a.bn == 80)) {
+        if (a.in_i8) {
+            st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
+        } else if (!no_wsk && !a.out_i8 && !a.res_i8 && a.bk == 32 && a.CinK % 32 == 0 && tiles128 <= 256 && a.Kpad / 32 >= 16 && (a.bn == 64 || a.bn == 80)) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);
         } else {

@@ -32,6 +32,14 @@ struct ConvArgs {
     int CinK;        // igemm: per-tap stride of the packed K axis: Cin rounded up to bk, or 16 (two taps per step);
                      // Kpad = kh*kw*CinK rounded up to bk
     int bk;          // igemm: k-step width in halfs (32, or 64 when CinK % 64 == 0)
+    // INT8 (kINT8 engines, conv_igemm only).  in_i8: activations and weights are int8, accumulated by v_mfma_i32_16x16x64_i8;
+    // the input-side fields Cin, ld_in, CinK, K, Kpad are then counted in PAIRS of int8 channels (= 2-byte units), so that
+    // every byte offset the kernel derives is the one the fp16 kernel would derive; Cout / ld_out / ld_res stay in channels.
+    // out = act(acc * cscale[c] + bias[c]) with cscale[c] = input_scale * weight_scale[c]; out_i8: quantised with out_inv_scale
+    // (round to nearest even, clamp +-127); res_i8: the residual is int8 with scale res_scale.
+    int in_i8, out_i8, res_i8;
+    const float* cscale;   // [Cout_pad]
+    float out_inv_scale, res_scale;
 };
 
 // --- conv -------------------------------------------------------------------------------------------
@@ -40,6 +48,10 @@ int conv_igemm_pick_bn(int cout);   // column-tile width for a Cout
 int conv_igemm_pick_bk(int cin, int taps);  // k-step width for a (padded-to-8) Cin and kh*kw filter taps
 int conv_igemm_pick_cink(int cin, int bk);  // per-tap stride of the packed K axis
 bool conv_igemm_supported(const ConvArgs& a);
+// int8 weight packing: per-output-channel symmetric scales (max |w| / 127 after the BN scale is folded in), same [Cout_pad][Kpad]
+// row layout as the fp16 packing with CinK = Cin rounded up to 64 channels; wscale_out[Cout_pad]
+void conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw, int cink, const float* ch_scale, int cout_pad, int kpad,
+                          int8_t* packed, float* wscale_out);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it

@@ -93,6 +93,49 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     return st;
 }
 
+// --- kINT8 conv, test / tool entry points.  Packed dims: cink = Cin rounded up to 64 channels, kpad = kh*kw*cink (bytes per row).
+extern "C" int32_t trtx_conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw, const float* ch_scale, int8_t* packed,
+                                             float* wscale_out, int32_t* cout_pad_out, int32_t* kpad_out) {
+    if (!w_kcrs || cout < 1 || cin < 1) return TRTX_ERR_INVALID;
+    const int bn = conv_igemm_pick_bn(cout);
+    const int cout_pad = (cout + bn - 1) / bn * bn, cink = (cin + 63) / 64 * 64, kpad = kh * kw * cink;
+    if (cout_pad_out) *cout_pad_out = cout_pad;
+    if (kpad_out) *kpad_out = kpad;
+    if (packed && wscale_out) conv_pack_weights_i8(w_kcrs, cout, cin, kh, kw, cink, ch_scale, cout_pad, kpad, packed, wscale_out);
+    return TRTX_OK;
+}
+
+// in: int8 NHWC [N,H,W,ld_in]; out: int8 (out_inv_scale > 0) or fp16 NHWC; cscale[Cout_pad] = input scale * weight scale
+extern "C" int32_t trtx_op_conv2d_nhwc_i8(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked, const float* cscale,
+                                          const float* bias, void* out, int out_is_i8, float out_inv_scale, int Cout, int ld_out, int kh,
+                                          int kw, int sh, int sw, int ph, int pw, int act1, const void* residual, int res_is_i8,
+                                          float res_scale, int ld_res, int act2, trtx_stream_t stream) {
+    if (Cin % 16 || ld_in % 16) return TRTX_ERR_INVALID;
+    ConvArgs a{};
+    a.in = in; a.wgt = wpacked; a.bias = bias; a.out = out; a.residual = residual;
+    a.N = N; a.H = H; a.W = W;
+    a.Ho = (H + 2 * ph - kh) / sh + 1;
+    a.Wo = (W + 2 * pw - kw) / sw + 1;
+    a.Cout = Cout;
+    a.bn = conv_igemm_pick_bn(Cout);
+    a.Cout_pad = (Cout + a.bn - 1) / a.bn * a.bn;
+    a.ld_out = ld_out; a.ld_res = ld_res;
+    a.kh = kh; a.kw = kw; a.stride_h = sh; a.stride_w = sw; a.pad_h = ph; a.pad_w = pw; a.dil_h = 1; a.dil_w = 1; a.groups = 1;
+    a.bk = 32;
+    const int cink = (Cin + 63) / 64 * 64;
+    a.in_i8 = 1; a.out_i8 = out_is_i8; a.res_i8 = res_is_i8;
+    a.cscale = cscale; a.out_inv_scale = out_inv_scale; a.res_scale = res_scale;
+    // input-side geometry in 2-byte units (pairs of int8 channels)
+    a.Cin = Cin / 2; a.ld_in = ld_in / 2; a.CinK = cink / 2;
+    a.K = kh * kw * a.CinK;
+    a.Kpad = a.K;
+    a.M = N * a.Ho * a.Wo;
+    a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
+    a.scalar_out = 0;
+    if (Cout % 8 || ld_out % 8 || (residual && ld_res % 8)) return TRTX_ERR_UNSUPPORTED;
+    return conv_igemm_f16(a, stream);
+}
+
 extern "C" int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad,
                                                 int ld_out, trtx_stream_t stream) {
     return nchw_f32_to_nhwc(in, out, DT_F16, N, C, H, W, Cpad, ld_out, stream);

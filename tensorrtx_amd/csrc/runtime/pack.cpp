@@ -1,5 +1,6 @@
 #include "pack.h"
 
+#include <math.h>
 #include <string.h>
 
 #include "../kernels/kernels.h"
@@ -35,6 +36,35 @@ void pack_conv_weights_f16(const float* w, int cout, int cin, int kh, int kw, in
                 }
     }
 }
+
+}  // namespace trtx
+
+// kINT8: per-output-channel symmetric quantisation of the (BN-folded) weights, rows [Cout_pad][Kpad] with k = tap * cink + c
+void trtx::conv_pack_weights_i8(const float* w, int cout, int cin, int kh, int kw, int cink, const float* ch_scale, int cout_pad, int kpad,
+                                int8_t* packed, float* wscale_out) {
+    memset(packed, 0, (size_t)cout_pad * kpad);
+    for (int co = 0; co < cout_pad; ++co) wscale_out[co] = 1.0f;
+    for (int co = 0; co < cout; ++co) {
+        const float sc = ch_scale ? ch_scale[co] : 1.0f;
+        float amax = 0.f;
+        const size_t n = (size_t)cin * kh * kw;
+        for (size_t i = 0; i < n; ++i) {
+            const float v = fabsf(w[(size_t)co * n + i] * sc);
+            amax = v > amax ? v : amax;
+        }
+        const float s = amax > 0.f ? amax / 127.0f : 1.0f;
+        wscale_out[co] = s;
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int q = 0; q < kw; ++q) {
+                    float t = nearbyintf(w[(((size_t)co * cin + c) * kh + r) * kw + q] * sc / s);
+                    t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+                    packed[(size_t)co * kpad + (size_t)(r * kw + q) * cink + c] = (int8_t)t;
+                }
+    }
+}
+
+namespace trtx {
 
 void pack_conv_weights_f32(const float* w, int cout, int cin_g, int kh, int kw, const float* ch_scale, float* packed) {
     for (int co = 0; co < cout; ++co) {
