@@ -121,9 +121,25 @@ class IProfiler {
     virtual ~IProfiler() = default;
 };
 
+// INT8 calibration interfaces (the reference: yolov8/include/calibrator.h:14-36, yolov8/src/calibrator.cpp:9-74,
+// retinaface/calibrator.h).  getBatch hands DEVICE pointers for the named inputs; the cache is opaque text owned by the runtime.
+enum class CalibrationAlgoType : int32_t { kLEGACY_CALIBRATION = 0, kENTROPY_CALIBRATION = 1, kENTROPY_CALIBRATION_2 = 2, kMINMAX_CALIBRATION = 3 };
 class IInt8Calibrator {
    public:
+    virtual int32_t getBatchSize() const noexcept = 0;
+    virtual bool getBatch(void* bindings[], const char* names[], int32_t nbBindings) noexcept = 0;
+    virtual const void* readCalibrationCache(size_t& length) noexcept = 0;
+    virtual void writeCalibrationCache(const void* ptr, size_t length) noexcept = 0;
+    virtual CalibrationAlgoType getAlgorithm() noexcept = 0;
     virtual ~IInt8Calibrator() = default;
+};
+class IInt8EntropyCalibrator2 : public IInt8Calibrator {
+   public:
+    CalibrationAlgoType getAlgorithm() noexcept override { return CalibrationAlgoType::kENTROPY_CALIBRATION_2; }
+};
+class IInt8EntropyCalibrator : public IInt8Calibrator {
+   public:
+    CalibrationAlgoType getAlgorithm() noexcept override { return CalibrationAlgoType::kENTROPY_CALIBRATION; }
 };
 class IGpuAllocator;
 
@@ -817,7 +833,19 @@ class IBuilderConfig {
     void setMemoryPoolLimit(MemoryPoolType, size_t bytes) noexcept { trtx_builder_set_workspace(mB, bytes); }
     void setFlag(BuilderFlag f) noexcept { trtx_builder_set_flag(mB, (int32_t)f, 1); }
     void clearFlag(BuilderFlag f) noexcept { trtx_builder_set_flag(mB, (int32_t)f, 0); }
-    void setInt8Calibrator(IInt8Calibrator*) noexcept {}
+    void setInt8Calibrator(IInt8Calibrator* c) noexcept {
+        trtx_calibrator_vtbl v{};
+        if (c) {
+            v.self = c;
+            v.get_batch_size = [](void* s) -> int32_t { return static_cast<IInt8Calibrator*>(s)->getBatchSize(); };
+            v.get_batch = [](void* s, void** bindings, const char* const* names, int32_t nb) -> int32_t {
+                return static_cast<IInt8Calibrator*>(s)->getBatch(bindings, const_cast<const char**>(names), nb) ? 1 : 0;
+            };
+            v.read_cache = [](void* s, size_t* len) -> const void* { return static_cast<IInt8Calibrator*>(s)->readCalibrationCache(*len); };
+            v.write_cache = [](void* s, const void* p, size_t len) { static_cast<IInt8Calibrator*>(s)->writeCalibrationCache(p, len); };
+        }
+        trtx_builder_set_int8_calibrator(mB, c ? &v : nullptr);
+    }
 
    private:
     trtx_builder* mB;
@@ -837,7 +865,7 @@ class IBuilder {
     INetworkDefinition* createNetwork() noexcept { return createNetworkV2(0U); }
     void setMaxBatchSize(int32_t n) noexcept { trtx_builder_set_max_batch(mB, n); }
     bool platformHasFastFp16() const noexcept { return true; }
-    bool platformHasFastInt8() const noexcept { return false; }  // INT8 path not implemented yet
+    bool platformHasFastInt8() const noexcept { return true; }  // v_mfma_i32_16x16x64_i8
     IHostMemory* buildSerializedNetwork(INetworkDefinition& net, IBuilderConfig&) noexcept {
         trtx_hostmem* m = nullptr;
         if (trtx_build_serialized(mB, net.handle(), &m) != TRTX_OK) return nullptr;

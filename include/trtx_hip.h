@@ -384,6 +384,22 @@ void trtx_builder_destroy(trtx_builder* b);
 int32_t trtx_builder_set_max_batch(trtx_builder* b, int32_t n);        /* IBuilder::setMaxBatchSize */
 int32_t trtx_builder_set_flag(trtx_builder* b, int32_t flag, int32_t on); /* IBuilderConfig::setFlag */
 int32_t trtx_builder_set_workspace(trtx_builder* b, size_t bytes);     /* setMaxWorkspaceSize / setMemoryPoolLimit */
+/* IBuilderConfig::setInt8Calibrator (yolov8/src/model.cpp:317-324): the calibrator as a C v-table, IInt8EntropyCalibrator2's
+ * methods (yolov8/include/calibrator.h:14-36).  With BuilderFlag::kINT8, trtx_build_serialized first asks read_cache; if that
+ * yields a cache the scales come from it (no GPU needed), otherwise get_batch is called until it returns 0, every batch runs
+ * through an fp16 engine of the network on the GPU, per-tensor |x| histograms are reduced to thresholds by entropy minimisation
+ * and the resulting cache text is handed to write_cache. */
+typedef struct trtx_calibrator_vtbl {
+    void* self;
+    int32_t (*get_batch_size)(void* self);
+    /* fills bindings[i] with the DEVICE pointer of input names[i] for one batch; returns 1, or 0 when the data is exhausted */
+    int32_t (*get_batch)(void* self, void** bindings, const char* const* names, int32_t nb_bindings);
+    const void* (*read_cache)(void* self, size_t* length); /* NULL / length 0: no cache */
+    void (*write_cache)(void* self, const void* cache, size_t length);
+} trtx_calibrator_vtbl;
+int32_t trtx_builder_set_int8_calibrator(trtx_builder* b, const trtx_calibrator_vtbl* calibrator);
+/* the threshold search of the entropy calibration on a caller-supplied histogram of |x| over [0, range] (tests, tools) */
+float trtx_int8_entropy_threshold(const double* hist, int32_t bins, float range);
 /* createNetworkV2(flags): bit 0 = kEXPLICIT_BATCH */
 int32_t trtx_network_create(trtx_builder* b, uint32_t flags, trtx_network** out);
 void trtx_network_destroy(trtx_network* n);

@@ -748,7 +748,7 @@ int conv_igemm_pick_cink(int cin, int bk) {
 }
 
 bool conv_igemm_supported(const ConvArgs& a) {
-    if (a.in_i8 && (a.bk != 32 || a.CinK % 32 || a.scalar_out || !a.cscale)) return false;  // int8: 64-channel k-steps, vector epilogue
+    if (a.in_i8 && (a.bk != 32 || a.CinK % 32 || a.scalar_out)) return false;  // int8: 64-channel k-steps, vector epilogue
     if ((a.out_i8 || a.res_i8) && a.scalar_out) return false;
     const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
     const int bk = a.CinK % 64 == 0 && a.bk == 64 ? 64 : 32;
@@ -759,7 +759,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
 }
 
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
-    if (!conv_igemm_supported(a0)) return TRTX_ERR_UNSUPPORTED;
+    if (!conv_igemm_supported(a0) || (a0.in_i8 && !a0.cscale)) return TRTX_ERR_UNSUPPORTED;
     // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel
     if (!a0.in_i8 && !a0.out_i8 && !a0.res_i8 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.

@@ -9,7 +9,8 @@
 namespace trtx {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SILU = 3, ACT_LEAKY = 4, ACT_TANH = 5 };
-enum DType : int { DT_F32 = 0, DT_F16 = 1 };
+enum DType : int { DT_F32 = 0, DT_F16 = 1, DT_I8 = 2 };
+inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_I8 ? 1 : 4); }
 enum EwOp : int { EW_SUM = 0, EW_PROD = 1, EW_MAX = 2, EW_MIN = 3, EW_SUB = 4, EW_DIV = 5, EW_POW = 6 };
 enum PoolOp : int { POOL_MAX = 0, POOL_AVG = 1 };
 
@@ -93,6 +94,12 @@ int32_t nhwc_copy(const void* in, void* out, int dtype, long pixels, int C, int 
 // mean over H*W: NHWC [N][H][W][C] -> NHWC [N][1][1][C]
 int32_t nhwc_reduce_hw_avg(const void* in, void* out, int dtype, int N, int HW, int C, int ld_in, int ld_out,
                            hipStream_t s);
+
+// --- INT8 support (quant_ops.hip): calibration statistics over NHWC fp16 tensors, int8 resize with requantisation
+int32_t nhwc_absmax_f16(const void* x, long pixels, int C, int ld, unsigned* out_float_bits, hipStream_t s);  // atomicMax of the float bits
+int32_t nhwc_hist_f16(const void* x, long pixels, int C, int ld, float range, unsigned long long* hist2048, hipStream_t s);
+int32_t nhwc_resize_nearest_i8(const void* in, void* out, int N, int H, int W, int C, int ld_in, int Ho, int Wo, int ld_out, float ratio,
+                               hipStream_t s);
 
 // --- LINEAR fp32 ops (rank <= 6, row-major, batch outermost) -----------------------------------------------
 struct StridedView {

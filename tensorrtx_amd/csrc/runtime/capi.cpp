@@ -5,6 +5,7 @@
 
 #include "../common.h"
 #include "graph.h"
+#include "int8.h"
 #include "plan.h"
 #include "plugin.h"
 
@@ -15,6 +16,7 @@ struct trtx_builder {
     bool fp16 = false;
     bool int8 = false;
     size_t workspace = 0;
+    trtx_calibrator_vtbl calib{};  // IBuilderConfig::setInt8Calibrator
 };
 
 struct trtx_network {
@@ -54,6 +56,11 @@ extern "C" int32_t trtx_builder_set_flag(trtx_builder* b, int32_t flag, int32_t 
         b->int8 = on != 0;
     else
         return TRTX_ERR_INVALID;
+    return TRTX_OK;
+}
+extern "C" int32_t trtx_builder_set_int8_calibrator(trtx_builder* b, const trtx_calibrator_vtbl* calibrator) {
+    if (!b) return TRTX_ERR_INVALID;
+    b->calib = calibrator ? *calibrator : trtx_calibrator_vtbl{};
     return TRTX_OK;
 }
 extern "C" int32_t trtx_builder_set_workspace(trtx_builder* b, size_t bytes) {
@@ -336,12 +343,10 @@ extern "C" int32_t trtx_mark_output(trtx_network* n, int32_t tensor) {
 
 extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_hostmem** out) {
     if (!b || !n || !out) return TRTX_ERR_INVALID;
-    if (b->int8) {
-        fprintf(stderr, "[trtx_hip] BuilderFlag::kINT8 is not implemented (SURVEY.md §8 f3); build fp16 or fp32\n");
-        return TRTX_ERR_UNSUPPORTED;
-    }
     n->net.max_batch = b->max_batch;
     n->net.fp16 = b->fp16;
+    n->net.int8 = false;
+    n->net.tensor_scale.clear();
     if (n->net.output_ids().empty()) {
         n->net.error = "network has no outputs";
         return TRTX_ERR_STATE;
@@ -349,6 +354,37 @@ extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_
     if (!n->net.validate()) {
         fprintf(stderr, "[trtx_hip] buildSerializedNetwork: %s\n", n->net.error.c_str());
         return TRTX_ERR_INVALID;
+    }
+    if (b->int8) {
+        // kINT8 (yolov8/src/model.cpp:317-324): activation scales from the calibrator's cache, or from a calibration run on the GPU.
+        // Layers that cannot run in int8 fall back to fp16 (the engine is built as fp16 + int8).
+        n->net.fp16 = true;
+        bool have = false;
+        if (b->calib.read_cache) {
+            size_t len = 0;
+            const void* cache = b->calib.read_cache(b->calib.self, &len);
+            if (cache && len) {
+                std::string err;
+                if (!read_calibration_cache(cache, len, &n->net, &err)) {
+                    fprintf(stderr, "[trtx_hip] buildSerializedNetwork: %s\n", err.c_str());
+                    return TRTX_ERR_IO;
+                }
+                have = true;
+            }
+        }
+        if (!have) {
+            if (!b->calib.get_batch) {
+                fprintf(stderr, "[trtx_hip] buildSerializedNetwork: BuilderFlag::kINT8 needs setInt8Calibrator (batches or a calibration cache)\n");
+                return TRTX_ERR_STATE;
+            }
+            const int32_t st = run_int8_calibration(&n->net, b->calib);
+            if (st != TRTX_OK) return st;
+            if (b->calib.write_cache) {
+                const std::string text = write_calibration_cache(n->net);
+                b->calib.write_cache(b->calib.self, text.data(), text.size());
+            }
+        }
+        n->net.int8 = true;
     }
     // validate by lowering once on the host (no device needed): unsupported graphs fail at build time
     Plan plan;
@@ -361,4 +397,10 @@ extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_
     n->net.serialize(blob);
     *out = trtx_hostmem_from(std::move(blob));
     return TRTX_OK;
+}
+
+// test hook: the entropy threshold search of the INT8 calibration (int8.cpp) on a caller-supplied |x| histogram
+extern "C" float trtx_int8_entropy_threshold(const double* hist, int32_t bins, float range) {
+    if (!hist || bins < 128) return 0.f;
+    return entropy_threshold(std::vector<double>(hist, hist + bins), range);
 }

@@ -6,6 +6,7 @@
 #include <sstream>
 
 #include "../common.h"
+#include "int8.h"
 #include "plugin.h"
 
 using namespace trtx;
@@ -54,7 +55,7 @@ struct Resolver {
     }
     void* ptr(int tid) const {
         const PTensor& t = plan.tensors[tid];
-        const size_t es = t.dtype == DT_F16 ? 2 : 4;
+        const size_t es = dtype_size(t.dtype);
         return base(t) + (t.layout == LAY_NHWC ? (size_t)t.rcoff : (size_t)t.reoff) * es;
     }
 };
@@ -100,7 +101,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
     // lanes: independent branches of the plan run on the context's own streams, fenced by events (profiling runs
     // everything on the caller's stream so that the per-op events measure isolated kernels)
     hipStream_t const user_stream = stream;
-    const bool lanes = !prof && plan.num_lanes > 1;
+    const bool lanes = !prof && !c->observer && plan.num_lanes > 1;  // calibration statistics are collected on one stream
     std::vector<char> lane_started(plan.num_lanes, 0);
     if (lanes) TRTX_HIP_TRY(hipEventRecord(c->start_event, user_stream));
     for (size_t k = 0; k < plan.ops.size(); ++k) {
@@ -129,6 +130,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 a.residual = op.in.size() > 1 ? R.ptr(op.in[1]) : nullptr;
                 a.wgt = W + op.w_off;
                 a.bias = reinterpret_cast<const float*>(W + op.b_off);
+                a.cscale = a.in_i8 ? reinterpret_cast<const float*>(W + op.s_off) : nullptr;
                 a.N = op.stem ? batch : nb(t0);
                 a.M = a.N * a.Ho * a.Wo;
                 if (op.kind == OP_DECONV)
@@ -156,6 +158,11 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                                              to.ld, stream);
                 break;
             case OP_RESIZE:
+                if (t0.dtype == DT_I8) {  // int8 in place; requantised when the two owners were calibrated to different scales
+                    st = nhwc_resize_nearest_i8(R.ptr(op.in[0]), R.ptr(op.out[0]), nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H, to.W, to.ld,
+                                                t0.scale / to.scale, stream);
+                    break;
+                }
                 st = nhwc_resize_nearest(R.ptr(op.in[0]), R.ptr(op.out[0]), op.dtype, nb(t0), t0.H, t0.W, t0.C, t0.ld, to.H,
                                          to.W, to.ld, stream);
                 break;
@@ -303,6 +310,19 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                         (void)hipStreamWaitEvent(user_stream, c->lane_done[l], 0);
             for (auto& ev : evs) (void)hipEventDestroy(ev);
             return st;
+        }
+        if (c->observer) {  // INT8 calibration: |x| maximum or histogram of every fp16 NHWC tensor this op wrote, per owning storage
+            for (int t : op.out) {
+                const PTensor& pt = plan.tensors[t];
+                if (pt.layout != LAY_NHWC || pt.dtype != DT_F16 || pt.C % 8 || pt.ld % 8) continue;
+                const long pixels = (long)nb(pt) * pt.H * pt.W;
+                CalibObserver& ob = *c->observer;
+                if (ob.mode == 1)
+                    st = nhwc_absmax_f16(R.ptr(t), pixels, pt.C, pt.ld, ob.d_max + pt.storage, stream);
+                else if (ob.mode == 2 && ob.range[pt.storage] > 0.f)
+                    st = nhwc_hist_f16(R.ptr(t), pixels, pt.C, pt.ld, ob.range[pt.storage], ob.d_hist + (size_t)pt.storage * kCalibBins, stream);
+                if (st != TRTX_OK) return st;
+            }
         }
         if (prof) TRTX_HIP_TRY(hipEventRecord(evs[k + 1], stream));
         if (lanes && op.signal) TRTX_HIP_TRY(hipEventRecord(c->op_event[k], stream));

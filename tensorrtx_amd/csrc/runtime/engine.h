@@ -19,6 +19,10 @@ struct trtx_engine {
     ~trtx_engine();
 };
 
+namespace trtx {
+struct CalibObserver;
+}
+
 struct trtx_context {
     trtx_engine* engine = nullptr;
     void* d_arena = nullptr;
@@ -39,6 +43,7 @@ struct trtx_context {
     std::vector<CapturedGraph> graphs;
     std::vector<CapturedGraph> seen;   // combinations enqueued once (eagerly) so far
     uint64_t enqueue_count = 0;
+    struct trtx::CalibObserver* observer = nullptr;  // INT8 calibration run: statistics of every NHWC tensor written (int8.h)
     int graph_state = 0;   // 0 undecided, 1 eligible, -1 never (user plugins, capture failed once, disabled)
     ~trtx_context();
 };

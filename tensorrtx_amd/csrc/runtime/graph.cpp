@@ -393,9 +393,12 @@ void Network::serialize(std::vector<uint8_t>& out, std::vector<std::array<size_t
     Writer w{out};
     if (w_offsets) w_offsets->assign(layers.size(), {0, 0, 0});
     w.raw(kMagic, 8);
-    w.pod<uint32_t>(1);  // format version
+    w.pod<uint32_t>(2);  // format version (2: + int8 flag and per-tensor calibration scales)
     w.pod<uint8_t>(explicit_batch);
     w.pod<uint8_t>(fp16);
+    w.pod<uint8_t>(int8);
+    w.pod<uint32_t>((uint32_t)tensor_scale.size());
+    for (float sc : tensor_scale) w.pod<float>(sc);
     w.pod<int32_t>(max_batch);
     w.pod<uint32_t>((uint32_t)tensors.size());
     for (const auto& t : tensors) {
@@ -456,13 +459,23 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
         if (err) *err = "not a trtx plan (bad magic)";
         return nullptr;
     }
-    if (r.pod<uint32_t>() != 1) {
+    const uint32_t version = r.pod<uint32_t>();
+    if (version != 1 && version != 2) {
         if (err) *err = "unsupported plan version";
         return nullptr;
     }
     const bool eb = r.pod<uint8_t>();
     std::unique_ptr<Network> n(new Network(eb ? 1u : 0u));
     n->fp16 = r.pod<uint8_t>();
+    if (version >= 2) {
+        n->int8 = r.pod<uint8_t>();
+        const uint32_t ns = r.pod<uint32_t>();
+        if (!r.ok || ns > (r.n - r.pos) / 4) {
+            if (err) *err = "truncated or corrupt plan";
+            return nullptr;
+        }
+        for (uint32_t i = 0; i < ns; ++i) n->tensor_scale.push_back(r.pod<float>());
+    }
     n->max_batch = r.pod<int32_t>();
     const uint32_t nt = r.pod<uint32_t>();
     for (uint32_t i = 0; r.ok && i < nt; ++i) {
@@ -575,7 +588,7 @@ std::string Network::describe_json() const {
         serialize(tmp, &offs);
     }
     std::ostringstream o;
-    o << "{\"explicit_batch\":" << (explicit_batch ? "true" : "false") << ",\"fp16\":" << (fp16 ? "true" : "false")
+    o << "{\"explicit_batch\":" << (explicit_batch ? "true" : "false") << ",\"fp16\":" << (fp16 ? "true" : "false") << ",\"int8\":" << (int8 ? "true" : "false")
       << ",\"max_batch\":" << max_batch << ",\"tensors\":[";
     for (size_t i = 0; i < tensors.size(); ++i) {
         const auto& t = tensors[i];

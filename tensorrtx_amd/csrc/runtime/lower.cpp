@@ -1019,7 +1019,7 @@ struct Lowerer {
     }
 
     size_t tensor_bytes(const PTensor& t) const {
-        const size_t es = t.dtype == DT_F16 ? 2 : 4;
+        const size_t es = dtype_size(t.dtype);
         if (t.layout == LAY_NHWC) {
             const size_t n = (t.nfix ? (size_t)t.nfix : (size_t)plan.max_batch) * (size_t)t.nmul;
             return n * t.H * t.W * (size_t)t.Calloc * es;
@@ -1027,7 +1027,72 @@ struct Lowerer {
         return (t.batched ? (size_t)plan.max_batch : 1) * (size_t)t.dims.volume() * es;
     }
 
+    // kINT8: which NHWC tensors live in int8.  An owning tensor (a conv output, or a concat buffer several producers write
+    // slices of) becomes int8 when it has a calibrated scale and EVERY op touching it can work on int8 in place: MFMA-eligible
+    // convolutions (as producer, consumer or residual) and nearest resizes.  Anything else (pool chains, the fused detect
+    // head, layout conversions, plugins, depth-to-space ...) keeps the tensor in fp16, and a convolution simply dequantises /
+    // requantises at that boundary in its epilogue.  The scale is a property of the OWNER, so all producers of a concat
+    // buffer quantise to the same scale (TensorRT reaches the same end by forcing equal scales on concat inputs).
+    void assign_int8() {
+        if (!net.int8 || dt != DT_F16) return;
+        const int nt = (int)plan.tensors.size();
+        auto top = [&](int t) {
+            while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
+            return t;
+        };
+        std::vector<char> cand(nt, 0);
+        for (const PTensor& t : plan.tensors)
+            if (t.parent < 0 && t.layout == LAY_NHWC && t.dtype == DT_F16 && t.net_tensor >= 0 && t.net_tensor < (int)net.tensor_scale.size() &&
+                net.tensor_scale[t.net_tensor] > 0.f && t.C % 16 == 0 && t.nmul == 1 && !is_binding_tensor(t.id))
+                cand[t.id] = 1;
+        auto view_ok = [&](int t) {
+            int off = 0;
+            owner_of(t, &off);
+            return off % 16 == 0 && plan.tensors[t].C % 16 == 0;
+        };
+        auto conv_ok = [&](const POp& op) {
+            const ConvArgs& a = op.conv;
+            return op.kind == OP_CONV && !op.stem && !op.from_deconv && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= 30;
+        };
+        for (const POp& op : plan.ops) {
+            for (size_t j = 0; j < op.in.size(); ++j) {
+                const PTensor& t = plan.tensors[op.in[j]];
+                if (t.layout != LAY_NHWC) continue;
+                bool ok = false;
+                if (conv_ok(op)) ok = view_ok(op.in[j]) && (j > 0 || op.conv.kh * op.conv.kw * t.C >= 32);
+                else if (op.kind == OP_RESIZE) ok = view_ok(op.in[j]);
+                if (!ok) cand[top(op.in[j])] = 0;
+            }
+            for (int o : op.out) {
+                if (plan.tensors[o].layout != LAY_NHWC) continue;
+                const bool ok = (conv_ok(op) || op.kind == OP_RESIZE) && view_ok(o);
+                if (!ok) cand[top(o)] = 0;
+            }
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            auto tie = [&](int a, int b) {  // both int8 or neither
+                if (cand[a] != cand[b]) {
+                    cand[a] = cand[b] = 0;
+                    changed = true;
+                }
+            };
+            for (const POp& op : plan.ops) {
+                if (op.kind == OP_CONV && op.in.size() > 1) tie(top(op.in[1]), top(op.out[0]));
+                if (op.kind == OP_RESIZE) tie(top(op.in[0]), top(op.out[0]));
+            }
+        }
+        for (PTensor& t : plan.tensors) {
+            if (t.layout != LAY_NHWC) continue;
+            const int o = top(t.id);
+            if (!cand[o]) continue;
+            t.dtype = DT_I8;
+            t.scale = net.tensor_scale[plan.tensors[o].net_tensor];
+        }
+    }
+
     bool finalize() {
+        assign_int8();
         // 1. storages for owners
         for (auto& t : plan.tensors) {
             if (t.parent >= 0 || t.storage >= 0) continue;
@@ -1080,6 +1145,9 @@ struct Lowerer {
                     cin_eff = (a.Cin + 7) / 8 * 8;
                 }
                 ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0;
+                const bool in8 = ti.dtype == DT_I8, out8 = to.dtype == DT_I8;
+                const bool res8 = op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8;
+                if (in8) ok = ok && a.Cin % 16 == 0 && ti.rcoff % 16 == 0 && ti.ld % 16 == 0;
                 // output side: 16-byte stores when everything is a multiple of 8, element-wise stores otherwise
                 bool vec_out = a.Cout % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
                 if (op.in.size() > 1) {
@@ -1104,14 +1172,30 @@ struct Lowerer {
                     t.Kpad = (t.K + t.bk - 1) / t.bk * t.bk;
                     t.bn = conv_igemm_pick_bn(t.Cout);
                     t.Cout_pad = (t.Cout + t.bn - 1) / t.bn * t.bn;
+                    if (in8) {  // int8 operands: 64-channel k-steps; the input-side geometry is handed over in 2-byte units (ConvArgs)
+                        t.bk = 32;
+                        t.in_i8 = 1;
+                        t.Cin = a.Cin / 2;
+                        t.ld_in = ti.ld / 2;
+                        t.CinK = (a.Cin + 63) / 64 * 64 / 2;
+                        t.K = t.kh * t.kw * t.CinK;
+                        t.Kpad = t.K;
+                    }
+                    t.out_i8 = out8 ? 1 : 0;
+                    t.res_i8 = res8 ? 1 : 0;
+                    t.out_inv_scale = out8 ? 1.0f / to.scale : 0.f;
+                    t.res_scale = res8 ? plan.tensors[op.in[1]].scale : 0.f;
                     if (conv_igemm_supported(t)) {
                         a = t;
                         op.igemm = true;
                     }
                 }
             }
-            const double es = dt == DT_F16 ? 2 : 4;
-            op.bytes = to.nmul * ((op.stem ? 4.0 : es) * (double)a.H * a.W * a.Cin + es * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
+            if ((ti.dtype == DT_I8 || to.dtype == DT_I8 || (op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8)) && !op.igemm)
+                return fail(op.name + ": int8 tensor on a convolution that cannot take the MFMA path");
+            const double es_in = (double)dtype_size(ti.dtype), es_out = (double)dtype_size(to.dtype);
+            const double cin_real = ti.dtype == DT_I8 ? 2.0 * a.Cin : (double)a.Cin;
+            op.bytes = to.nmul * ((op.stem ? 4.0 : es_in) * (double)a.H * a.W * cin_real + es_out * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
         }
         // 4. plugins: configure + workspace
         for (size_t k = 0; k < plan.ops.size(); ++k) {
@@ -1382,6 +1466,17 @@ bool pack_weights(const Network& net, Plan* plan) {
                     op.w_off = reserve((size_t)cout * cin_logical * 4);
                     pack_conv_weights_f32(w2.data(), cout, cin_logical, 1, 1, sc.data(), reinterpret_cast<float*>(blob.data() + op.w_off));
                 }
+            } else if (op.igemm && a.in_i8) {
+                // int8 weights, per-output-channel scales; cscale[c] = input tensor scale * weight scale (dequantises the int32 sums)
+                const size_t kpad_bytes = (size_t)a.Kpad * 2;
+                op.w_off = reserve((size_t)a.Cout_pad * kpad_bytes);
+                std::vector<float> wscale(a.Cout_pad, 1.f);
+                conv_pack_weights_i8(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK * 2, sc.data(), a.Cout_pad, (int)kpad_bytes,
+                                     reinterpret_cast<int8_t*>(blob.data() + op.w_off), wscale.data());
+                const float s_in = plan->tensors[op.in[0]].scale;
+                for (float& v : wscale) v *= s_in;
+                op.s_off = reserve(wscale.size() * 4);
+                memcpy(blob.data() + op.s_off, wscale.data(), wscale.size() * 4);
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
                 pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.bk, sc.data(),
@@ -1445,12 +1540,12 @@ std::string Plan::describe_json() const {
         o << "\",\"flops\":" << op.flops << ",\"bytes\":" << op.bytes;
         if (op.kind == OP_CONV || op.kind == OP_DECONV) {
             const ConvArgs& a = op.conv;
-            o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout
+            o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << (a.in_i8 ? 2 * a.Cin : a.Cin) << ",\"cout\":" << a.Cout
               << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
               << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
               << ",\"act2\":" << a.act2 << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
-              << ",\"ld_out\":" << a.ld_out << ",\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
+              << ",\"ld_out\":" << a.ld_out << ",\"i8\":[" << a.in_i8 << "," << a.out_i8 << "," << a.res_i8 << "],\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
               << (op.stem ? 0 : tensors[op.in[0]].nfix);
         }
         o << ",\"lane\":" << op.lane << ",\"waits\":[";
@@ -1467,7 +1562,8 @@ std::string Plan::describe_json() const {
         o << (k ? "," : "") << "{\"id\":" << t.id << ",\"net\":" << t.net_tensor << ",\"layout\":\""
           << (t.layout == LAY_NHWC ? "nhwc" : "linear") << "\",\"dims\":[";
         for (int d = 0; d < t.dims.nb; ++d) o << (d ? "," : "") << t.dims.d[d];
-        o << "],\"storage\":" << t.storage << ",\"coff\":" << t.rcoff << ",\"ld\":" << t.ld << ",\"view\":"
+        o << "],\"storage\":" << t.storage << ",\"coff\":" << t.rcoff << ",\"ld\":" << t.ld << ",\"dtype\":" << t.dtype << ",\"scale\":" << t.scale
+          << ",\"view\":"
           << (t.parent >= 0 ? "true" : "false") << "}";
     }
     o << "],\"storages\":[";

@@ -68,6 +68,7 @@ struct PTensor {
     int rcoff = 0;       // resolved channel offset within the storage
     long reoff = 0;      // resolved element offset within the storage (LINEAR)
     int Calloc = 0;      // owning NHWC tensor: allocated channel count
+    float scale = 0.f;   // DT_I8 tensors: real value = int8 value * scale (the calibrated scale of the owning tensor)
     long sample_elems() const { return layout == LAY_NHWC ? (long)nmul * H * W * ld : (long)dims.volume(); }
 };
 

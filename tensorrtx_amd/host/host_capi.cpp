@@ -6,6 +6,7 @@
 #include <memory>
 #include <sstream>
 
+#include "calibrator.h"
 #include "common.h"
 #include "models.h"
 
@@ -26,12 +27,36 @@ static int geti(const std::map<std::string, std::string>& m, const char* k, int 
     return it == m.end() ? d : std::atoi(it->second.c_str());
 }
 
+// calibrator used by builds with int8=1: a C v-table supplied by the caller (tests / Python tools), or, when none is set,
+// the reference-style directory calibrator over $TRTX_CALIB_DIR (*.ppm) with the cache file $TRTX_CALIB_TABLE
+static trtx_calibrator_vtbl g_calib{};
+static bool g_have_calib = false;
+extern "C" void trtx_host_set_calibrator(const trtx_calibrator_vtbl* v) {
+    g_have_calib = v != nullptr;
+    if (v) g_calib = *v;
+}
+
 extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, const char* options, void** blob, size_t* size) {
     if (!model || !wts_path || !blob || !size) return TRTX_ERR_INVALID;
     const auto o = parse_opts(options);
     trtx_host::Logger logger;
     std::unique_ptr<IBuilder> builder(createInferBuilder(logger));
     std::unique_ptr<IBuilderConfig> config(builder->createBuilderConfig());
+    std::unique_ptr<IInt8Calibrator> calibrator;
+    if (geti(o, "int8", 0)) {  // USE_INT8 of the reference builders (yolov8/src/model.cpp:317-324, retinaface/retina_r50.cpp:219-225)
+        if (!builder->platformHasFastInt8()) return TRTX_ERR_UNSUPPORTED;
+        config->setFlag(BuilderFlag::kINT8);
+        if (g_have_calib) {
+            calibrator.reset(new trtx_host::CallbackCalibrator(g_calib));
+        } else {
+            const char* dir = std::getenv("TRTX_CALIB_DIR");
+            const char* table = std::getenv("TRTX_CALIB_TABLE");
+            const std::string m0(model);
+            calibrator.reset(new trtx_host::Int8EntropyCalibrator2(1, geti(o, "w", 640), geti(o, "h", 640), dir ? dir : "./coco_calib/",
+                                                                   table ? table : "int8calib.table", m0 == "yolov8n" ? "images" : "data"));
+        }
+        config->setInt8Calibrator(calibrator.get());
+    }
     std::unique_ptr<IHostMemory> plan;
     const std::string m(model);
     if (m == "lenet") {

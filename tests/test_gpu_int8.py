@@ -65,3 +65,96 @@ def test_conv_i8_mfma_vs_integer_reference(gpu, case):
     else:
         err = (got.cpu().float() - y).abs().max().item()
         assert err <= 2e-3 * max(float(y.abs().max()), 1.0) + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ calibration + engines
+import ctypes
+import struct
+
+from oracle import quant as oq
+from tensorrtx_amd import calibrator, engine, synth
+from util import synth_wts
+
+
+def test_entropy_threshold_matches_numpy_restatement():
+    L = capi.lib()
+    L.trtx_int8_entropy_threshold.restype = ctypes.c_float
+    rng = np.random.default_rng(0)
+    for kind in ("gauss", "laplace_outliers", "uniform"):
+        if kind == "gauss":
+            x = np.abs(rng.normal(0, 1, 400000))
+        elif kind == "laplace_outliers":
+            x = np.abs(np.concatenate([rng.laplace(0, 0.5, 400000), rng.uniform(20, 40, 40)]))
+        else:
+            x = rng.uniform(0, 3, 400000)
+        r = float(x.max())
+        hist, _ = np.histogram(x, bins=2048, range=(0, r))
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        got = L.trtx_int8_entropy_threshold(h.ctypes.data_as(ctypes.c_void_p), 2048, ctypes.c_float(r))
+        want = oq.entropy_threshold(hist, r)
+        assert abs(got - want) <= 1e-5 * r, (kind, got, want)
+        if kind == "laplace_outliers":
+            assert got < 0.5 * r      # the threshold clips the rare outliers instead of spending the int8 range on them
+        if kind == "uniform":
+            assert got > 0.95 * r     # nothing to clip
+
+
+def test_int8_build_from_cache_needs_no_gpu_and_marks_int8_convs():
+    path, _ = synth_wts("yolov8n")
+    plan16 = engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=1)
+    names = [t["name"] or f"(Unnamed Tensor* {t['id']})" for t in engine.describe_plan(plan16)["tensors"]]
+    cache = b"TRT-8601-EntropyCalibration2\n" + b"".join(f"{n}: {struct.unpack('<I', struct.pack('<f', 0.05))[0]:08x}\n".encode() for n in names)
+    with calibrator.Calibrator(cache=cache).installed():
+        plan8 = engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=1, int8=1)
+    assert engine.describe_plan(plan8)["int8"] is True
+    low = engine.describe_plan(plan8, lowered=True)
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert sum(o["i8"][0] for o in convs) >= 55 and not convs[0]["i8"][0]          # everything behind the two Cin <= 16 layers
+    assert all(not o["i8"][1] for o in convs if low["ops"][-1]["in"].count(o["out"][0]))  # the detect head reads fp16
+    assert low["arena_bytes"] < engine.describe_plan(plan16, lowered=True)["arena_bytes"]
+    with pytest.raises(Exception):   # kINT8 without a calibrator / cache is a build error
+        engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=1, int8=1)
+
+
+@pytest.mark.gpu
+def test_yolov8n_int8_engine_calibrated_on_the_gpu(gpu):
+    """Calibrate (4 batches through the fp16 plan, |x| histograms, entropy thresholds), build, run; the written cache rebuilds the
+    same plan; heads vs the fp32 oracle."""
+    import json
+    import os
+    import torch
+    from oracle import models_torch as mt
+    from oracle import wts as owts
+    path, _ = synth_wts("yolov8n")
+    B, S = 4, 320
+    batches = [torch.from_numpy(synth.images(B, S, S, seed=50 + k)).to(gpu) for k in range(4)]
+    cal = calibrator.Calibrator(batches=batches, batch_size=B)
+    with cal.installed():
+        plan8 = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, int8=1, mark_heads=1)
+    assert cal.written_cache and cal.written_cache.startswith(b"TRT-")
+    scales = calibrator.parse_cache(cal.written_cache)
+    assert len(scales) > 40 and all(0 < v < 10 for v in scales.values())
+    with calibrator.Calibrator(cache=cal.written_cache).installed():
+        again = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, int8=1, mark_heads=1)
+    assert again == plan8
+    plan16 = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1)
+    x = synth.images(B, S, S, seed=77)
+    outs = {}
+    for tag, plan in (("int8", plan8), ("fp16", plan16)):
+        e = engine.Engine(plan)
+        bufs = [torch.from_numpy(x).to(gpu)] + [torch.zeros(B * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(1, e.nb_bindings)]
+        e.enqueue(B, bufs)
+        torch.cuda.synchronize()
+        outs[tag] = {e.names[i]: bufs[i].cpu().numpy() for i in range(1, e.nb_bindings)}
+        e.close()
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), torch.from_numpy(x))
+    err8 = max(float(np.abs(outs["int8"][f"head{i}"].reshape(h.shape) - h.numpy()).max()) for i, h in enumerate(heads))
+    err16 = max(float(np.abs(outs["fp16"][f"head{i}"].reshape(h.shape) - h.numpy()).max()) for i, h in enumerate(heads))
+    rel8 = max(float(np.abs(outs["int8"][f"head{i}"].reshape(h.shape) - h.numpy()).mean() / np.abs(h.numpy()).mean()) for i, h in enumerate(heads))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_metrics.jsonl", "a") as f:
+        f.write(json.dumps(dict(test="yolov8n_int8_320", head_max_abs_err_int8=err8, head_max_abs_err_fp16=err16, head_mean_rel_err_int8=rel8)) + "\n")
+    assert np.isfinite(outs["int8"]["output"]).all()
+    assert err16 < 0.25
+    assert rel8 < 0.25, (err8, rel8)   # int8 activations + weights: a few percent mean error on the head tensors
