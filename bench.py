@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--config", default="yolov8n", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default=None, choices=["weak", "strong"],
                     help="weak: fixed per-GPU batch (default); strong: the config's global batch is split over the GPUs")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "int8"],
+                    help="int8: BuilderFlag::kINT8 engine (entropy calibration on 2 synthetic batches, int8 MFMA convs, fp16 fallback)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent timing table (JSON) to this path")
     args = ap.parse_args()
@@ -194,7 +196,14 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from util import synth_wts  # seeded synthetic weights through the product-side writer
         path, _ = synth_wts(args.config)
-    plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1)
+    if args.precision == "int8":
+        from tensorrtx_amd import calibrator
+        cal_batches = [torch.from_numpy(synth.images(batch, H, W, seed=900 + k) * cfg["scale"]).to(dev) for k in range(2)]
+        with calibrator.Calibrator(batches=cal_batches, batch_size=batch).installed():
+            plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1, int8=1)
+        del cal_batches
+    else:
+        plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1)
     low = engine.describe_plan(plan, lowered=True)
     eng = engine.Engine(plan)
 
@@ -275,8 +284,10 @@ def main():
     flop_per_step = 0.0
     for o in igemm_ops:
         nb = o.get("nfix") or batch              # images per launch = nb * nmul (nmul: RoIs per image in the R-CNN head)
-        act = o["hw_in"][0] * o["hw_in"][1] * o["cin"] + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (2 if o["residual"] else 1)
-        alg_bytes += 2.0 * act * nb * o.get("nmul", 1) + 2.0 * o["cout"] * o["cin"] * o["k"][0] * o["k"][1]
+        i8 = o.get("i8", [0, 0, 0])
+        es_in, es_out, es_res = (1.0 if i8[0] else 2.0), (1.0 if i8[1] else 2.0), (1.0 if i8[2] else 2.0)
+        act_b = (es_in * o["hw_in"][0] * o["hw_in"][1] * o["cin"] + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (es_out + (es_res if o["residual"] else 0.0)))
+        alg_bytes += act_b * nb * o.get("nmul", 1) + es_in * o["cout"] * o["cin"] * o["k"][0] * o["k"][1]
         flop_per_step += o["flops"] * nb          # plan flops are per sample and already include nmul
     avg_launch_s = conv_ms * 1e-3 / max(n_conv, 1)
     achieved_gbps = alg_bytes / max(n_conv, 1) / avg_launch_s / 1e9
@@ -298,11 +309,11 @@ def main():
                 "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms, "hbm_view": hbm_view, "mfma_view": mfma_view,
                 "whole_step_hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": alg_bytes / (dt / args.steps) / 1e9}}
     res = {
-        "metric": f"images/sec @ batch={cfg['batch']} {W}x{H} fp16 ({args.config}" + (" conv backbone + YoloLayer decode + NMS)" if cfg["nms"] else ", IExecutionContext::enqueue)"),
+        "metric": f"images/sec @ batch={cfg['batch']} {W}x{H} {args.precision} ({args.config}" + (" conv backbone + YoloLayer decode + NMS)" if cfg["nms"] else ", IExecutionContext::enqueue)"),
         "value": (global_batch if mode == "strong" else world * batch) * args.steps / dt, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": mode,
-        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{args.config} fp16 {W}x{H}, {cfg['tag']}: per-GPU batch {batch}, " +
+        "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "i8 (+f16 fallback layers)", "data": "synthetic",
+        "config": {"workload": f"{args.config} {args.precision} {W}x{H}, {cfg['tag']}: per-GPU batch {batch}, " +
                                ("enqueue + GPU NMS" if cfg["nms"] else "enqueue (all plugins inside the engine)") +
                                f", {len(binding_sets)} rotating input batches resident in HBM",
                    "global_batch": global_batch, "parallelism": f"replica-per-GPU x{world} (image-sharded, no data-path collective; RCCL only brackets the timed region)",
@@ -318,7 +329,7 @@ def main():
                              "kept_after_nms_per_image": float(keep_cnt.float().mean().item()),
                              "note": "seeded random weights: candidate counts are not those of a trained model"}
     if rank == 0:
-        if world == 1 and args.config == "yolov8n" and not args.no_cpu_baseline and mode == "weak":
+        if world == 1 and args.config == "yolov8n" and not args.no_cpu_baseline and mode == "weak" and args.precision == "fp16":
             # GPU outputs for the oracle's sample images (a separate small engine run, outside every timed region)
             nb = 4
             plan_h = engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=1, mark_heads=1)

@@ -157,9 +157,12 @@ def test_yolov8n_fp16_engine_640(gpu):
     st = _match_detections(dec, dec_ref)
     _metric("yolov8n_fp16_640", cls_logit_max_abs_err=worst_cls, box_ltrb_max_abs_err=worst_box,
             counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
-    assert worst_cls < 0.25 and worst_box < 0.05
-    assert st["ref"] > 50 and st["matched"] >= 0.98 * st["ref"]
-    assert st["min_iou"] > 0.98
+    # fp16 storage of 63 layers vs the fp32 oracle: measured 0.065 on O(10) class logits, 0.02 cells on the DFL distances, min IoU
+    # 0.9973 (gpurun_out/parity_metrics.jsonl); asserted at <= 1.5x of that.  The north_star's 1e-4 / 1e-3 bar is met by the fp32
+    # build only (test_yolov8n_fp32_engine_matches_oracle).
+    assert worst_cls < 0.1 and worst_box < 0.03
+    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"]
+    assert st["min_iou"] > 0.996
 
 
 def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
@@ -177,8 +180,8 @@ def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
     dec = out["output"].reshape(4, -1).numpy()
     st = _match_detections(dec, dec_ref)
     _metric("yolov8n_fp16_640_fused", counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
-    assert st["ref"] > 50 and st["matched"] >= 0.98 * st["ref"]
-    assert st["min_iou"] > 0.98
+    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"]
+    assert st["min_iou"] > 0.996
     assert np.abs(dec[:, 0] - dec_ref[:, 0]).max() <= 0.02 * dec_ref[:, 0].max() + 3
 
 
@@ -250,7 +253,8 @@ def test_retinaface_r50_fp16_engine(gpu, hw, batch):
     assert st["ref"] > 100 and st["matched"] >= 0.97 * st["ref"]
     # boxes are exp()-scaled anchors up to several hundred px wide: judge them by IoU (north_star: 1e-3 box IoU is the
     # fp32 budget; fp16 storage measures ~5e-3) and bound the absolute error loosely
-    assert st["min_iou"] > 0.985 and st["max_box_err"] < 3.0 and st["max_conf_err"] < 0.05
+    # measured (RetinaFace-R50 fp16 vs fp32 oracle): min IoU 0.9917-0.9925, box error <= 1.25 px
+    assert st["min_iou"] > 0.988 and st["max_box_err"] < 2.0 and st["max_conf_err"] < 0.05
     # device NMS on the engine's own decode buffer == oracle NMS of the same buffer
     from tensorrtx_amd import det_ops
     gi_, gc_, _ = det_ops.retina_nms(torch.from_numpy(out).to(gpu), H, W)
