@@ -319,14 +319,15 @@ constexpr int kRegBudget = 256;  // ws_regs() of an entry: everything must fit t
 #ifdef TRTX_WS_ONLY
 #define TRTX_WS_CASES(X) TRTX_WS_ONLY
 #else
-#define TRTX_WS_CASES(X)                                                                                                        \
-    /* 3x3: 32->32, 64->64, 128->64 (64->80 on 8 column fragments and 192->64 1x1 measured slower than the implicit GEMM: not listed) */                                                                                  \
-    X(9, 1, 2, 1, 8, 1) X(9, 1, 2, 1, 8, 0) X(9, 1, 2, 1, 4, 0) X(9, 2, 2, 2, 8, 1) X(9, 2, 2, 2, 8, 0) X(9, 2, 2, 2, 4, 0)     \
-    X(9, 4, 1, 4, 4, 0) X(9, 4, 1, 4, 8, 1)                                             \
-    /* 1x1 */                                                                                                                   \
-    X(1, 1, 2, 1, 8, 0) X(1, 2, 2, 1, 8, 0) X(1, 2, 4, 1, 8, 0) X(1, 2, 4, 1, 4, 0) X(1, 3, 4, 1, 8, 0) X(1, 3, 5, 1, 8, 0)     \
-    X(1, 3, 5, 1, 4, 0) X(1, 4, 4, 1, 8, 0) X(1, 4, 4, 1, 4, 0) X(1, 4, 8, 1, 8, 0) X(1, 4, 8, 1, 4, 0)                         \
-    X(1, 6, 4, 2, 8, 0) X(1, 6, 4, 2, 4, 0) X(1, 8, 4, 2, 8, 0) X(1, 8, 4, 2, 4, 0) X(1, 8, 4, 4, 4, 0) X(1, 12, 2, 4, 4, 0)
+#define TRTX_WS_CASES(X)                                                          \
+    X(9, 1, 2, 1, 8, 1) /* 3x3 32 -> 32 on 16-pixel row tiles (C2f bottlenecks) */ \
+    X(1, 1, 2, 1, 8, 0) /* 1x1 32 -> 32 streaming                              */
+// Why only Cin = 32 (profiles/r02_trace_gaps_*.txt, r02_ws_per_op.txt): every workgroup starts by pulling the layer's whole
+// weight set into registers (18 KB here, 73 KB for 64 -> 64 3x3).  Timed one op at a time the wider configurations also beat the
+// implicit-GEMM kernel (64 -> 64 3x3: 94 vs 116 us at 320^2 b8), but inside the engine's back-to-back stream the first launch of
+// each of them costs 7-12 us more than it saves (conv_ws<9,2,2,2,8> 46.7 us against 34.7 for conv_igemm, then 31.2 on the
+// second launch), so YOLOv8n / ResNet-50 / RetinaFace / R-CNN steps were 0.6-2.7 % slower with them enabled.  The template
+// still supports those shapes (KC <= 12, WC 1/2/4, 64-pixel tiles): build with -DTRTX_WS_ONLY="X(...)" to experiment.
 #endif
 
 struct WsEntry {
