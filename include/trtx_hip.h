@@ -467,6 +467,10 @@ int32_t trtx_engine_binding_dims(const trtx_engine* e, int32_t index, trtx_dims*
 int32_t trtx_engine_binding_dtype(const trtx_engine* e, int32_t index);
 int32_t trtx_engine_max_batch(const trtx_engine* e);
 size_t trtx_engine_device_memory(const trtx_engine* e);
+/* Multi-GPU in one process (reference: tutorials/multi_GPU_processing.md:13-30, one `Plan` per device after cudaSetDevice(i)):
+ * an engine is bound to the HIP device that was current at trtx_engine_deserialize; this returns its ordinal (-1 for NULL).
+ * trtx_context_create / enqueue / enqueue_v3 / profile return TRTX_ERR_STATE when another device is current. */
+int32_t trtx_engine_device(const trtx_engine* e);
 int32_t trtx_context_create(trtx_engine* e, trtx_context** out);
 void trtx_context_destroy(trtx_context* c);
 /* IExecutionContext::enqueue(batch, bindings, stream, nullptr) — implicit batch */

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -415,13 +416,15 @@ template <int TAPS, int KC, int NFW, int WC, int NF, bool ROWS>
 int32_t launch_ws(const ConvArgs& a, const WsGeom& g, unsigned in_bytes, hipStream_t s, int* occ_cache) {
     auto kern = conv_ws_f16_kernel<TAPS, KC, NFW, WC, NF, ROWS>;
     const size_t lds = 2 * (size_t)KC * g.plane_bytes + 4 * 16 * (NFW * 32 + 16);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
+    static std::atomic<bool> attr_done[64];  // per instantiation and per device (one process may drive several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TRTX_ERR_HIP;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
             (void)hipGetLastError();
             return TRTX_ERR_HIP;
         }
-        attr_done = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     // persistent grid: as many workgroups as stay resident (registers and this launch's LDS), on 256 CUs
     int occ = *occ_cache;

@@ -387,6 +387,25 @@ extern "C" int32_t trtx_plan_describe(const void* plan_data, size_t size, int32_
     return TRTX_OK;
 }
 
+// An engine's weights, its contexts' arenas, lane streams and events all belong to ONE HIP device: the device that was current
+// at deserializeCudaEngine (tutorials/multi_GPU_processing.md of the reference: cudaSetDevice(i) before building / using the i-th
+// Plan).  Using it with another device current would launch kernels over foreign memory, so that is refused, loudly.
+static int32_t check_device(const trtx_engine* e, const char* what) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return TRTX_ERR_HIP;
+    }
+    if (dev != e->device) {
+        fprintf(stderr, "[trtx_hip] %s: the engine lives on HIP device %d but device %d is current - call hipSetDevice(%d) first\n", what,
+                e->device, dev, e->device);
+        return TRTX_ERR_STATE;
+    }
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_engine_device(const trtx_engine* e) { return e ? e->device : -1; }
+
 extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, trtx_engine** out) {
     if (!plan_data || !out) return TRTX_ERR_INVALID;
     if (trtx_device_count() < 1) {
@@ -395,6 +414,7 @@ extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, t
     }
     std::string err;
     std::unique_ptr<trtx_engine> e(new trtx_engine());
+    TRTX_HIP_TRY(hipGetDevice(&e->device));
     e->net = Network::deserialize(static_cast<const uint8_t*>(plan_data), size, &err);
     if (!e->net) {
         fprintf(stderr, "[trtx_hip] deserializeCudaEngine: %s\n", err.c_str());
@@ -468,6 +488,7 @@ extern "C" size_t trtx_engine_device_memory(const trtx_engine* e) {
 
 extern "C" int32_t trtx_context_create(trtx_engine* e, trtx_context** out) {
     if (!e || !out) return TRTX_ERR_INVALID;
+    if (const int32_t st = check_device(e, "createExecutionContext")) return st;
     std::unique_ptr<trtx_context> c(new trtx_context());
     c->engine = e;
     c->addr.assign(e->plan.binding_tensor.size(), nullptr);
@@ -577,6 +598,7 @@ extern "C" int32_t trtx_context_enqueue(trtx_context* c, int32_t batch, void* co
         fprintf(stderr, "[trtx_hip] enqueue: batch %d outside [1, %d]\n", b, c->engine->plan.max_batch);
         return TRTX_ERR_INVALID;
     }
+    if (const int32_t st = check_device(c->engine, "enqueue")) return st;
     return enqueue_maybe_graph(c, b, bindings, stream);
 }
 
@@ -592,12 +614,14 @@ extern "C" int32_t trtx_context_enqueue_v3(trtx_context* c, trtx_stream_t stream
     if (!c) return TRTX_ERR_INVALID;
     for (void* p : c->addr)
         if (!p) return TRTX_ERR_STATE;
+    if (const int32_t st = check_device(c->engine, "enqueueV3")) return st;
     return enqueue_maybe_graph(c, c->engine->plan.explicit_batch ? 1 : c->engine->plan.max_batch, c->addr.data(), stream);
 }
 
 extern "C" int32_t trtx_context_profile(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream,
                                         char** json_out) {
     if (!c || !bindings || !json_out) return TRTX_ERR_INVALID;
+    if (const int32_t st = check_device(c->engine, "profile")) return st;
     std::vector<OpTiming> prof;
     const int32_t st = execute_plan(c, c->engine->plan.explicit_batch ? 1 : batch, bindings, stream, &prof);
     if (st != TRTX_OK) return st;

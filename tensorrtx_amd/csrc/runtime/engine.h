@@ -15,6 +15,7 @@ struct trtx_engine {
     trtx::Plan plan;
     std::vector<uint8_t> blob;  // the serialized plan this engine was created from
     void* d_weights = nullptr;
+    int device = -1;  // HIP device the weights live on (current device at deserialize); contexts and enqueues must run there
     int plugins_initialized = 0;  // number of plugin ops (in plan order) whose initialize() succeeded
     ~trtx_engine();
 };

@@ -69,6 +69,7 @@ class Engine:
             check(L.trtx_engine_binding_dims(self._e, i, ctypes.byref(d)), "binding_dims")
             self.dims.append([d.d[k] for k in range(d.nb)])
         self.device_memory = L.trtx_engine_device_memory(self._e)
+        self.device = L.trtx_engine_device(self._e)  # HIP ordinal the weights / arena live on (current device at creation)
 
     def enqueue(self, batch, bindings, stream=None):
         """bindings: list of CUDA tensors in binding order (inputs first). Async on the current stream."""

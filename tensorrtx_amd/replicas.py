@@ -44,3 +44,49 @@ def gather_counts(local_counts, dist):
     out = [torch.empty_like(local_counts) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local_counts)
     return out
+
+
+class DeviceReplicas:
+    """One process driving several GPUs: a replica (engine + context + stream + bindings) per device, images dealt to the
+    replicas by `partition`, no cross-device traffic (the reference's own recipe, tutorials/multi_GPU_processing.md:13-30:
+    cudaSetDevice(i), then one Plan {engine, context, stream, buffers} per device).  bench.py uses one PROCESS per GPU instead
+    (the driver's launch contract); this class is the in-process form for hosts that own all GPUs from one address space.
+
+    make_engine(device_index) -> engine is called with that device current; engines refuse to run on any other device
+    (trtx_engine_device / TRTX_ERR_STATE)."""
+
+    def __init__(self, devices, make_engine):
+        import torch
+        self.devices = list(devices)
+        if not self.devices:
+            raise ValueError("DeviceReplicas needs at least one device")
+        self.engines, self.streams = [], []
+        for d in self.devices:
+            with torch.cuda.device(d):
+                self.engines.append(make_engine(d))
+                self.streams.append(torch.cuda.Stream(device=d))
+
+    def shards(self, n_items: int):
+        """Image index range of every replica for a global batch of n_items."""
+        return [partition(n_items, len(self.devices), r) for r in range(len(self.devices))]
+
+    def enqueue(self, batches, bindings):
+        """batches[r] / bindings[r]: batch size and binding list (tensors on devices[r]) of replica r.  Asynchronous: every
+        replica runs on its own stream; call synchronize() (or record events on .streams) before reading results."""
+        import torch
+        for r, d in enumerate(self.devices):
+            if batches[r] == 0:
+                continue
+            with torch.cuda.device(d):
+                self.engines[r].enqueue(batches[r], bindings[r], stream=self.streams[r].cuda_stream)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        import torch
+        for d, e in zip(self.devices, self.engines):
+            with torch.cuda.device(d):
+                e.close()
+        self.engines = []

@@ -283,3 +283,30 @@ def test_kernel_equals_stride_deconvolution_small_channel_counts(gpu, cin, cout,
     got = _run(plan, {"data": x.numpy()}, 2, gpu)["out"].reshape(2, cout, 18, 14)
     ref = F.conv_transpose2d(x.half().float() if fp16 else x, w.half().float() if fp16 else w, b, stride=2)
     assert (got - ref).abs().max().item() < (2e-2 if fp16 else 1e-4)
+
+
+def test_engine_is_bound_to_its_device_and_device_replicas_run(gpu):
+    """Multi-GPU in one process (tutorials/multi_GPU_processing.md:13-30): an engine reports the device it was deserialized on, and
+    DeviceReplicas shards a global batch over per-device replicas, each on its own stream (one device on the test box: this
+    covers the path, not the scaling).  (LeNet is no use here: the reference graph, lenet.cpp:95-118, multiplies W x flat^T and is
+    only meaningful for N = 1.)"""
+    from tensorrtx_amd import replicas
+    path, _ = synth_wts("resnet50")
+    plan = engine.build_plan("resnet50", path, batch=4, fp16=0, h=64, w=64)
+    reps = replicas.DeviceReplicas([torch.cuda.current_device()], lambda d: engine.Engine(plan))
+    try:
+        e = reps.engines[0]
+        assert e.device == torch.cuda.current_device()
+        shards = reps.shards(4)
+        assert [len(s) for s in shards] == [4]
+        x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+        xin = x.to(gpu)
+        out = torch.empty(4 * 1000, dtype=torch.float32, device=gpu)
+        torch.cuda.synchronize()
+        reps.enqueue([4], [[xin if e.is_input[i] else out for i in range(e.nb_bindings)]])
+        reps.synchronize()
+        with torch.inference_mode():
+            ref = mt.resnet50(mt.Params(owts.load_wts(path)), x)
+        assert (out.cpu().reshape(4, 1000) - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    finally:
+        reps.close()

@@ -1,6 +1,8 @@
 """N>1 path on CPU: world_size-2 gloo processes exercise the image partition, the timing reduce and the
 optional result gather used by bench.py (no data-path collective exists to test)."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -60,3 +62,13 @@ def test_partition_edge_cases():
     assert list(replicas.partition(3, 8, 5)) == []
     assert sum(len(replicas.partition(1000, 7, r)) for r in range(7)) == 1000
     assert replicas.max_over_ranks(0.5, None) == 0.5
+
+
+def test_device_replicas_shards_without_gpu():
+    """The in-process multi-device helper deals images exactly like the process-per-GPU partition."""
+    from tensorrtx_amd import replicas
+    r = replicas.DeviceReplicas.__new__(replicas.DeviceReplicas)
+    r.devices = [0, 1, 2]
+    assert [list(s) for s in r.shards(8)] == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    with pytest.raises(ValueError):
+        replicas.DeviceReplicas([], lambda d: None)
