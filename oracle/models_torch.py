@@ -134,9 +134,13 @@ def _get_depth(x, gd):  # model.cpp:18-25
     return max(r, 1)
 
 
-def yolov8_det(p: Params, x, num_class=80, gd=0.33, gw=0.25, max_channels=1024, cls_bias=-7.0, cls_gain=80.0):
-    """Returns ([B, 4+nc, g] for stride 8/16/32, strides) — exactly what feeds YoloLayer_TRT."""
+def yolov8_det(p: Params, x, num_class=80, gd=0.33, gw=0.25, max_channels=1024, cls_bias=-7.0, cls_gain=80.0, task="det", nk=17):
+    """Returns ([B, 4+nc(+extra), g] for stride 8/16/32, strides) — exactly what feeds YoloLayer_TRT.  task "seg" / "pose" / "obb"
+    adds the cv4 branch of buildEngineYolov8Seg / Pose / Obb (model.cpp:54-96, 1253-1272, 1483-1535, 2699-2721): 32 mask
+    coefficients, nk*3 keypoint values or 1 angle logit per cell, appended after the class rows; "seg" also returns the Proto
+    tensor [B, 32, H/4, W/4] (model.cpp:36-52) as a third value."""
     eps = 1e-3
+    extra = {"det": 0, "seg": 32, "pose": nk * 3, "obb": 1}[task]
 
     def cbs(x, name, cout, k, s, pad):  # convBnSiLU, block.cpp:79-96
         y = F.conv2d(x, p.conv_w(name + ".conv.weight", cout, x.shape[1], k), None, stride=s, padding=pad)
@@ -208,7 +212,20 @@ def yolov8_det(p: Params, x, num_class=80, gd=0.33, gw=0.25, max_channels=1024, 
         # DFL, block.cpp:239-257: (64,g)->(4,16,g)->(16,4,g) softmax over the 16 bins, 1x1 conv(arange)
         t = boxp.reshape(-1, 4, 16, g).permute(0, 2, 1, 3)
         t = F.conv2d(F.softmax(t, dim=1), dfl_w).reshape(-1, 4, g)
-        outs.append(torch.cat([t, clsp], 1).contiguous())
+        parts = [t, clsp]
+        if extra:  # cv4_conv_combined: two 3x3 convBnSiLU + biased 1x1 conv, flattened to (extra, g)
+            mid = max(c15.shape[1] // 4, extra)  # ultralytics Segment/Pose/OBB: c4 = max(ch[0] // 4, n) (== the table of model.cpp:61-70)
+            e = cbs(cbs(feat, f"model.22.cv4.{s}.0", mid, 3, 1, 1), f"model.22.cv4.{s}.1", mid, 3, 1, 1)
+            e = F.conv2d(e, p.conv_w(f"model.22.cv4.{s}.2.weight", extra, mid, 1), p.vec(f"model.22.cv4.{s}.2.bias", extra, lambda: 0.1 * p.randn(extra)))
+            parts.append(e.reshape(e.shape[0], extra, g))
+        outs.append(torch.cat(parts, 1).contiguous())
+    if task == "seg":  # Proto: cv1 3x3 -> ConvTranspose2d(2, 2, bias) -> cv2 3x3 -> cv3 1x1 to 32 masks
+        mid = W(256)
+        y = cbs(c15, "model.22.proto.cv1", mid, 3, 1, 1)
+        wt = p._get("model.22.proto.upsample.weight", (mid, mid, 2, 2), lambda: p.randn(mid, mid, 2, 2) * math.sqrt(2.0 / mid))
+        y = F.conv_transpose2d(y, wt, p.vec("model.22.proto.upsample.bias", mid, lambda: 0.1 * p.randn(mid)), stride=2)
+        y = cbs(cbs(y, "model.22.proto.cv2", mid, 3, 1, 1), "model.22.proto.cv3", 32, 1, 1, 0)
+        return outs, strides, y
     return outs, strides
 
 

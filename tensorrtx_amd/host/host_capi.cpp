@@ -76,6 +76,9 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
         cfg.num_class = geti(o, "classes", 80);
         cfg.max_out_bbox = geti(o, "max_out", 1000);
         cfg.mark_heads = geti(o, "mark_heads", 0) != 0;
+        cfg.task = geti(o, "task", 0);  // 0 det, 1 seg, 2 pose, 3 obb
+        cfg.num_points = geti(o, "points", cfg.num_points);
+        if (cfg.task < 0 || cfg.task > 3) return TRTX_ERR_INVALID;
         plan.reset(trtx_host::buildEngineYolov8Det(builder.get(), config.get(), wts_path, cfg));
     } else if (m == "rcnn_r50c4") {
         trtx_host::RcnnConfig cfg;

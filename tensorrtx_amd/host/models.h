@@ -30,8 +30,13 @@ struct Yolov8Config {
     float gd = 0.33f, gw = 0.25f;       // 'n' scale (yolov8_det.cpp:130-133)
     int max_channels = 1024;
     bool mark_heads = false;            // debugging: also expose the three plugin inputs as outputs "head0..2"
+    // 0 det (buildEngineYolov8Det), 1 seg (..Seg, model.cpp:1057-1308: + 32 mask coefficients per cell and the "proto" output),
+    // 2 pose (..Pose, :1310-1563: + kNumberOfPoints * 3 keypoint values), 3 obb (..Obb, :2499-2740: + 1 angle logit)
+    int task = 0;
+    int num_points = 17;                // kNumberOfPoints (include/config.h:28)
+    float kpt_conf = 0.5f;              // kConfThreshKeypoints (include/config.h:14); the plugin field carries (int)kpt_conf like the reference
 };
-// yolov8/src/model.cpp:98-336
+// yolov8/src/model.cpp:98-336 (det), 1057-1308 (seg), 1310-1563 (pose), 2499-2740 (obb): one graph, the task adds the cv4 branch
 nvinfer1::IHostMemory* buildEngineYolov8Det(nvinfer1::IBuilder* builder, nvinfer1::IBuilderConfig* config,
                                             const std::string& wts, const Yolov8Config& cfg);
 

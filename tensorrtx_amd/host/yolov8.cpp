@@ -116,8 +116,8 @@ ITensor* DFL(Ctx& c, ITensor& in, int grid, const std::string& wkey) {
 IPluginV2Layer* addYoLoLayer(Ctx& c, const std::vector<ITensor*>& dets, const std::vector<int>& strides, const Yolov8Config& cfg) {
     auto* creator = getPluginRegistry()->getPluginCreator("YoloLayer_TRT", "1");
     assert(creator && "YoloLayer_TRT creator not registered");
-    std::vector<int> info = {cfg.num_class, 17 /*kNumberOfPoints*/, 0 /*(int)kConfThreshKeypoints*/, cfg.input_w, cfg.input_h,
-                             cfg.max_out_bbox, 0 /*seg*/, 0 /*pose*/, 0 /*obb*/};
+    std::vector<int> info = {cfg.num_class, cfg.num_points, (int)cfg.kpt_conf /* block.cpp:278: the float threshold is truncated */,
+                             cfg.input_w, cfg.input_h, cfg.max_out_bbox, cfg.task == 1, cfg.task == 2, cfg.task == 3};
     info.insert(info.end(), strides.begin(), strides.end());
     PluginField field("combinedInfo", info.data(), PluginFieldType::kINT32, (int32_t)info.size());
     PluginFieldCollection fc{1, &field};
@@ -127,6 +127,38 @@ IPluginV2Layer* addYoLoLayer(Ctx& c, const std::vector<ITensor*>& dets, const st
     auto* layer = c.net->addPluginV2(ins.data(), (int32_t)ins.size(), *plugin);
     plugin->destroy();  // the network holds its own clone
     return layer;
+}
+
+// cv4_conv_combined (model.cpp:54-96): two 3x3 convBnSiLU + biased 1x1 conv, flattened to (out_ch, grid)
+ITensor* cv4Branch(Ctx& c, ITensor& in, const std::string& lname, int grid, const Yolov8Config& cfg) {
+    int mid = 0, out_ch = 0;
+    if (cfg.task == 1) {  // seg: the reference's width table (:61-70)
+        mid = cfg.gw <= 0.5f ? 32 : (cfg.gw == 0.75f ? 48 : (cfg.gw == 1.0f ? 64 : 80));
+        out_ch = 32;
+    } else {              // pose / obb: the width stored in the weights (:74-82)
+        mid = (int)need(c.wm, lname + ".0.bn.weight").count;
+        out_ch = cfg.task == 2 ? cfg.num_points * 3 : 1;
+    }
+    ITensor* a = convBnSiLU(c, in, mid, 3, 1, 1, lname + ".0");
+    ITensor* b = convBnSiLU(c, *a, mid, 3, 1, 1, lname + ".1");
+    auto* cv = c.net->addConvolutionNd(*b, out_ch, DimsHW{1, 1}, need(c.wm, lname + ".2.weight"), need(c.wm, lname + ".2.bias"));
+    assert(cv);
+    cv->setStrideNd(DimsHW{1, 1});
+    auto* sh = c.net->addShuffle(*cv->getOutput(0));
+    sh->setReshapeDimensions(Dims2{out_ch, grid});
+    return sh->getOutput(0);
+}
+
+// Proto (model.cpp:36-52): 3x3 convBnSiLU -> ConvTranspose 2x2 stride 2 (bias) -> 3x3 -> 1x1 to 32 mask prototypes
+ITensor* proto(Ctx& c, ITensor& in, const Yolov8Config& cfg) {
+    const int mid = get_width(256, cfg.gw, cfg.max_channels);
+    ITensor* a = convBnSiLU(c, in, mid, 3, 1, 1, "model.22.proto.cv1");
+    auto* up = c.net->addDeconvolutionNd(*a, mid, DimsHW{2, 2}, need(c.wm, "model.22.proto.upsample.weight"),
+                                         need(c.wm, "model.22.proto.upsample.bias"));
+    assert(up);
+    up->setStrideNd(DimsHW{2, 2});
+    ITensor* b = convBnSiLU(c, *up->getOutput(0), mid, 3, 1, 1, "model.22.proto.cv2");
+    return convBnSiLU(c, *b, 32, 1, 1, 0, "model.22.proto.cv3");
 }
 
 }  // namespace
@@ -192,7 +224,12 @@ IHostMemory* buildEngineYolov8Det(IBuilder* builder, IBuilderConfig* config, con
         ITensor* boxPart = net->addSlice(*flat->getOutput(0), Dims2{0, 0}, Dims2{64, grid}, Dims2{1, 1})->getOutput(0);
         ITensor* clsPart = net->addSlice(*flat->getOutput(0), Dims2{64, 0}, Dims2{cfg.num_class, grid}, Dims2{1, 1})->getOutput(0);
         ITensor* dfl = DFL(c, *boxPart, grid, "model.22.dfl.conv.weight");
-        dets.push_back(cat2(c, dfl, clsPart));
+        if (cfg.task == 0) {
+            dets.push_back(cat2(c, dfl, clsPart));
+        } else {  // seg / pose / obb: [dfl(4), classes, cv4 branch] (model.cpp:1253-1272, 1483-1532, 2699-2718)
+            ITensor* v[] = {dfl, clsPart, cv4Branch(c, *feats[lv], "model.22.cv4." + s, grid, cfg)};
+            dets.push_back(net->addConcatenation(v, 3)->getOutput(0));
+        }
     }
     if (cfg.mark_heads)
         for (size_t i = 0; i < dets.size(); ++i) {
@@ -203,6 +240,11 @@ IHostMemory* buildEngineYolov8Det(IBuilder* builder, IBuilderConfig* config, con
     assert(yolo);
     yolo->getOutput(0)->setName("output");
     net->markOutput(*yolo->getOutput(0));
+    if (cfg.task == 1) {  // model.cpp:1280-1282
+        ITensor* pr = proto(c, *c15, cfg);
+        pr->setName("proto");
+        net->markOutput(*pr);
+    }
 
     builder->setMaxBatchSize(cfg.max_batch);
     config->setMaxWorkspaceSize(16 * (1 << 20));

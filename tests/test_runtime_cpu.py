@@ -364,3 +364,21 @@ def test_rcnn_fp16_plan_runs_roi_align_natively():
     assert kinds[1].count("roi_align") == 2 and kinds[0].count("roi_align") == 0   # box head + mask head
     assert kinds[1].count("plugin") == kinds[0].count("plugin") - 2
     assert kinds[1].count("to_nhwc") < kinds[0].count("to_nhwc") or kinds[1].count("to_nhwc") <= 2
+
+
+@pytest.mark.parametrize("task,name,nc,extra", [(1, "yolov8n_seg", 80, 32), (2, "yolov8n_pose", 1, 51), (3, "yolov8n_obb", 15, 1)])
+def test_yolov8_task_graphs_build_and_lower_on_the_host(task, name, nc, extra):
+    """buildEngineYolov8Seg / Pose / Obb (yolov8/src/model.cpp:1057-1308, 1310-1563, 2499-2740): the cv4 branch widens each plugin
+    input to 4 + classes + extra rows, "seg" adds the proto output, and the branch plugin is not folded into the det-only head kernel."""
+    from util import synth_wts
+    path, _ = synth_wts(name)
+    plan = engine.build_plan("yolov8n", path, batch=2, h=128, w=128, fp16=1, task=task, classes=nc, mark_heads=1)
+    outs = {t["name"]: t["dims"] for t in engine.describe_plan(plan)["tensors"] if t.get("is_output")}
+    assert outs["head0"] == [4 + nc + extra, 256] and outs["head2"] == [4 + nc + extra, 16] and outs["output"][0] == 1 + 1000 * 90
+    assert ("proto" in outs) == (task == 1)
+    if task == 1:
+        assert outs["proto"] == [32, 32, 32]
+    kinds = [o["kind"] for o in engine.describe_plan(plan, lowered=True)["ops"]]
+    assert kinds.count("plugin") == 1 and "yolo_head" not in kinds
+    with pytest.raises(Exception):
+        engine.build_plan("yolov8n", path, batch=1, h=128, w=128, task=7)

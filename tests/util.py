@@ -22,6 +22,9 @@ def synth_wts(model: str, seed: int = 0, dialect: str = "double", **kw):
         "lenet": (mt.lenet, torch.zeros(1, 1, 32, 32)),
         "resnet50": (mt.resnet50, torch.zeros(1, 3, 64, 64)),
         "yolov8n": (mt.yolov8_det, torch.zeros(1, 3, 64, 64)),
+        "yolov8n_seg": (functools.partial(mt.yolov8_det, task="seg"), torch.zeros(1, 3, 64, 64)),
+        "yolov8n_pose": (functools.partial(mt.yolov8_det, task="pose", num_class=1), torch.zeros(1, 3, 64, 64)),
+        "yolov8n_obb": (functools.partial(mt.yolov8_det, task="obb", num_class=15), torch.zeros(1, 3, 64, 64)),
         "retinaface_r50": (mt.retinaface_r50, torch.zeros(1, 3, 64, 64)),
         "rcnn_r50c4": (functools.partial(mt.rcnn_r50c4, stage="init"), torch.zeros(1, 64, 64, 3)),
     }[model]
