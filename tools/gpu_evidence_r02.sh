@@ -15,6 +15,8 @@ prof() {  # name, bench args
   rm -rf $E/prof_$1
 }
 prof c3 ""
+# the same step on ONE lane: no kernels overlap, so per-kernel durations are comparable with bench.py's serialized hipEvent profile
+TRTX_LANES=1 prof c3_lanes1 ""
 prof c2 "--config resnet50"
 prof c4 "--config retinaface_r50"
 prof c5 "--config rcnn_r50c4"
