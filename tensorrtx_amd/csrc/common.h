@@ -9,6 +9,17 @@
 
 namespace trtx {
 
+#if defined(__HIPCC__)
+// fp32 -> fp16 with the fp32 value materialised first.  Without the (empty) asm the compiler fuses "a * b" with the conversion into
+// v_fma_mixlo_f16 for SOME elements of an unrolled epilogue (one rounding) and keeps v_mul_f32 + v_cvt_f16_f32 for others (two
+// roundings): the same pixel then differs by one fp16 ulp depending on which fragment of a tile - i.e. which batch position - it
+// lands in (tests/test_gpu_engine.py::test_yolov8n_fp16_engine_640_batch32_the_bench_configuration).
+__device__ __forceinline__ _Float16 round_to_half(float v) {
+    asm("" : "+v"(v));
+    return (_Float16)v;
+}
+#endif
+
 constexpr int kYoloDetFloats = 90;  // sizeof(Detection)/4, yolov8/include/types.h:4-12
 
 inline size_t align_up(size_t v, size_t a) {

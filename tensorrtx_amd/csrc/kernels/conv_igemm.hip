@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
                     const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
                     half4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)act_fixed<ACT>(acc[i][j][e] + b4[e], p.act1, p.alpha1);
+                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(act_fixed<ACT>(acc[i][j][e] + b4[e], p.act1, p.alpha1));
                     *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
                 }
         };
@@ -417,13 +417,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
                         if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
                             const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) rv[e] = (_Float16)((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
+                            for (int e = 0; e < 8; ++e) rv[e] = round_to_half((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
                         } else {
                             rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)act_fixed<ACT>((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_fixed<ACT>((float)v[e] + (float)rv[e], p.act2, p.alpha2));
                 }
                 if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
                     unsigned long long q = 0;
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             for (int e = 0; e < 4; ++e) {
                 if (co + e < p.Cout) {
                     float x = act_apply(acc[i][j][e] + b4[e], p.act1, p.alpha1);
-                    if (second) x = act_apply((float)(_Float16)x + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
-                    orow[co + e] = (_Float16)x;
+                    if (second) x = act_apply((float)round_to_half(x) + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
+                    orow[co + e] = round_to_half(x);
                 }
             }
         }
@@ -664,13 +664,13 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
             dispatch_act(p.act1, [&](auto t1) {
                 constexpr int A1 = decltype(t1)::value;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (_Float16)act_fixed<A1>(v[e] + bb[e], p.act1, p.alpha1);
+                for (int e = 0; e < 8; ++e) o[e] = round_to_half(act_fixed<A1>(v[e] + bb[e], p.act1, p.alpha1));
             });
             if (second)
                 dispatch_act(p.act2, [&](auto t2) {
                     constexpr int A2 = decltype(t2)::value;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)act_fixed<A2>((float)o[e] + (float)rv[e], p.act2, p.alpha2);
+                    for (int e = 0; e < 8; ++e) o[e] = round_to_half(act_fixed<A2>((float)o[e] + (float)rv[e], p.act2, p.alpha2));
                 });
             *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = o;
         } else {
@@ -678,8 +678,8 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
             for (int e = 0; e < 8; ++e) {
                 if (co + e >= p.Cout) break;
                 float x = act_apply(v[e] + (p.bias ? p.bias[co + e] : 0.f), p.act1, p.alpha1);
-                if (second) x = act_apply((float)(_Float16)x + (res ? (float)res[(size_t)m * p.ld_res + co + e] : 0.f), p.act2, p.alpha2);
-                out[(size_t)m * p.ld_out + co + e] = (_Float16)x;
+                if (second) x = act_apply((float)round_to_half(x) + (res ? (float)res[(size_t)m * p.ld_res + co + e] : 0.f), p.act2, p.alpha2);
+                out[(size_t)m * p.ld_out + co + e] = round_to_half(x);
             }
         }
     }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs p) {
     for (int c8 = 0; c8 < COUT / 8; ++c8) {
         half8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (_Float16)stem_act(acc[c8 * 8 + e], p.act1, p.alpha1);
+        for (int e = 0; e < 8; ++e) v[e] = round_to_half(stem_act(acc[c8 * 8 + e], p.act1, p.alpha1));
         *reinterpret_cast<half8*>(out + c8 * 8) = v;
     }
 }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = acc[j][e] + bias4[j][e];
-                    o[e] = (_Float16)(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)));
+                    o[e] = round_to_half(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)));
                 }
             } else if (p.act1 == ACT_RELU) {
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)stem_act(acc[j][e] + bias4[j][e], p.act1, p.alpha1);
+                for (int e = 0; e < 4; ++e) o[e] = round_to_half(stem_act(acc[j][e] + bias4[j][e], p.act1, p.alpha1));
             }
             *reinterpret_cast<half4_t*>(out + m * p.ld_out + co) = o;
         }

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, ws_min_waves(ws_regs(TAPS, KC, NFW, WC, NF, RO
                     const float b4[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
                     half4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)ws_act<A1>(acc[f][j][e] + b4[e], p.act1, p.alpha1);
+                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(ws_act<A1>(acc[f][j][e] + b4[e], p.act1, p.alpha1));
                     *reinterpret_cast<half4*>(stg + (lane & 15) * RS + j * 32 + (lane >> 4) * 8) = o;
                 }
 #pragma unroll
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, ws_min_waves(ws_regs(TAPS, KC, NFW, WC, NF, RO
                         half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
                         if (res) rv = *reinterpret_cast<const half8*>(res + m * p.ld_res + co);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (_Float16)ws_act<A2>((float)v[e] + (float)rv[e], p.act2, p.alpha2);
+                        for (int e = 0; e < 8; ++e) v[e] = round_to_half(ws_act<A2>((float)v[e] + (float)rv[e], p.act2, p.alpha2));
                     }
                     *reinterpret_cast<half8*>(out + m * p.ld_out + co) = v;
                 }

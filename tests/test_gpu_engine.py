@@ -185,6 +185,45 @@ def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
     assert np.abs(dec[:, 0] - dec_ref[:, 0]).max() <= 0.02 * dec_ref[:, 0].max() + 3
 
 
+def test_yolov8n_fp16_engine_640_batch32_the_bench_configuration(gpu):
+    """Config 3 exactly as bench.py runs it (fp16, 640x640, BATCH 32, production plan).  Full-size checks that do not need 32 oracle
+    forward passes: (a) images 0..3 against the fp32 oracle as at batch 4; (b) permuting the images of the batch permutes the
+    outputs bit for bit (no cross-image leakage in tiles that span image borders, slot compaction per image); (c) the kept set of
+    the device NMS is the oracle NMS of the engine's own decode buffer, for all 32 images."""
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=32, h=640, w=640, fp16=1)
+    e = engine.Engine(plan)
+    x = torch.from_numpy(synth.images(32, 640, 640, seed=1))
+    perm = torch.tensor([(7 * i + 3) % 32 for i in range(32)])
+    outs = []
+    for xin in (x, x[perm]):
+        out = torch.full((32, 1 + 1000 * 90), float("nan"), dtype=torch.float32, device=gpu)
+        e.enqueue(32, [xin.to(gpu), out])
+        torch.cuda.synchronize()
+        outs.append(out)
+    dec, dec_p = outs[0].cpu().numpy(), outs[1].cpu().numpy()
+    # (b) record j of the permuted run is image perm[j] of the first run; only the written part of each row is defined
+    for j in range(32):
+        n = int(dec_p[j, 0])
+        assert n == int(dec[perm[j], 0]) and 0 < n <= 1000
+        assert np.array_equal(dec_p[j, 1:1 + n * 90].reshape(n, 90)[:, :6], dec[perm[j], 1:1 + n * 90].reshape(n, 90)[:, :6])
+    # (a)
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), x[:4])
+    dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
+    st = _match_detections(dec[:4], dec_ref)
+    _metric("yolov8n_fp16_640_b32", counts=dec[:4, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
+    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"] and st["min_iou"] > 0.996
+    # (c)
+    ki, kc, kd = capi.yolo_nms(outs[0])
+    torch.cuda.synchronize()
+    ri, rc, rd = yp.batch_nms_c(np.nan_to_num(dec))
+    assert np.array_equal(kc.cpu().numpy(), rc)
+    for b in range(32):
+        assert np.array_equal(ki.cpu().numpy()[b, :rc[b]], ri[b, :rc[b]])
+    e.close()
+
+
 def test_engine_decode_then_nms_pipeline(gpu):
     """enqueue -> YoloLayer plugin output stays on the device -> trtx_yolo_nms; the kept boxes must be the
     oracle NMS of the engine's own decode buffer (bit-exact selection on identical inputs)."""
