@@ -1270,7 +1270,11 @@ struct Lowerer {
         // otherwise it opens a free lane, otherwise it queues behind the lane that went idle first.  Independent branches
         // (the six cv2/cv3 head chains of YOLOv8, model.cpp:224-291; FPN/SSH branches of RetinaFace) end up on different
         // lanes and overlap on the GPU; a sequential network stays on lane 0.
-        int max_lanes = 6;
+        // At most 4 by default: HIP multiplexes all streams of a process onto 4 hardware queues (GPU_MAX_HW_QUEUES), so further lanes
+        // only alias with each other and with the caller's own copy / post-processing streams.  Measured (YOLOv8n b32, same box):
+        // 6 lanes 1.335-1.353 ms vs 4 lanes 1.354-1.360 with resident inputs, but 2.56-2.74 vs 1.67-1.71 ms once a host-fed pipeline
+        // adds an H2D stream; ResNet-50 / RetinaFace / R-CNN are 0.5-1.3 % faster with 4.  (8 or 16 hardware queues: 2.2x slower.)
+        int max_lanes = 4;
         if (const char* e = getenv("TRTX_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));
         std::vector<int> tail(max_lanes, -1);
         plan.num_lanes = 1;
