@@ -138,6 +138,8 @@ def main():
                     help="weak: fixed per-GPU batch (default); strong: the config's global batch is split over the GPUs")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "int8"],
                     help="int8: BuilderFlag::kINT8 engine (entropy calibration on 2 synthetic batches, int8 MFMA convs, fp16 fallback)")
+    ap.add_argument("--contexts", type=int, default=3,
+                    help="execution contexts kept in flight per GPU (each on its own stream; 1 = the reference's serial loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent timing table (JSON) to this path")
     args = ap.parse_args()
@@ -196,147 +198,141 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from util import synth_wts  # seeded synthetic weights through the product-side writer
         path, _ = synth_wts(args.config)
-    if args.precision == "int8":
-        from tensorrtx_amd import calibrator
-        cal_batches = [torch.from_numpy(synth.images(batch, H, W, seed=900 + k) * cfg["scale"]).to(dev) for k in range(2)]
-        with calibrator.Calibrator(batches=cal_batches, batch_size=batch).installed():
-            plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1, int8=1)
-        del cal_batches
-    else:
-        plan = engine.build_plan(args.config, path, batch=batch, h=H, w=W, fp16=1)
+    n_ctx = max(1, args.contexts)
+
+    def build(aux):
+        opts = dict(batch=batch, h=H, w=W, fp16=1)
+        if aux >= 0:
+            opts["aux_streams"] = aux        # IBuilderConfig::setMaxAuxStreams
+        if args.precision == "int8":
+            from tensorrtx_amd import calibrator
+            cal_batches = [torch.from_numpy(synth.images(batch, H, W, seed=900 + k) * cfg["scale"]).to(dev) for k in range(2)]
+            with calibrator.Calibrator(batches=cal_batches, batch_size=batch).installed():
+                return engine.build_plan(args.config, path, int8=1, **opts)
+        return engine.build_plan(args.config, path, **opts)
+
+    # Several execution contexts in flight (each on its own stream, over one set of weights) is how a throughput-oriented caller
+    # drives an engine; with them the concurrency comes from whole batches overlapping, so the contexts themselves stay on their
+    # caller's stream (setMaxAuxStreams(0)).  A single context instead spreads independent branches over 3 auxiliary streams.
+    plan = build(0 if n_ctx > 1 else -1)
     low = engine.describe_plan(plan, lowered=True)
     eng = engine.Engine(plan)
 
-    # bindings: N_INPUT_SETS rotating input batches (resident in HBM), one set of outputs
+    # bindings: N_INPUT_SETS rotating input batches (resident in HBM), one set of outputs per context
     rng_imgs = [synth.images(batch, H, W, seed=100 + 17 * rank + k) * cfg["scale"] for k in range(N_INPUT_SETS if args.config == "yolov8n" else 2)]
     nhwc_input = args.config == "rcnn_r50c4"  # DataPreprocess takes HWC images (rcnn.cpp:80-100)
     inputs = [torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1)) if nhwc_input else x).to(dev) for x in rng_imgs]
-    outs = {}
-    for i in range(eng.nb_bindings):
-        if not eng.is_input[i]:
-            outs[i] = torch.empty(batch * int(np.prod(eng.dims[i])), dtype=torch.float32, device=dev)
     in_idx = [i for i in range(eng.nb_bindings) if eng.is_input[i]][0]
-    binding_sets = [[inputs[k] if i == in_idx else outs[i] for i in range(eng.nb_bindings)] for k in range(len(inputs))]
-
     L = capi.lib()
-    stream = capi._stream()
-    if cfg["nms"]:
-        # Two result slots: NMS of step k runs on a second stream while the launch stream already executes the backbone of step k+1
-        # (the usual double-buffering of a serving loop; every step's NMS still completes inside the timed region).  Event fences:
-        # decoded[s] (launch -> nms stream) and nms_done[s] (nms -> launch stream, before slot s's decode buffer is overwritten).
-        n_res = 2
-        out_idx = eng.names.index("output")
-        out_slots = [outs[out_idx]] + [torch.empty_like(outs[out_idx]) for _ in range(n_res - 1)]
-        out = out_slots[0].reshape(batch, 1 + 1000 * 90)
-        keep_idx = [torch.empty((batch, 1000), dtype=torch.int32, device=dev) for _ in range(n_res)]
-        keep_cnt = [torch.empty((batch,), dtype=torch.int32, device=dev) for _ in range(n_res)]
-        keep_det = [torch.empty((batch, 1000, 6), dtype=torch.float32, device=dev) for _ in range(n_res)]
-        L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
-        nms_ws_bytes = L.trtx_yolo_nms_workspace(batch)
-        nms_ws = [torch.empty((nms_ws_bytes,), dtype=torch.uint8, device=dev) for _ in range(n_res)]
-        host_cnt = torch.empty((batch,), dtype=torch.int32).pin_memory()
-        host_det = torch.empty((batch, 1000, 6), dtype=torch.float32).pin_memory()
-        nms_stream = torch.cuda.Stream()
-        nms_stream_p = ctypes.c_void_p(nms_stream.cuda_stream)
-        launch_stream = torch.cuda.current_stream()
-        decoded = [torch.cuda.Event() for _ in range(n_res)]
-        nms_done = [torch.cuda.Event() for _ in range(n_res)]
-        res_sets = [[[inputs[k] if i == in_idx else (out_slots[r] if i == out_idx else outs[i]) for i in range(eng.nb_bindings)]
-                     for k in range(len(inputs))] for r in range(n_res)]
+    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
 
-    def nms_on(r, st):
-        capi.check(L.trtx_yolo_nms(capi._p(out_slots[r]), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(keep_idx[r]),
-                                   capi._p(keep_cnt[r]), capi._p(keep_det[r]), capi._p(nms_ws[r]), ctypes.c_size_t(nms_ws_bytes), st),
-                   "trtx_yolo_nms")
+    class Slot:
+        """One batch in flight: an execution context, its stream, its output / NMS / pinned host buffers."""
 
-    def step(k, with_d2h=False):
-        if not cfg["nms"]:
-            eng.enqueue(batch, binding_sets[k % len(binding_sets)])
-            return
-        r = k % n_res
-        launch_stream.wait_event(nms_done[r])        # slot r's previous NMS (step k - 2) has consumed its decode buffer
-        eng.enqueue(batch, res_sets[r][k % len(inputs)])
-        decoded[r].record(launch_stream)
-        with torch.cuda.stream(nms_stream):
-            nms_stream.wait_event(decoded[r])
-            nms_on(r, nms_stream_p)
-            if with_d2h:  # what the reference's timer includes: results back on the host (yolov8_det.cpp:97-104)
-                host_cnt.copy_(keep_cnt[r], non_blocking=True)
-                host_det.copy_(keep_det[r], non_blocking=True)  # contiguous 768 KB: two DMA copies per step
-            nms_done[r].record(nms_stream)
+        def __init__(self, e, ctx):
+            self.e, self.ctx = e, ctx
+            self.stream = torch.cuda.Stream()
+            self.stream_p = ctypes.c_void_p(self.stream.cuda_stream)
+            self.outs = {i: torch.empty(batch * int(np.prod(e.dims[i])), dtype=torch.float32, device=dev)
+                         for i in range(e.nb_bindings) if not e.is_input[i]}
+            if cfg["nms"]:
+                self.out = self.outs[e.names.index("output")].reshape(batch, 1 + 1000 * 90)
+                self.keep_idx = torch.empty((batch, 1000), dtype=torch.int32, device=dev)
+                self.keep_cnt = torch.empty((batch,), dtype=torch.int32, device=dev)
+                self.keep_det = torch.empty((batch, 1000, 6), dtype=torch.float32, device=dev)
+                self.ws_bytes = L.trtx_yolo_nms_workspace(batch)
+                self.ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+                self.host_cnt = torch.empty((batch,), dtype=torch.int32).pin_memory()
+                self.host_det = torch.empty((batch, 1000, 6), dtype=torch.float32).pin_memory()
 
-    def timed(n_steps, with_d2h=False):
+        def bindings(self, x):
+            return [x if i == in_idx else self.outs[i] for i in range(self.e.nb_bindings)]
+
+        def run(self, x, with_d2h=False):
+            """enqueue (+ device NMS (+ D2H of the detections)) of one batch, all on this slot's stream"""
+            self.ctx.enqueue(batch, self.bindings(x), stream=self.stream.cuda_stream)
+            if cfg["nms"]:
+                capi.check(L.trtx_yolo_nms(capi._p(self.out), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(self.keep_idx),
+                                           capi._p(self.keep_cnt), capi._p(self.keep_det), capi._p(self.ws), ctypes.c_size_t(self.ws_bytes),
+                                           self.stream_p), "trtx_yolo_nms")
+                if with_d2h:  # what the reference's timer includes: results back on the host (yolov8_det.cpp:97-104)
+                    with torch.cuda.stream(self.stream):
+                        self.host_cnt.copy_(self.keep_cnt, non_blocking=True)
+                        self.host_det.copy_(self.keep_det, non_blocking=True)  # contiguous 768 KB
+
+    def make_slots(e, n):
+        return [Slot(e, e if j == 0 else e.create_context()) for j in range(n)]
+
+    def timed(slots, n_steps, with_d2h=False):
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(n_steps):
-            step(k, with_d2h)
-        torch.cuda.synchronize()                     # all streams: the last steps' NMS / copies are inside the timed region
+            slots[k % len(slots)].run(inputs[k % len(inputs)], with_d2h)   # step k; steps on the same slot are ordered by its stream
+        torch.cuda.synchronize()                     # all streams: every step's NMS / copies end inside the timed region
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         return replicas.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
+    slots = make_slots(eng, n_ctx)
     for k in range(args.warmup):
-        step(k)
-    dt = timed(args.steps)
+        slots[k % n_ctx].run(inputs[k % len(inputs)])
+    dt = timed(slots, args.steps)
     detections = None
     if cfg["nms"]:
-        last = (args.steps - 1) % n_res
-        detections = {"decode_candidates_per_image": float(out_slots[last].reshape(batch, -1)[:, 0].float().mean().item()),
-                      "kept_after_nms_per_image": float(keep_cnt[last].float().mean().item()),
+        torch.cuda.synchronize()
+        last = slots[(args.steps - 1) % n_ctx]
+        detections = {"decode_candidates_per_image": float(last.out[:, 0].float().mean().item()),
+                      "kept_after_nms_per_image": float(last.keep_cnt.float().mean().item()),
                       "note": "last timed step; seeded random weights: counts are not those of a trained model"}
-    dt_d2h = timed(args.steps, with_d2h=True) if cfg["nms"] else None
+    dt_d2h = timed(slots, args.steps, with_d2h=True) if cfg["nms"] else None
+    # the reference's own loop shape for comparison: ONE context, batches strictly one after the other (3 auxiliary streams inside it)
+    dt_single = None
+    if n_ctx > 1:
+        eng1 = engine.Engine(build(-1))
+        one = make_slots(eng1, 1)
+        for k in range(min(args.warmup, 5)):
+            one[0].run(inputs[k % len(inputs)])
+        dt_single = timed(one, args.steps)
+        eng1.close()
 
     # Host-fed variant (not `value`): what a caller pays when the boundary hands over HOST images, as the reference's demo does
     # (yolov8_det.cpp:146-160: cuda_batch_preprocess of cv::Mat frames, infer, D2H).  Raw uint8 HWC frames sit in pinned host
-    # memory; a copy stream uploads batch k+1 while the launch stream runs letterbox (preprocess.cu twin) -> enqueue -> NMS -> D2H
-    # of batch k.  Two slots, event-fenced both ways.
+    # memory; a copy stream uploads batch k+1 while the slots run letterbox (preprocess.cu twin) -> enqueue -> NMS -> D2H of the
+    # batches before it.  n_ctx + 1 upload buffers, event-fenced both ways.
     dt_host = None
     if cfg["nms"]:
         from tensorrtx_amd import preproc
-        n_slots = 2
+        n_up = n_ctx + 1
         # the same synthetic scenes as the resident-input legs, as camera frames: uint8, HWC, BGR
-        frames = [torch.from_numpy(np.ascontiguousarray((np.clip(rng_imgs[s], 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8).transpose(0, 2, 3, 1)[..., ::-1]))
-                  .pin_memory() for s in range(n_slots)]
-        raw = [torch.empty((batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-        net_in = [torch.empty((batch, 3, H, W), dtype=torch.float32, device=dev) for _ in range(n_slots)]
-        host_sets = [[[net_in[s] if i == in_idx else (out_slots[r] if i == out_idx else outs[i]) for i in range(eng.nb_bindings)]
-                      for r in range(n_res)] for s in range(n_slots)]
+        frames = [torch.from_numpy(np.ascontiguousarray((np.clip(rng_imgs[s % len(rng_imgs)], 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+                                                        .transpose(0, 2, 3, 1)[..., ::-1])).pin_memory() for s in range(n_up)]
+        raw = [torch.empty((batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n_up)]
+        net_in = [torch.empty((batch, 3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
         copy_stream = torch.cuda.Stream()
-        uploaded = [torch.cuda.Event() for _ in range(n_slots)]
-        consumed = [torch.cuda.Event() for _ in range(n_slots)]
-        main_stream = torch.cuda.current_stream()
+        uploaded = [torch.cuda.Event() for _ in range(n_up)]
+        consumed = [torch.cuda.Event() for _ in range(n_up)]
 
         def upload(s):
             with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(consumed[s])      # the letterbox kernel of the previous user of this slot is done
-                # in pieces of 4 frames (4.9 MB, ~0.1 ms): HIP multiplexes all streams of a process onto 4 hardware queues, so the
-                # copy stream shares one with an engine lane, and a single 39 MB copy would hold that lane's kernels up for ~1 ms
-                for i in range(0, batch, 4):
-                    raw[s][i:i + 4].copy_(frames[s][i:i + 4], non_blocking=True)
+                copy_stream.wait_event(consumed[s])      # the letterbox kernel of the previous user of this buffer is done
+                raw[s].copy_(frames[s], non_blocking=True)
                 uploaded[s].record(copy_stream)
 
         def host_step(k):
-            s, r = k % n_slots, k % n_res
-            main_stream.wait_event(nms_done[r])
-            main_stream.wait_event(uploaded[s])
-            preproc.letterbox_batch(list(raw[s]), W, H, out=net_in[s])
-            consumed[s].record(main_stream)
-            eng.enqueue(batch, host_sets[s][r])
-            decoded[r].record(main_stream)
-            with torch.cuda.stream(nms_stream):
-                nms_stream.wait_event(decoded[r])
-                nms_on(r, nms_stream_p)
-                host_cnt.copy_(keep_cnt[r], non_blocking=True)
-                host_det.copy_(keep_det[r], non_blocking=True)
-                nms_done[r].record(nms_stream)
+            s, slot = k % n_up, slots[k % n_ctx]
+            with torch.cuda.stream(slot.stream):
+                slot.stream.wait_event(uploaded[s])
+                preproc.letterbox_batch(list(raw[s]), W, H, out=net_in[k % n_ctx])
+                consumed[s].record(slot.stream)
+            slot.run(net_in[k % n_ctx], with_d2h=True)
 
         def host_timed(n_steps):
-            for s in range(n_slots):
-                consumed[s].record(main_stream)
+            for s in range(n_up):
+                consumed[s].record(torch.cuda.current_stream())
             torch.cuda.synchronize()
             if dist:
                 dist.barrier()
@@ -345,7 +341,7 @@ def main():
             upload(0)
             for k in range(n_steps):
                 if k + 1 < n_steps:
-                    upload((k + 1) % n_slots)            # prefetch the next batch while this one computes
+                    upload((k + 1) % n_up)               # prefetch the next batch while the earlier ones compute
                 host_step(k)
             torch.cuda.synchronize()
             if dist:
@@ -353,7 +349,7 @@ def main():
             torch.cuda.synchronize()
             return replicas.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
-        host_timed(min(4, args.steps))                   # warm the path (letterbox kernel, pinned copies)
+        host_timed(min(2 * n_ctx, args.steps))           # warm the path (letterbox kernel, pinned copies)
         dt_host = host_timed(args.steps)
 
     # per-kernel timing with HIP events on the launch stream (IProfiler analogue): roofline of the dominant kernel
@@ -361,7 +357,7 @@ def main():
     conv_ms = tot_ms = 0.0
     n_conv = 0
     for _ in range(prof_runs):
-        rows = eng.profile(batch, binding_sets[0])
+        rows = eng.profile(batch, slots[0].bindings(inputs[0]))
         conv = [r for r, o in zip(rows, low["ops"]) if o["kind"] == "conv" and o.get("igemm")]
         n_conv = len(conv)
         conv_ms += sum(r["ms"] for r in conv)
@@ -410,12 +406,19 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": mode,
         "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "i8 (+f16 fallback layers)", "data": "synthetic",
         "config": {"workload": f"{args.config} {args.precision} {W}x{H}, {cfg['tag']}: per-GPU batch {batch}, " +
-                               ("enqueue + GPU NMS (NMS of step k on a second stream, overlapping the backbone of step k+1; two result slots)" if cfg["nms"] else "enqueue (all plugins inside the engine)") +
-                               f", {len(binding_sets)} rotating input batches resident in HBM",
+                               ("enqueue + GPU NMS" if cfg["nms"] else "enqueue (all plugins inside the engine)") +
+                               (f", {n_ctx} execution contexts in flight (one stream each, setMaxAuxStreams(0)); every step is a full batch-{batch} pass"
+                                if n_ctx > 1 else ", one execution context (3 auxiliary streams), steps strictly in sequence") +
+                               f", {len(inputs)} rotating input batches resident in HBM",
+                   "contexts": n_ctx,
                    "global_batch": global_batch, "parallelism": f"replica-per-GPU x{world} (image-sharded, no data-path collective; RCCL only brackets the timed region)",
                    "weights": "seeded synthetic .wts (no trained weights offline)"},
         "roofline": roofline,
     }
+    if dt_single is not None:
+        res["single_context"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_single, "unit": "images/sec",
+                                 "ms_per_step": dt_single / args.steps * 1e3,
+                                 "what": "the same K steps through ONE execution context, strictly one batch after the other (the shape of the reference's loop, yolov8_det.cpp:97-104): the per-batch latency figure"}
     if cfg["nms"]:
         res["d2h_inclusive"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_d2h, "unit": "images/sec",
                                 "ms_per_step": dt_d2h / args.steps * 1e3,

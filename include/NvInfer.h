@@ -832,6 +832,7 @@ class IBuilderConfig {
     void setMaxWorkspaceSize(size_t bytes) noexcept { trtx_builder_set_workspace(mB, bytes); }
     void setMemoryPoolLimit(MemoryPoolType, size_t bytes) noexcept { trtx_builder_set_workspace(mB, bytes); }
     void setFlag(BuilderFlag f) noexcept { trtx_builder_set_flag(mB, (int32_t)f, 1); }
+    void setMaxAuxStreams(int32_t n) noexcept { trtx_builder_set_max_aux_streams(mB, n); }
     void clearFlag(BuilderFlag f) noexcept { trtx_builder_set_flag(mB, (int32_t)f, 0); }
     void setInt8Calibrator(IInt8Calibrator* c) noexcept {
         trtx_calibrator_vtbl v{};

@@ -397,6 +397,10 @@ typedef struct trtx_calibrator_vtbl {
     const void* (*read_cache)(void* self, size_t* length); /* NULL / length 0: no cache */
     void (*write_cache)(void* self, const void* cache, size_t length);
 } trtx_calibrator_vtbl;
+/* IBuilderConfig::setMaxAuxStreams (TensorRT >= 8.6): how many streams besides the caller's an execution context may use to run
+ * independent branches of the plan concurrently.  -1 (default) = the runtime's choice (3); 0 = strictly the caller's stream, the
+ * right setting when several execution contexts are kept in flight on their own streams (bench.py --contexts). */
+int32_t trtx_builder_set_max_aux_streams(trtx_builder* b, int32_t n);
 int32_t trtx_builder_set_int8_calibrator(trtx_builder* b, const trtx_calibrator_vtbl* calibrator);
 /* the threshold search of the entropy calibration on a caller-supplied histogram of |x| over [0, range] (tests, tools) */
 float trtx_int8_entropy_threshold(const double* hist, int32_t bins, float range);

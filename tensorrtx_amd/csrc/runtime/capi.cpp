@@ -15,6 +15,7 @@ struct trtx_builder {
     int max_batch = 1;
     bool fp16 = false;
     bool int8 = false;
+    int max_aux_streams = -1;
     size_t workspace = 0;
     trtx_calibrator_vtbl calib{};  // IBuilderConfig::setInt8Calibrator
 };
@@ -56,6 +57,11 @@ extern "C" int32_t trtx_builder_set_flag(trtx_builder* b, int32_t flag, int32_t 
         b->int8 = on != 0;
     else
         return TRTX_ERR_INVALID;
+    return TRTX_OK;
+}
+extern "C" int32_t trtx_builder_set_max_aux_streams(trtx_builder* b, int32_t n) {
+    if (!b || n < -1 || n > 15) return TRTX_ERR_INVALID;
+    b->max_aux_streams = n;
     return TRTX_OK;
 }
 extern "C" int32_t trtx_builder_set_int8_calibrator(trtx_builder* b, const trtx_calibrator_vtbl* calibrator) {
@@ -345,6 +351,7 @@ extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_
     if (!b || !n || !out) return TRTX_ERR_INVALID;
     n->net.max_batch = b->max_batch;
     n->net.fp16 = b->fp16;
+    n->net.max_aux_streams = b->max_aux_streams;
     n->net.int8 = false;
     n->net.tensor_scale.clear();
     if (n->net.output_ids().empty()) {

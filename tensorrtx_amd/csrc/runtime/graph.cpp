@@ -393,12 +393,13 @@ void Network::serialize(std::vector<uint8_t>& out, std::vector<std::array<size_t
     Writer w{out};
     if (w_offsets) w_offsets->assign(layers.size(), {0, 0, 0});
     w.raw(kMagic, 8);
-    w.pod<uint32_t>(2);  // format version (2: + int8 flag and per-tensor calibration scales)
+    w.pod<uint32_t>(3);  // format version (2: + int8 flag and per-tensor calibration scales; 3: + max_aux_streams)
     w.pod<uint8_t>(explicit_batch);
     w.pod<uint8_t>(fp16);
     w.pod<uint8_t>(int8);
     w.pod<uint32_t>((uint32_t)tensor_scale.size());
     for (float sc : tensor_scale) w.pod<float>(sc);
+    w.pod<int32_t>(max_aux_streams);
     w.pod<int32_t>(max_batch);
     w.pod<uint32_t>((uint32_t)tensors.size());
     for (const auto& t : tensors) {
@@ -460,7 +461,7 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
         return nullptr;
     }
     const uint32_t version = r.pod<uint32_t>();
-    if (version != 1 && version != 2) {
+    if (version < 1 || version > 3) {
         if (err) *err = "unsupported plan version";
         return nullptr;
     }
@@ -475,6 +476,13 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
             return nullptr;
         }
         for (uint32_t i = 0; i < ns; ++i) n->tensor_scale.push_back(r.pod<float>());
+    }
+    if (version >= 3) {
+        n->max_aux_streams = r.pod<int32_t>();
+        if (n->max_aux_streams < -1 || n->max_aux_streams > 15) {
+            if (err) *err = "corrupt plan (max_aux_streams)";
+            return nullptr;
+        }
     }
     n->max_batch = r.pod<int32_t>();
     const uint32_t nt = r.pod<uint32_t>();
@@ -588,7 +596,7 @@ std::string Network::describe_json() const {
         serialize(tmp, &offs);
     }
     std::ostringstream o;
-    o << "{\"explicit_batch\":" << (explicit_batch ? "true" : "false") << ",\"fp16\":" << (fp16 ? "true" : "false") << ",\"int8\":" << (int8 ? "true" : "false")
+    o << "{\"explicit_batch\":" << (explicit_batch ? "true" : "false") << ",\"fp16\":" << (fp16 ? "true" : "false") << ",\"int8\":" << (int8 ? "true" : "false") << ",\"max_aux_streams\":" << max_aux_streams
       << ",\"max_batch\":" << max_batch << ",\"tensors\":[";
     for (size_t i = 0; i < tensors.size(); ++i) {
         const auto& t = tensors[i];

@@ -101,6 +101,7 @@ class Network {
     bool explicit_batch;
     int max_batch = 1;  // implicit-batch capacity (IBuilder::setMaxBatchSize)
     bool fp16 = false;  // BuilderFlag::kFP16
+    int max_aux_streams = -1;  // IBuilderConfig::setMaxAuxStreams: extra streams (lanes) a context may use; -1 = runtime default
     bool int8 = false;  // BuilderFlag::kINT8: tensor_scale holds the calibrated activation scales (0 = not calibrated)
     std::vector<float> tensor_scale;  // per network tensor: real value = int8 value * scale
     std::vector<TensorDef> tensors;

@@ -1274,8 +1274,8 @@ struct Lowerer {
         // only alias with each other and with the caller's own copy / post-processing streams.  Measured (YOLOv8n b32, same box):
         // 6 lanes 1.335-1.353 ms vs 4 lanes 1.354-1.360 with resident inputs, but 2.56-2.74 vs 1.67-1.71 ms once a host-fed pipeline
         // adds an H2D stream; ResNet-50 / RetinaFace / R-CNN are 0.5-1.3 % faster with 4.  (8 or 16 hardware queues: 2.2x slower.)
-        int max_lanes = 4;
-        if (const char* e = getenv("TRTX_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));
+        int max_lanes = net.max_aux_streams >= 0 ? 1 + net.max_aux_streams : 4;  // IBuilderConfig::setMaxAuxStreams
+        if (const char* e = getenv("TRTX_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));  // A/B override
         std::vector<int> tail(max_lanes, -1);
         plan.num_lanes = 1;
         for (int k = 0; k < nops; ++k) {

@@ -73,9 +73,7 @@ class Engine:
 
     def enqueue(self, batch, bindings, stream=None):
         """bindings: list of CUDA tensors in binding order (inputs first). Async on the current stream."""
-        arr = (ctypes.c_void_p * self.nb_bindings)(*[t.data_ptr() for t in bindings])
-        st = capi._stream() if stream is None else ctypes.c_void_p(stream)
-        check(lib().trtx_context_enqueue(self._c, batch, arr, st), "trtx_context_enqueue")
+        _enqueue(self._c, self.nb_bindings, batch, bindings, stream)
 
     def profile(self, batch, bindings):
         arr = (ctypes.c_void_p * self.nb_bindings)(*[t.data_ptr() for t in bindings])
@@ -85,7 +83,15 @@ class Engine:
         lib().trtx_string_free(out)
         return json.loads(js)
 
+    def create_context(self):
+        """ICudaEngine::createExecutionContext: a further context (own activation arena, lane streams and events) over the same
+        weights.  Several contexts may be in flight at once, each on its own stream (bench.py --contexts)."""
+        return ExecutionContext(self)
+
     def close(self):
+        for c in getattr(self, "_extra", []):
+            c.close()
+        self._extra = []
         if self._c:
             lib().trtx_context_destroy(self._c)
             self._c = None
@@ -98,3 +104,29 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def _enqueue(ctx, nb, batch, bindings, stream):
+    arr = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in bindings])
+    st = capi._stream() if stream is None else ctypes.c_void_p(stream)
+    check(lib().trtx_context_enqueue(ctx, batch, arr, st), "trtx_context_enqueue")
+
+
+class ExecutionContext:
+    """One more IExecutionContext of an Engine (the Engine object owns it and destroys it before the engine)."""
+
+    def __init__(self, eng: Engine):
+        self.engine = eng
+        self._c = ctypes.c_void_p()
+        check(lib().trtx_context_create(eng._e, ctypes.byref(self._c)), "trtx_context_create")
+        if not hasattr(eng, "_extra"):
+            eng._extra = []
+        eng._extra.append(self)
+
+    def enqueue(self, batch, bindings, stream=None):
+        _enqueue(self._c, self.engine.nb_bindings, batch, bindings, stream)
+
+    def close(self):
+        if self._c:
+            lib().trtx_context_destroy(self._c)
+            self._c = None

@@ -57,6 +57,11 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
         }
         config->setInt8Calibrator(calibrator.get());
     }
+    if (o.count("aux_streams")) {
+        const int aux = geti(o, "aux_streams", -1);
+        if (aux < -1 || aux > 15) return TRTX_ERR_INVALID;  // the shim's setter is void (as TensorRT's): range-check here
+        config->setMaxAuxStreams(aux);
+    }
     std::unique_ptr<IHostMemory> plan;
     const std::string m(model);
     if (m == "lenet") {

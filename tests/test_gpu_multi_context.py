@@ -1,0 +1,69 @@
+"""Several execution contexts of one engine in flight at once (ICudaEngine::createExecutionContext x N, one stream each - how
+bench.py drives the engines): every context must produce, bit for bit, what a lone context produces for the same input.  Covers
+shared-state hazards: weights and plugin objects are shared, arenas / workspaces / lane streams are per context."""
+import numpy as np
+import pytest
+import torch
+
+from tensorrtx_amd import engine, synth
+from util import synth_wts
+
+pytestmark = pytest.mark.gpu
+
+
+def _outputs(e, batch, gpu):
+    return {i: torch.zeros(batch * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(e.nb_bindings) if not e.is_input[i]}
+
+
+def _check(model, batch, h, w, xs, gpu, rounds=4, rec=0, **opts):
+    path, _ = synth_wts(model)
+    e = engine.Engine(engine.build_plan(model, path, batch=batch, h=h, w=w, fp16=1, aux_streams=0, **opts))
+    try:
+        n = len(xs)
+        xs = [x.to(gpu) for x in xs]
+        # reference: one context, one input after the other
+        want = []
+        for x in xs:
+            o = _outputs(e, batch, gpu)
+            e.enqueue(batch, [x if e.is_input[i] else o[i] for i in range(e.nb_bindings)])
+            torch.cuda.synchronize()
+            want.append({i: t.cpu() for i, t in o.items()})
+        ctxs = [e] + [e.create_context() for _ in range(n - 1)]
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        outs = [_outputs(e, batch, gpu) for _ in range(n)]
+        torch.cuda.synchronize()
+        for r in range(rounds):          # keep all contexts busy at the same time, several rounds back to back
+            for j in range(n):
+                k = (j + r) % n          # context j sees a different input every round
+                ctxs[j].enqueue(batch, [xs[k] if e.is_input[i] else outs[j][i] for i in range(e.nb_bindings)], stream=streams[j].cuda_stream)
+        torch.cuda.synchronize()
+        for j in range(n):
+            k = (j + rounds - 1) % n
+            for i, t in outs[j].items():
+                got, ref = t.cpu().reshape(batch, -1), want[k][i].reshape(batch, -1)
+                if rec:  # decode buffers: [count, count x rec floats, untouched tail (stale records of earlier rounds)]
+                    assert torch.equal(got[:, 0], ref[:, 0])
+                    for b in range(batch):
+                        m = 1 + int(ref[b, 0]) * rec
+                        assert torch.equal(got[b, :m], ref[b, :m]), f"{model}: context {j} image {b} differs from the serial run"
+                else:
+                    assert torch.equal(got, ref), f"{model}: context {j} output '{e.names[i]}' differs from the serial run"
+    finally:
+        e.close()
+
+
+def test_yolov8n_three_contexts_in_flight(gpu):
+    xs = [torch.from_numpy(synth.images(8, 640, 640, seed=40 + k)) for k in range(3)]
+    _check("yolov8n", 8, 640, 640, xs, gpu, rec=90)
+
+
+def test_retinaface_three_contexts_in_flight(gpu):
+    xs = [(torch.from_numpy(synth.images(2, 640, 640, seed=50 + k)) * 255 - 110) / 64 for k in range(3)]
+    _check("retinaface_r50", 2, 640, 640, xs, gpu, rec=15)
+
+
+def test_rcnn_three_contexts_in_flight(gpu):
+    """user plugins (the reference-named R-CNN classes) shared by the contexts"""
+    g = torch.Generator().manual_seed(60)
+    xs = [torch.rand(2, 320, 416, 3, generator=g) * 255.0 for _ in range(3)]
+    _check("rcnn_r50c4", 2, 320, 416, xs, gpu)

@@ -382,3 +382,16 @@ def test_yolov8_task_graphs_build_and_lower_on_the_host(task, name, nc, extra):
     assert kinds.count("plugin") == 1 and "yolo_head" not in kinds
     with pytest.raises(Exception):
         engine.build_plan("yolov8n", path, batch=1, h=128, w=128, task=7)
+
+
+def test_max_aux_streams_travels_in_the_plan_and_bounds_the_lanes():
+    """IBuilderConfig::setMaxAuxStreams (TensorRT >= 8.6): stored in the plan (format 3), lanes = 1 + aux streams."""
+    from util import synth_wts
+    path, _ = synth_wts("yolov8n")
+    for aux, lanes in ((None, 4), (0, 1), (1, 2), (3, 4)):
+        kw = {} if aux is None else dict(aux_streams=aux)
+        plan = engine.build_plan("yolov8n", path, batch=2, h=128, w=128, fp16=1, **kw)
+        assert engine.describe_plan(plan)["max_aux_streams"] == (-1 if aux is None else aux)
+        assert engine.describe_plan(plan, lowered=True)["n_lanes"] == lanes
+    with pytest.raises(Exception):
+        engine.build_plan("yolov8n", path, batch=2, h=128, w=128, aux_streams=99)
