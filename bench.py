@@ -362,6 +362,14 @@ def main():
         n_conv = len(conv)
         conv_ms += sum(r["ms"] for r in conv)
         tot_ms += sum(r["ms"] for r in rows)
+    tac = eng.tactics()
+    moved = [t for t in tac if t["tactic"] != t["default"]]
+    tactic_summary = {"convs_timed": len(tac), "moved_off_default": len(moved),
+                      "default_sum_us": round(sum(t["default_us"] for t in tac if t["default_us"] > 0), 1),
+                      "chosen_sum_us": round(sum(t["us"] for t in tac if t["us"] > 0), 1),
+                      "what": "in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp); TRTX_TUNE=0 disables"}
+    if args.dump_ops and rank == 0:
+        json.dump(tac, open(args.dump_ops + ".tactics.json", "w"), indent=0)
     if args.dump_ops and rank == 0:
         json.dump([dict(r, **{k: o.get(k) for k in ("cin", "cout", "k", "hw_in", "hw_out", "residual", "flops", "kernel")})
                    for r, o in zip(rows, low["ops"])], open(args.dump_ops, "w"), indent=0)
@@ -399,6 +407,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "arithmetic_intensity_flop_per_byte": intensity,
                 "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms, "hbm_view": hbm_view, "mfma_view": mfma_view,
+                "tactics": tactic_summary,
                 "whole_step_hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": alg_bytes / (dt / args.steps) / 1e9}}
     res = {
         "metric": f"images/sec @ batch={cfg['batch']} {W}x{H} {args.precision} ({args.config}" + (" conv backbone + YoloLayer decode + NMS)" if cfg["nms"] else ", IExecutionContext::enqueue)"),

@@ -233,6 +233,13 @@ int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, in
                                 const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int sh, int sw,
                                 int ph, int pw, int act1, const void* residual, int ld_res, int act2,
                                 trtx_stream_t stream);
+/* Tactics of that launch (tests / tools): the exchangeable launch configurations of the layer trtx_op_conv2d_nhwc_f16 would
+ * run, 5 ints each {column-tile width, k-step width, rows per tile, wave-split-K (1 off / 2 on), weight-stationary (1 off / 2 on)};
+ * entry 0 is the default.  Returns the count (<= max_out).  trtx_op_conv_force_tactic pins the configuration used by the following
+ * trtx_op_conv2d_nhwc_f16 calls of this process (NULL: back to the default). */
+int32_t trtx_op_conv2d_tactics(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                               int has_residual, int ld_res, int32_t* out5, int32_t max_out);
+int32_t trtx_op_conv_force_tactic(const int32_t* tactic5);
 int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad, int ld_out,
                                      trtx_stream_t stream);
 int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ld_in,
@@ -471,6 +478,12 @@ int32_t trtx_engine_binding_dims(const trtx_engine* e, int32_t index, trtx_dims*
 int32_t trtx_engine_binding_dtype(const trtx_engine* e, int32_t index);
 int32_t trtx_engine_max_batch(const trtx_engine* e);
 size_t trtx_engine_device_memory(const trtx_engine* e);
+/* Tactic selection (TensorRT's builder times several kernels per layer and keeps the fastest; buildSerializedNetwork,
+ * yolov8/src/model.cpp:327).  Here it runs inside trtx_engine_deserialize: every MFMA convolution's exchangeable launch
+ * configurations are timed in place, behind their real producers, and a layer leaves its default for one that is >= 3 % faster
+ * (TRTX_TUNE=0: defaults only).  Returns JSON [{op, name, tactic, default, us, default_us, candidates}, ...]; free with
+ * trtx_string_free. */
+int32_t trtx_engine_tactics(const trtx_engine* e, char** json_out);
 /* Multi-GPU in one process (reference: tutorials/multi_GPU_processing.md:13-30, one `Plan` per device after cudaSetDevice(i)):
  * an engine is bound to the HIP device that was current at trtx_engine_deserialize; this returns its ordinal (-1 for NULL).
  * trtx_context_create / enqueue / enqueue_v3 / profile return TRTX_ERR_STATE when another device is current. */

@@ -52,7 +52,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int BM = 128;
 constexpr int NSTAGE = 3;
 constexpr unsigned kOOB = 0x80000000u;  // offset beyond any num_records: the buffer load returns 0
 constexpr int kMaxTaps = 30;            // tap-validity mask is one 32-bit word (+2 bits of run-out past the last tap)
@@ -109,11 +108,15 @@ __device__ __forceinline__ int swz(int row) {
 // I8: int8 activations / weights on v_mfma_i32_16x16x64_i8 (kINT8 engines).  A 64-byte LDS row then holds 64 int8 channels
 // instead of 32 halfs; the host passes the input-side geometry in 2-byte units (see ConvArgs), so the whole operand path
 // below is byte-for-byte the fp16 one - only the MFMA and the epilogue's dequantise / requantise differ.
-template <int NFRAG, int BKT, int TPS, bool I8 = false>
+// MI = 16-row MFMA fragments per wave along M: 2 -> a 128-row tile (the default), 1 -> a 64-row tile (twice the workgroups for
+// layers whose 128-row tiling leaves most of the 256 CUs idle; chosen per layer by the tactic tuner, runtime/tune.cpp).
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
     constexpr int BN = 16 * NFRAG;
+    constexpr int BM = 64 * MI;                    // rows per tile: every wave owns 16 * MI of them
+    constexpr int WR = 16 * MI;                    // rows per wave
     constexpr int ROW_B = BKT * 2;                 // bytes per LDS row
     constexpr int CH = BKT / 8;                    // 16-byte chunks per row
     constexpr int RPI = 64 / CH;                   // rows filled by one wave-instruction (16 / 8)
@@ -279,10 +282,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         }
     };
 
-    floatx4 acc[2][NFRAG];
-    intx4 acci[2][NFRAG];
+    floatx4 acc[MI][NFRAG];
+    intx4 acci[MI][NFRAG];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NFRAG; ++j) {
             acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -295,31 +298,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     int f_off[KSUB];
 #pragma unroll
     for (int h = 0; h < KSUB; ++h) f_off[h] = frow * ROW_B + ((((lane >> 4) + 4 * h) ^ fswz) * 16);
-    const int a_frag = wave * 32 * ROW_B;
+    const int a_frag = wave * WR * ROW_B;
 
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int h = 0; h < KSUB; ++h) {
             if constexpr (I8) {
-                intx4 af[2];
+                intx4 af[MI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const intx4*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const intx4*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) {
                     const intx4 bf = *reinterpret_cast<const intx4*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acci[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf, af[i], acci[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i) acci[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf, af[i], acci[i][j], 0, 0, 0);
                 }
             } else {
-                half8 af[2];
+                half8 af[MI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) {
                     const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: bias/BN + act1 in registers (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15) of
-    // its wave's 32 rows), then through a wave-private LDS tile so that global traffic is row-major 16-byte chunks:
+    // its wave's WR rows), then through a wave-private LDS tile so that global traffic is row-major 16-byte chunks:
     // residual reads and output stores cover whole 128-byte lines instead of 32-byte slivers.
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
@@ -371,21 +374,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
             const float c4[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = (float)acci[i][j][e] * c4[e];
         }
     }
     if (!p.scalar_out) {
         constexpr int RS = BN * 2 + 16;  // padded row stride: 16 consecutive rows start in distinct bank groups
-        static_assert(4 * 32 * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
+        static_assert(4 * WR * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
         __syncthreads();  // every wave is done reading the last stage
-        char* mine = smem + wave * 32 * RS;
+        char* mine = smem + wave * WR * RS;
         // act1 is wave-uniform: select the code path once, not per element (the kernel is instruction-issue bound)
         auto stage1 = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) {
                     const int co = n0 + j * 16 + ch_in;
@@ -401,13 +404,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         dispatch_act(p.act1, stage1);
         // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
         constexpr int CPR = BN / 8;  // 16-byte chunks per row
+        constexpr int ITEMS = WR * CPR;  // 16-byte items of this wave's tile
         auto stage2 = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int t = 0; t < NFRAG; ++t) {
+            for (int t = 0; t < (ITEMS + 63) / 64; ++t) {
                 const int q = t * 64 + lane;
+                if (ITEMS % 64 != 0 && q >= ITEMS) break;
                 const int row = q / CPR, cc = q % CPR;
-                const int m = m0 + wave * 32 + row;
+                const int m = m0 + wave * WR + row;
                 const int co = n0 + cc * 8;
                 if (m >= p.M || co >= p.Cout) continue;
                 half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
@@ -444,8 +449,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     }
     // ragged channel counts / unaligned slices: element-wise stores straight from the accumulators
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wave * 32 + i * 16 + px_in;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wave * WR + i * 16 + px_in;
         if (m >= p.M) continue;
         _Float16* orow = out + (size_t)m * p.ld_out;
         const _Float16* rrow = res ? res + (size_t)m * p.ld_res : nullptr;
@@ -695,30 +700,45 @@ void launch_wsk(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStrea
                        chunk);
 }
 
-template <int NFRAG, int BKT, int TPS, bool I8 = false>
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2>
 void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
-    const int BN = 16 * NFRAG;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
+    const int BN = 16 * NFRAG, BMT = 64 * MI;
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.Cout_pad / BN;
     const int total = tiles_m * tiles_n;
     static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
     const int chunk = plain ? 0 : (total + 7) / 8;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes,
-                       tiles_n, total, chunk, dbg);
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
+                       w_bytes, tiles_n, total, chunk, dbg);
 }
 
-template <int BKT, int TPS, bool I8 = false>
+template <int BKT, int TPS, bool I8 = false, int MI = 2>
 int32_t launch_bn(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     switch (a.bn) {
-        case 16: launch<1, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
-        case 32: launch<2, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
-        case 64: launch<4, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
-        case 80: launch<5, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
-        case 128: launch<8, BKT, TPS, I8>(a, in_bytes, w_bytes, s); break;
+        case 16: launch<1, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+        case 32: launch<2, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+        case 64: launch<4, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+        case 80: launch<5, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+        case 128: launch<8, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return TRTX_OK;
 }
+
+bool valid_bn(int bn) { return bn == 16 || bn == 32 || bn == 64 || bn == 80 || bn == 128; }
+
+// the wave-split-K variant exists for 64- and 80-wide column tiles of fp16 layers with 32-wide k-steps
+bool wsk_possible(const ConvArgs& a) {
+    return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bk == 32 && a.CinK % 32 == 0 && (a.bn == 64 || a.bn == 80) && a.Kpad / 32 >= 4;
+}
+// ... and is what the untuned dispatch picks for few tiles with a long k-chain
+bool wsk_default(const ConvArgs& a) {
+    static const bool no_wsk = getenv("TRTX_CONV_NOWSK") != nullptr;  // A/B switch for the micro-benchmarks
+    const int tiles128 = ((a.M + 127) / 128) * (a.Cout_pad / a.bn);
+    return !no_wsk && wsk_possible(a) && tiles128 <= 256 && a.Kpad / 32 >= 16;
+}
+// 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
+bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 
 }  // namespace
 
@@ -737,7 +757,8 @@ int conv_igemm_pick_bk(int cin, int taps) {
     // 64-wide steps touch whole 128-B lines (the vector L1 serves lines, not halves) and halve the barriers, but their
     // 24..32 KB stages are double- instead of triple-buffered and occupancy drops.  Measured on YOLOv8n b32: isolated
     // 3x3 layers over Cin % 64 == 0 gain 5-12 %, 1x1 layers lose 15-20 %, and with 3x3-only selection the whole engine
-    // step is still 4 % slower (1.61 vs 1.54 ms on the same box): opt-in.
+    // step is still 4 % slower (1.61 vs 1.54 ms on the same box): not a static default; the tactic tuner (runtime/tune.cpp)
+    // times it per layer (the packed weights of a Cin % 64 == 0 layer are the same for both widths).
     static const bool allow64 = getenv("TRTX_CONV_BK64") != nullptr;
     return (cin % 64 == 0 && taps >= 9 && allow64) ? 64 : 32;
 }
@@ -755,13 +776,61 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const bool cink_ok = a.CinK % bk == 0 || (a.CinK == 16 && bk == 32);
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
     return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
-           a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9;
+           a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9 &&
+           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)));
+}
+
+// ---- tactics: the launch configurations of one layer that produce the SAME packed-weight layout, so that they can be exchanged
+// at run time.  Entry 0 is what the untuned dispatch does.  Tiles of any width / height accumulate every output element over
+// K in the same order (bit-identical results); the wave-split-K and weight-stationary kernels sum in a different order (fp16
+// results may differ in the last place).
+int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out) {
+    int n = 0;
+    auto push = [&](int bn, int bk, int bm, int wsk, int ws) {
+        for (int i = 0; i < n; ++i)
+            if (out[i].bn == bn && out[i].bk == bk && out[i].bm == bm && out[i].wsk == wsk && out[i].ws == ws) return;
+        if (n < max_out) out[n++] = ConvTactic{bn, bk, bm, wsk, ws};
+    };
+    ConvArgs a = a0;
+    a.bm = 0; a.t_wsk = 0; a.t_ws = 0;
+    if (!conv_igemm_supported(a)) return 0;
+    const bool fp16 = !a.in_i8 && !a.out_i8 && !a.res_i8;
+    const bool ws_ok = fp16 && conv_ws_supported(a);
+    // 0: the default
+    if (ws_ok) push(a.bn, a.bk, 128, 1, 2);
+    else push(a.bn, a.bk, 128, wsk_default(a) ? 2 : 1, 1);
+    const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
+    static const int bns[5] = {128, 80, 64, 32, 16};
+    for (int bi = 0; bi < 5; ++bi) {
+        const int bn = bns[bi];
+        if (a.Cout_pad % bn) continue;
+        if (bn == 16 && a.Cout_pad > 32 && bn != a.bn) continue;  // 16-wide tiles re-read the A tile Cout/16 times: only for tiny Cout
+        for (int ki = 0; ki < 2; ++ki) {
+            ConvArgs t = a;
+            t.bn = bn;
+            t.bk = bks[ki];
+            if (ki == 1 && bks[1] == bks[0]) continue;
+            push(bn, t.bk, 128, 1, 1);
+            if (bm64_possible(t)) push(bn, t.bk, 64, 1, 1);
+            if (wsk_possible(t)) push(bn, t.bk, 128, 2, 1);
+        }
+    }
+    return n;
+}
+
+void conv_apply_tactic(ConvArgs* a, const ConvTactic& t) {
+    a->bn = t.bn;
+    a->bk = t.bk;
+    a->bm = t.bm;
+    a->t_wsk = t.wsk;
+    a->t_ws = t.ws;
 }
 
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     if (!conv_igemm_supported(a0) || (a0.in_i8 && !a0.cscale)) return TRTX_ERR_UNSUPPORTED;
-    // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel
-    if (!a0.in_i8 && !a0.out_i8 && !a0.res_i8 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
+    const bool fp16 = !a0.in_i8 && !a0.out_i8 && !a0.res_i8;
+    // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel (t_ws: 0 = where supported, 1 = never, 2 = asked for)
+    if (fp16 && a0.t_ws != 1 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
@@ -775,18 +844,22 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * (a0.res_i8 ? 1 : 2);
         // extent of the addressed slice: last pixel's first byte + the channels this conv reads
         const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 2);
-        // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel)
-        static const bool no_wsk = getenv("TRTX_CONV_NOWSK") != nullptr;  // A/B switch for the micro-benchmarks
-        const int tiles128 = ((a.M + BM - 1) / BM) * (a.Cout_pad / a.bn);
+        // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel); t_wsk: 0 = that rule, 1 = never,
+        // 2 = wherever the variant exists
+        const bool wsk = a.t_wsk == 1 ? false : (a.t_wsk == 2 ? wsk_possible(a) : wsk_default(a));
+        const bool bm64 = a.bm == 64;
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
-        } else if (!no_wsk && !a.out_i8 && !a.res_i8 && a.bk == 32 && a.CinK % 32 == 0 && tiles128 <= 256 && a.Kpad / 32 >= 16 && (a.bn == 64 || a.bn == 80)) {
+        } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);
+        } else if (a.bk == 64) {
+            st = bm64 ? launch_bn<64, 1, false, 1>(a, in_bytes, w_bytes, s) : launch_bn<64, 1>(a, in_bytes, w_bytes, s);
+        } else if (a.CinK == 16) {
+            st = launch_bn<32, 2>(a, in_bytes, w_bytes, s);
         } else {
-            st = (a.bk == 64) ? launch_bn<64, 1>(a, in_bytes, w_bytes, s)
-                 : (a.CinK == 16 ? launch_bn<32, 2>(a, in_bytes, w_bytes, s) : launch_bn<32, 1>(a, in_bytes, w_bytes, s));
+            st = bm64 ? launch_bn<32, 1, false, 1>(a, in_bytes, w_bytes, s) : launch_bn<32, 1>(a, in_bytes, w_bytes, s);
         }
         if (st != TRTX_OK) return st;
     }

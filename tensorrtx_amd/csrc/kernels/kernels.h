@@ -41,6 +41,18 @@ struct ConvArgs {
     int in_i8, out_i8, res_i8;
     const float* cscale;   // [Cout_pad]
     float out_inv_scale, res_scale;
+    // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
+    int bm;     // igemm rows per tile: 0 / 128, or 64
+    int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
+    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported)
+};
+
+// One launch configuration of an implicit-GEMM layer.  All tactics of a layer share its packed weights (Cout_pad, CinK, Kpad), so
+// the executor may exchange them at run time: runtime/tune.cpp times them in place and keeps the fastest (TensorRT's builder does
+// the same with its tactics; here it happens at deserializeCudaEngine because plans store the network, not kernels).
+struct ConvTactic {
+    int bn, bk, bm;  // column-tile width, k-step width, rows per tile
+    int wsk, ws;     // values of ConvArgs::t_wsk / t_ws
 };
 
 // --- conv -------------------------------------------------------------------------------------------
@@ -54,6 +66,9 @@ bool conv_igemm_supported(const ConvArgs& a);
 void conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw, int cink, const float* ch_scale, int cout_pad, int kpad,
                           int8_t* packed, float* wscale_out);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
+// the tactics applicable to a layer (a.N / a.M at the batch it will run with); out[0] is the untuned default. Returns the count.
+int conv_tactics(const ConvArgs& a, ConvTactic* out, int max_out);
+void conv_apply_tactic(ConvArgs* a, const ConvTactic& t);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);

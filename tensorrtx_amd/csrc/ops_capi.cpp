@@ -60,16 +60,10 @@ extern "C" int32_t trtx_conv_pack_weights_f16(const float* w_kcrs, int cout, int
     return TRTX_OK;
 }
 
-extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked,
-                                           const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int sh,
-                                           int sw, int ph, int pw, int act1, const void* residual, int ld_res,
-                                           int act2, trtx_stream_t stream) {
+// geometry of the launch trtx_op_conv2d_nhwc_f16 performs (pointers left null)
+static ConvArgs op_conv_args(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int act1, int has_res, int ld_res, int act2) {
     ConvArgs a{};
-    a.in = in;
-    a.wgt = wpacked;
-    a.bias = bias;
-    a.out = out;
-    a.residual = residual;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in;
     a.Ho = (H + 2 * ph - kh) / sh + 1;
     a.Wo = (W + 2 * pw - kw) / sw + 1;
@@ -85,7 +79,44 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     a.Kpad = (a.K + a.bk - 1) / a.bk * a.bk;
     a.M = N * a.Ho * a.Wo;
     a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
-    a.scalar_out = (Cout % 8 || ld_out % 8 || (residual && ld_res % 8) || (reinterpret_cast<uintptr_t>(out) & 15)) ? 1 : 0;
+    a.scalar_out = (Cout % 8 || ld_out % 8 || (has_res && ld_res % 8)) ? 1 : 0;
+    return a;
+}
+
+static bool g_force_tactic = false;
+static ConvTactic g_forced{};
+
+extern "C" int32_t trtx_op_conv_force_tactic(const int32_t* t) {
+    g_force_tactic = t != nullptr;
+    if (t) g_forced = ConvTactic{t[0], t[1], t[2], t[3], t[4]};
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_op_conv2d_tactics(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph,
+                                          int pw, int has_residual, int ld_res, int32_t* out5, int32_t max_out) {
+    if (!out5 || max_out < 1 || N < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1) return 0;
+    ConvArgs a = op_conv_args(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, 0, has_residual, ld_res, 0);
+    a.residual = has_residual ? reinterpret_cast<const void*>(1) : nullptr;
+    std::vector<ConvTactic> t(max_out);
+    const int n = conv_tactics(a, t.data(), max_out);
+    for (int i = 0; i < n; ++i) {
+        out5[5 * i + 0] = t[i].bn; out5[5 * i + 1] = t[i].bk; out5[5 * i + 2] = t[i].bm; out5[5 * i + 3] = t[i].wsk; out5[5 * i + 4] = t[i].ws;
+    }
+    return n;
+}
+
+extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked,
+                                           const float* bias, void* out, int Cout, int ld_out, int kh, int kw, int sh,
+                                           int sw, int ph, int pw, int act1, const void* residual, int ld_res,
+                                           int act2, trtx_stream_t stream) {
+    ConvArgs a = op_conv_args(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, act1, residual != nullptr, ld_res, act2);
+    a.in = in;
+    a.wgt = wpacked;
+    a.bias = bias;
+    a.out = out;
+    a.residual = residual;
+    if (reinterpret_cast<uintptr_t>(out) & 15) a.scalar_out = 1;
+    if (g_force_tactic) conv_apply_tactic(&a, g_forced);
     // TRTX_OP_REPS=n (timing tools only): n back-to-back launches per call, so that the device — not the Python caller — sets the pace
     static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;
     int32_t st = TRTX_OK;

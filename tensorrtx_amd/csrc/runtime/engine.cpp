@@ -121,7 +121,8 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         const PTensor& to = plan.tensors[op.out[0]];
         auto nb = [&](const PTensor& t) { return (t.nfix ? t.nfix : batch) * t.nmul; };
         int32_t st = TRTX_OK;
-        switch (op.kind) {
+        const bool skip = c->tuning && (op.kind == OP_PLUGIN || op.kind == OP_YOLO_HEAD || op.kind == OP_ROI_ALIGN);
+        if (!skip) switch (op.kind) {
             case OP_CONV:
             case OP_DECONV: {
                 ConvArgs a = op.conv;
@@ -440,6 +441,7 @@ extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, t
         }
         ++e->plugins_initialized;
     }
+    if (const int32_t st = tune_engine(e.get())) return st;
     *out = e.release();
     return TRTX_OK;
 }

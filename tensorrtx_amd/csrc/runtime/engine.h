@@ -17,6 +17,14 @@ struct trtx_engine {
     void* d_weights = nullptr;
     int device = -1;  // HIP device the weights live on (current device at deserialize); contexts and enqueues must run there
     int plugins_initialized = 0;  // number of plugin ops (in plan order) whose initialize() succeeded
+    // what the tactic timing at deserialize decided, one record per MFMA convolution (runtime/tune.cpp; trtx_engine_tactics)
+    struct TacticRecord {
+        int op = -1;
+        std::string chosen, dflt;
+        float chosen_us = -1.f, default_us = -1.f;  // in-place timings of the chosen / the default tactic (-1: taken from the process cache)
+        int candidates = 0;
+    };
+    std::vector<TacticRecord> tactics;
     ~trtx_engine();
 };
 
@@ -45,6 +53,7 @@ struct trtx_context {
     std::vector<CapturedGraph> seen;   // combinations enqueued once (eagerly) so far
     uint64_t enqueue_count = 0;
     struct trtx::CalibObserver* observer = nullptr;  // INT8 calibration run: statistics of every NHWC tensor written (int8.h)
+    bool tuning = false;   // tactic-timing runs: plugins, the fused detect head and RoIAlign are skipped (runtime/tune.cpp)
     int graph_state = 0;   // 0 undecided, 1 eligible, -1 never (user plugins, capture failed once, disabled)
     ~trtx_context();
 };
@@ -57,4 +66,6 @@ struct OpTiming {
 };
 int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStream_t stream,
                      std::vector<OpTiming>* prof);
+// times the exchangeable launch configurations of every MFMA convolution in place and keeps the fastest (runtime/tune.cpp)
+int32_t tune_engine(trtx_engine* e);
 }  // namespace trtx

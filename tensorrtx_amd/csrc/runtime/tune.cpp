@@ -1,0 +1,194 @@
+// Tactic selection by measurement, the part of TensorRT's builder (IBuilder::buildSerializedNetwork, yolov8/src/model.cpp:327;
+// "tactics" in its verbose log) that picks one of several kernels for a layer by timing them on the device.  Here a plan stores
+// the network, not kernels, and lowering is re-run at deserializeCudaEngine - so that is where the timing happens:
+//
+//   * every MFMA convolution of the plan has a small set of exchangeable launch configurations (conv_tactics(): column-tile
+//     width, 64- or 128-row tiles, 32- or 64-wide k-steps, the wave-split-K and the weight-stationary kernel where they apply);
+//     they share the layer's packed weights, so nothing is re-packed;
+//   * the WHOLE plan is run in place (profile mode: one stream, HIP events around every op) once per candidate index, every
+//     layer using its candidate of that index: each candidate is timed behind its real producer, with the cache state of the
+//     real sequence, instead of alone in a loop (a kernel timed alone keeps its weights in L2 and looks faster than it is -
+//     profiles/r02_ws_per_op.txt);
+//   * a layer leaves its default only for a candidate that is at least 3 % faster; the choice is remembered per layer signature
+//     for the life of the process, so that two engines built from the same plan run the same kernels.
+//
+// Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
+// convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its default.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <sstream>
+
+#include "../common.h"
+#include "engine.h"
+
+using namespace trtx;
+
+namespace {
+
+constexpr int kMaxTactics = 16;
+
+struct SigKey {
+    int v[28];
+    bool operator<(const SigKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+
+SigKey signature(const ConvArgs& a, int act_pair) {
+    SigKey k{};
+    const int f[] = {a.N, a.H, a.W, a.Cin, a.ld_in, a.Ho, a.Wo, a.Cout, a.Cout_pad, a.ld_out, a.residual || a.ld_res ? a.ld_res : -1, a.kh, a.kw,
+                     a.stride_h, a.stride_w, a.pad_h, a.pad_w, a.CinK, a.Kpad, a.in_i8, a.out_i8, a.res_i8, a.scalar_out, a.bn, a.bk, act_pair};
+    static_assert(sizeof(f) / sizeof(int) <= 28, "signature too long");
+    memcpy(k.v, f, sizeof(f));
+    return k;
+}
+
+std::mutex g_mu;
+std::map<SigKey, ConvTactic> g_choice;  // process-wide: layer signature -> tactic in use
+
+bool same(const ConvTactic& a, const ConvTactic& b) { return a.bn == b.bn && a.bk == b.bk && a.bm == b.bm && a.wsk == b.wsk && a.ws == b.ws; }
+
+std::string tactic_name(const ConvTactic& t) {
+    std::ostringstream o;
+    if (t.ws == 2) {
+        o << "ws";
+    } else {
+        o << (t.wsk == 2 ? "wsk" : "igemm") << " " << (t.wsk == 2 ? 64 : t.bm) << "x" << t.bn << "x" << t.bk;
+    }
+    return o.str();
+}
+
+}  // namespace
+
+namespace trtx {
+
+int32_t tune_engine(trtx_engine* e) {
+    static const bool off = getenv("TRTX_TUNE") && atoi(getenv("TRTX_TUNE")) == 0;
+    static const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
+    Plan& plan = e->plan;
+    e->tactics.clear();
+    struct Item {
+        int op;
+        SigKey key;
+        ConvTactic cand[kMaxTactics];
+        int n = 0;
+        float best_ms[kMaxTactics];
+    };
+    std::vector<Item> items;
+    for (size_t k = 0; k < plan.ops.size(); ++k) {
+        POp& op = plan.ops[k];
+        if (op.kind != OP_CONV || !op.igemm || op.stem) continue;
+        const PTensor& t0 = plan.tensors[op.in[0]];
+        ConvArgs a = op.conv;  // as execute_plan fills it at the largest batch
+        a.N = (t0.nfix ? t0.nfix : plan.max_batch) * t0.nmul;
+        a.M = a.N * a.Ho * a.Wo;
+        a.residual = op.in.size() > 1 ? reinterpret_cast<const void*>(1) : nullptr;  // only its presence matters here
+        Item it;
+        it.op = (int)k;
+        it.key = signature(a, a.act1 * 16 + a.act2);
+        it.n = conv_tactics(a, it.cand, kMaxTactics);
+        if (it.n < 1) continue;
+        for (int i = 0; i < kMaxTactics; ++i) it.best_ms[i] = 1e30f;
+        items.push_back(it);
+    }
+    if (off || items.empty()) return TRTX_OK;
+    // layers this process has already decided: same kernels as before
+    bool all_known = true;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (const Item& it : items)
+            if (!g_choice.count(it.key)) all_known = false;
+    }
+    int passes = 0;
+    for (const Item& it : items) passes = std::max(passes, it.n);
+    if (!all_known && passes > 1) {
+        // a scratch context and scratch bindings at the largest batch
+        trtx_context* c = nullptr;
+        if (const int32_t st = trtx_context_create(e, &c)) return st;
+        c->tuning = true;
+        std::vector<void*> bindings(plan.binding_ptensor.size(), nullptr);
+        hipStream_t stream = nullptr;
+        int32_t st = TRTX_OK;
+        auto cleanup = [&]() {
+            if (stream) {
+                (void)hipStreamSynchronize(stream);
+                (void)hipStreamDestroy(stream);
+            }
+            for (void* p : bindings)
+                if (p) (void)hipFree(p);
+            trtx_context_destroy(c);
+        };
+        for (size_t b = 0; b < bindings.size() && st == TRTX_OK; ++b) {
+            const PTensor& t = plan.tensors[plan.binding_ptensor[b]];
+            const size_t bytes = std::max<size_t>(plan.storages[t.storage].bytes, (size_t)plan.max_batch * (size_t)std::max<int64_t>(1, t.dims.volume()) * 4) + 256;
+            if (hipMalloc(&bindings[b], bytes) != hipSuccess || hipMemset(bindings[b], 0, bytes) != hipSuccess) st = TRTX_ERR_HIP;
+        }
+        if (st == TRTX_OK && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) st = TRTX_ERR_HIP;
+        const int reps = 3;
+        for (int p = 0; p < passes && st == TRTX_OK; ++p) {
+            for (const Item& it : items) conv_apply_tactic(&plan.ops[it.op].conv, it.cand[p < it.n ? p : 0]);
+            for (int r = 0; r <= reps && st == TRTX_OK; ++r) {  // r == 0: untimed (first launch of a kernel loads its code object)
+                std::vector<OpTiming> prof;
+                st = execute_plan(c, plan.max_batch, bindings.data(), stream, &prof);
+                if (st != TRTX_OK || r == 0) continue;
+                for (Item& it : items) {
+                    const int ci = p < it.n ? p : 0;
+                    it.best_ms[ci] = std::min(it.best_ms[ci], prof[it.op].ms);
+                }
+            }
+        }
+        for (const Item& it : items) conv_apply_tactic(&plan.ops[it.op].conv, it.cand[0]);
+        cleanup();
+        if (st != TRTX_OK) {
+            (void)hipGetLastError();
+            fprintf(stderr, "[trtx_hip] tactic timing failed (%s): every layer keeps its default kernel\n", trtx_status_string(st));
+            return TRTX_OK;  // the defaults are a complete engine
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (Item& it : items) {
+        auto found = g_choice.find(it.key);
+        int pick = 0;
+        if (found != g_choice.end()) {
+            for (int i = 0; i < it.n; ++i)
+                if (same(it.cand[i], found->second)) pick = i;
+        } else {
+            for (int i = 1; i < it.n; ++i)
+                if (it.best_ms[i] < it.best_ms[pick] && it.best_ms[i] < 0.97f * it.best_ms[0]) pick = i;
+            g_choice[it.key] = it.cand[pick];
+        }
+        conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
+        trtx_engine::TacticRecord rec;
+        rec.op = it.op;
+        rec.chosen = tactic_name(it.cand[pick]);
+        rec.dflt = tactic_name(it.cand[0]);
+        rec.chosen_us = it.best_ms[pick] < 1e29f ? it.best_ms[pick] * 1e3f : -1.f;
+        rec.default_us = it.best_ms[0] < 1e29f ? it.best_ms[0] * 1e3f : -1.f;
+        rec.candidates = it.n;
+        e->tactics.push_back(rec);
+        if (verbose)
+            fprintf(stderr, "[trtx_hip] tactic %-40s %-18s %7.1f us (default %-18s %7.1f us, %d candidates)\n", plan.ops[it.op].name.c_str(),
+                    rec.chosen.c_str(), rec.chosen_us, rec.dflt.c_str(), rec.default_us, it.n);
+    }
+    return TRTX_OK;
+}
+
+}  // namespace trtx
+
+extern "C" int32_t trtx_engine_tactics(const trtx_engine* e, char** json_out) {
+    if (!e || !json_out) return TRTX_ERR_INVALID;
+    std::ostringstream o;
+    o << "[";
+    for (size_t i = 0; i < e->tactics.size(); ++i) {
+        const auto& r = e->tactics[i];
+        o << (i ? "," : "") << "{\"op\":" << r.op << ",\"name\":\"";
+        for (char ch : e->plan.ops[r.op].name) o << ((ch == '"' || ch == '\\' || (unsigned char)ch < 0x20) ? ' ' : ch);
+        o << "\",\"tactic\":\"" << r.chosen << "\",\"default\":\"" << r.dflt << "\",\"us\":" << r.chosen_us << ",\"default_us\":" << r.default_us
+          << ",\"candidates\":" << r.candidates << "}";
+    }
+    o << "]";
+    *json_out = strdup(o.str().c_str());
+    return TRTX_OK;
+}

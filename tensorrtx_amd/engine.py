@@ -83,6 +83,14 @@ class Engine:
         lib().trtx_string_free(out)
         return json.loads(js)
 
+    def tactics(self):
+        """What the tactic timing at deserializeCudaEngine decided: one record per MFMA convolution (trtx_engine_tactics)."""
+        out = ctypes.c_char_p()
+        check(lib().trtx_engine_tactics(self._e, ctypes.byref(out)), "trtx_engine_tactics")
+        js = ctypes.string_at(out).decode()
+        lib().trtx_string_free(out)
+        return json.loads(js)
+
     def create_context(self):
         """ICudaEngine::createExecutionContext: a further context (own activation arena, lane streams and events) over the same
         weights.  Several contexts may be in flight at once, each on its own stream (bench.py --contexts)."""

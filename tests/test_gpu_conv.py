@@ -102,3 +102,56 @@ def test_conv_writes_channel_slice_of_wider_buffer(gpu):
     got = buf.float().cpu()
     assert (got[..., :16] == 7.0).all() and (got[..., 48:] == 7.0).all()
     assert (got[..., 16:48] - ref).abs().max().item() < 5e-3
+
+
+# Every launch configuration the tactic tuner may pick for a layer (runtime/tune.cpp, conv_tactics): all of them must be the same
+# convolution.  Tile shapes (column-tile width, 64- / 128-row tiles, 32- / 64-wide k-steps) accumulate over K in the same order:
+# bit-identical.  The wave-split-K and weight-stationary kernels sum in a different order: within the fp16 tolerance.
+TACTIC_CASES = [
+    (2, 20, 20, 128, 128, 3, 1, 1, "silu", True, "none"),    # 13 tactics: 3 tile widths x 2 heights x 2 k-steps + wave-split-K
+    (2, 40, 40, 64, 64, 3, 1, 1, "silu", False, "none"),
+    (1, 20, 20, 64, 80, 3, 1, 1, "silu", False, "none"),     # Cout 80: 5 column fragments, odd item count in the 64-row epilogue
+    (2, 20, 20, 256, 256, 1, 1, 0, "silu", False, "none"),   # 1x1 with 64-wide k-steps
+    (3, 80, 80, 32, 32, 3, 1, 1, "silu", True, "none"),      # weight-stationary default vs the implicit-GEMM tiles
+    (1, 17, 13, 64, 64, 3, 1, 1, "relu", False, "none"),     # ragged M (221 pixels): partial 64- and 128-row tiles
+    (2, 10, 10, 128, 256, 3, 2, 1, "silu", False, "none"),   # stride 2
+    (1, 14, 14, 256, 64, 1, 1, 0, "none", True, "relu"),     # residual + second activation
+    (1, 9, 9, 24, 40, 5, 1, 2, "leaky", False, "none"),      # Cin 24 (one ragged k-chunk), Cout 40 -> 48
+]
+
+
+@pytest.mark.parametrize("case", TACTIC_CASES)
+def test_every_conv_tactic_is_the_same_convolution(gpu, case):
+    import torch
+    N, H, W, Cin, Cout, k, s, p, act1, use_res, act2 = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, H, W, Cin, generator=g).half()
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).half() if use_res else None
+    packed, cout_pad, kpad, bn = capi.pack_conv_weights_f16(w.numpy(), cin_pad=Cin)
+    bias_pad = torch.zeros(cout_pad)
+    bias_pad[:Cout] = bias
+    xg, wg, bg = x.to(gpu), torch.from_numpy(packed.view(np.int16)).to(gpu), bias_pad.to(gpu)
+    rg = res.to(gpu) if use_res else None
+    ref = _ref(x, w, bias, s, p, act1, res, act2)
+    scale = ref.abs().max().item()
+    tactics = capi.conv2d_tactics(N, H, W, Cin, Cout, k, s, p, residual=use_res)
+    assert len(tactics) >= 2 and len(set(tactics)) == len(tactics)
+    exact = None
+    try:
+        for t in tactics:
+            capi.conv_force_tactic(t)
+            y = capi.conv2d_nhwc_f16(xg, wg, bg, Cout, k, k, s, p, act1, rg, act2)
+            torch.cuda.synchronize()
+            got = y.float().cpu()
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"tactic {t}: max err {err} (scale {scale})"
+            if t[3] == 1 and t[4] == 1:  # plain implicit-GEMM tiles
+                if exact is None:
+                    exact = got
+                else:
+                    assert torch.equal(got, exact), f"tactic {t} is not bit-identical to the other tile shapes"
+    finally:
+        capi.conv_force_tactic(None)

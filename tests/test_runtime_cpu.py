@@ -395,3 +395,18 @@ def test_max_aux_streams_travels_in_the_plan_and_bounds_the_lanes():
         assert engine.describe_plan(plan, lowered=True)["n_lanes"] == lanes
     with pytest.raises(Exception):
         engine.build_plan("yolov8n", path, batch=2, h=128, w=128, aux_streams=99)
+
+
+def test_conv_tactics_are_enumerated_on_the_host():
+    """conv_tactics (what runtime/tune.cpp times per layer): entry 0 is the untuned default, every entry shares the layer's packed
+    weights (tile widths divide the padded Cout, 64-wide k-steps only where Cin % 64 == 0), no duplicates."""
+    from tensorrtx_amd import capi
+    t = capi.conv2d_tactics(32, 20, 20, 128, 128, 3, 1, 1)
+    assert t[0] == (128, 32, 128, 1, 1) and len(set(t)) == len(t) >= 8
+    assert (64, 32, 128, 2, 1) in t and (64, 64, 64, 1, 1) in t          # wave-split-K on 64-wide tiles; 64-row tiles with 64-wide k-steps
+    assert all(128 % bn == 0 and bk in (32, 64) and bm in (64, 128) for bn, bk, bm, _, _ in t)
+    t = capi.conv2d_tactics(32, 80, 80, 32, 32, 3, 1, 1)                  # weight-stationary kernel is the default where it applies
+    assert t[0][4] == 2 and all(x[4] == 1 for x in t[1:]) and all(x[1] == 32 for x in t)
+    t = capi.conv2d_tactics(32, 80, 80, 64, 80, 3, 1, 1)
+    assert {x[0] for x in t} == {80}
+    assert capi.conv2d_tactics(32, 160, 160, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1)]   # two taps per k-step: one configuration
