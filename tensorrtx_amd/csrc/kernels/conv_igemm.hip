@@ -71,23 +71,6 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
     return act_slow(v, act, alpha);
 }
 
-// activation with the kind fixed at compile time (-1 = anything else, resolved at run time out of line)
-template <int ACT>
-__device__ __forceinline__ float act_fixed(float x, int act, float alpha) {
-    if (ACT == ACT_NONE) return x;
-    if (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-    if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
-    return act_slow(x, act, alpha);
-}
-// call f(std::integral_constant<int, ACT>) for the wave-uniform activation code `act`
-template <typename F>
-__device__ __forceinline__ void dispatch_act(int act, F&& f) {
-    if (act == ACT_SILU) f(std::integral_constant<int, ACT_SILU>{});
-    else if (act == ACT_RELU) f(std::integral_constant<int, ACT_RELU>{});
-    else if (act == ACT_NONE) f(std::integral_constant<int, ACT_NONE>{});
-    else f(std::integral_constant<int, -1>{});
-}
-
 // bit t set iff 0 <= x0 + t < extent, for t in [0, k), k <= 30
 __device__ __forceinline__ unsigned tap_range_mask(int x0, int k, int extent) {
     const int lo = x0 < 0 ? -x0 : 0;
@@ -359,115 +342,116 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: bias/BN + act1 in registers (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15) of
-    // its wave's WR rows), then through a wave-private LDS tile so that global traffic is row-major 16-byte chunks:
-    // residual reads and output stores cover whole 128-byte lines instead of 32-byte slivers.
+    // ---- epilogue.  The accumulators (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15) of its wave's WR
+    // rows) go through a wave-private fp32 LDS tile, 16 rows at a time, and come back row-major: one lane = 8 consecutive channels
+    // of one pixel, so residual reads and output stores are whole 16-byte chunks (128-byte lines per 8 lanes) and - this is the
+    // point - the code that finishes them (bias, act1, rounding, residual, act2, requantisation, ragged stores) exists ONCE, in a
+    // rolled loop with wave-uniform branches, instead of once per accumulator fragment and activation kind.  Unrolled, that code
+    // was 80 % of a 45-90 KB kernel against a 64 KB instruction cache shared by two CUs: every switch between two of the ~10
+    // instantiations a network uses started with instruction-fetch misses on all 256 CUs (measured: +10-20 us on the first
+    // launch after a switch, profiles/r02_icache_*.txt).
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
     const int px_in = lane & 15;
     const int ch_in = (lane >> 4) * 4;
     const bool second = res || p.act2 != ACT_NONE;
     if (dbg & 8) return;
-    if constexpr (I8) {  // int32 sums -> real values: acc * (input scale * weight scale of the channel)
+    constexpr int PS = BN * 4 + 16;   // fp32 row stride of the staging tile (padded: 16 consecutive rows start in distinct bank groups)
+    static_assert(4 * 16 * PS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
+    constexpr int CPR = BN / 8;       // 8-channel items per row
+    constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
+    __syncthreads();  // every wave is done reading the last stage
+    char* mine = smem + wave * 16 * PS;
+#pragma nounroll
+    for (int i = 0; i < MI; ++i) {
+        // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
 #pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
-            const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
-            const float c4[4] = {cs.x, cs.y, cs.z, cs.w};
+        for (int ii = 0; ii < MI; ++ii) {
+            if (ii != i) continue;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][e] = (float)acci[i][j][e] * c4[e];
+            for (int j = 0; j < NFRAG; ++j) {
+                floatx4 v = acc[ii][j];
+                if constexpr (I8) {
+                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
+                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
+                }
+                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
+            }
         }
-    }
-    if (!p.scalar_out) {
-        constexpr int RS = BN * 2 + 16;  // padded row stride: 16 consecutive rows start in distinct bank groups
-        static_assert(4 * WR * RS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
-        __syncthreads();  // every wave is done reading the last stage
-        char* mine = smem + wave * WR * RS;
-        // act1 is wave-uniform: select the code path once, not per element (the kernel is instruction-issue bound)
-        auto stage1 = [&](auto act_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j) {
-                    const int co = n0 + j * 16 + ch_in;
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
-                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
-                    half4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(act_fixed<ACT>(acc[i][j][e] + b4[e], p.act1, p.alpha1));
-                    *reinterpret_cast<half4*>(mine + (i * 16 + px_in) * RS + (j * 16 + ch_in) * 2) = o;
-                }
-        };
-        dispatch_act(p.act1, stage1);
         // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
-        constexpr int CPR = BN / 8;  // 16-byte chunks per row
-        constexpr int ITEMS = WR * CPR;  // 16-byte items of this wave's tile
-        auto stage2 = [&](auto act_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
+#pragma nounroll
+        for (int q = lane; q < ITEMS; q += 64) {
+            const int row = q / CPR, cc = q % CPR;
+            const int m = m0 + wave * WR + i * 16 + row;
+            const int co = n0 + cc * 8;
+            if (m >= p.M || co >= p.Cout) continue;
+            const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
+            const floatx4 hi = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32 + 16);
+            float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
+                x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+            }
+            half8 v;
+            if (p.act1 == ACT_SILU) {
 #pragma unroll
-            for (int t = 0; t < (ITEMS + 63) / 64; ++t) {
-                const int q = t * 64 + lane;
-                if (ITEMS % 64 != 0 && q >= ITEMS) break;
-                const int row = q / CPR, cc = q % CPR;
-                const int m = m0 + wave * WR + row;
-                const int co = n0 + cc * 8;
-                if (m >= p.M || co >= p.Cout) continue;
-                half8 v = *reinterpret_cast<const half8*>(mine + row * RS + cc * 16);
-                if (second) {
-                    half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (res) {
-                        if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
-                            const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-x[e])));
+            } else if (p.act1 == ACT_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) rv[e] = round_to_half((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
-                        } else {
-                            rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
-                        }
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] > 0.f ? x[e] : 0.f);
+            } else if (p.act1 == ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e]);
+            } else {
+#pragma nounroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_slow(x[e], p.act1, p.alpha1));
+            }
+            const bool vec = !p.scalar_out;
+            if (second) {
+                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (res) {
+                    if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
+                        const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = round_to_half((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
+                    } else if (vec) {
+                        rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                    } else {
+#pragma nounroll
+                        for (int e = 0; e < 8; ++e)
+                            if (co + e < p.Cout) rv[e] = res[(size_t)m * p.ld_res + co + e];
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_fixed<ACT>((float)v[e] + (float)rv[e], p.act2, p.alpha2));
                 }
-                if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
-                    unsigned long long q = 0;
+                if (p.act2 == ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
+                } else if (p.act2 == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float t = rintf((float)v[e] * p.out_inv_scale);
-                        t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
-                        q |= (unsigned long long)(unsigned char)(int8_t)(int)t << (8 * e);
+                        const float t = (float)v[e] + (float)rv[e];
+                        v[e] = round_to_half(t > 0.f ? t : 0.f);
                     }
-                    *reinterpret_cast<unsigned long long*>(static_cast<int8_t*>(p.out) + (size_t)m * p.ld_out + co) = q;
                 } else {
-                    *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+#pragma nounroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2));
                 }
             }
-        };
-        dispatch_act(p.act2, stage2);
-        return;
-    }
-    // ragged channel counts / unaligned slices: element-wise stores straight from the accumulators
+            if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
+                unsigned long long qv = 0;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wave * WR + i * 16 + px_in;
-        if (m >= p.M) continue;
-        _Float16* orow = out + (size_t)m * p.ld_out;
-        const _Float16* rrow = res ? res + (size_t)m * p.ld_res : nullptr;
-#pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
-            const int co = n0 + j * 16 + ch_in;
-            if (co >= p.Cout) continue;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
-            const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (co + e < p.Cout) {
-                    float x = act_apply(acc[i][j][e] + b4[e], p.act1, p.alpha1);
-                    if (second) x = act_apply((float)round_to_half(x) + (res ? (float)rrow[co + e] : 0.f), p.act2, p.alpha2);
-                    orow[co + e] = round_to_half(x);
+                for (int e = 0; e < 8; ++e) {
+                    float t = rintf((float)v[e] * p.out_inv_scale);
+                    t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+                    qv |= (unsigned long long)(unsigned char)(int8_t)(int)t << (8 * e);
                 }
+                *reinterpret_cast<unsigned long long*>(static_cast<int8_t*>(p.out) + (size_t)m * p.ld_out + co) = qv;
+            } else if (vec) {
+                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+            } else {  // ragged channel counts / unaligned slices: element-wise stores
+#pragma nounroll
+                for (int e = 0; e < 8; ++e)
+                    if (co + e < p.Cout) out[(size_t)m * p.ld_out + co + e] = v[e];
             }
         }
     }
@@ -636,15 +620,14 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
     const bool second = res || p.act2 != ACT_NONE;
     constexpr int CPR = BN / 8;                  // 8-channel items per row
     constexpr int ITEMS = 16 * CPR;              // per wave
-#pragma unroll
-    for (int t = 0; t < (ITEMS + 63) / 64; ++t) {
-        const int q = t * 64 + lane;
-        if (q >= ITEMS) break;
+    // rolled, with wave-uniform branches: the finishing code exists once (see the epilogue of conv_igemm_f16_kernel)
+#pragma nounroll
+    for (int q = lane; q < ITEMS; q += 64) {
         const int row = wave * 16 + q / CPR, cc = q % CPR;
         const int m = m0 + row;
         const int co = n0 + cc * 8;
         if (m >= p.M || co >= p.Cout) continue;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const char* src = smem + w * WAVE_BYTES + row * PS + cc * 32;
@@ -652,40 +635,61 @@ __global__ __launch_bounds__(256) void conv_igemm_wsk_f16_kernel(const ConvArgs 
             const floatx4 hi = *reinterpret_cast<const floatx4*>(src + 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] += lo[e];
-                v[4 + e] += hi[e];
+                x[e] += lo[e];
+                x[4 + e] += hi[e];
             }
         }
-        if (!p.scalar_out) {
-            half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
-            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-            if (p.bias) {
-                b0 = *reinterpret_cast<const float4*>(p.bias + co);
-                b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-            }
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            half8 o;
-            dispatch_act(p.act1, [&](auto t1) {
-                constexpr int A1 = decltype(t1)::value;
+        if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+            x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
+            x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+        }
+        half8 v;
+        if (p.act1 == ACT_SILU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = round_to_half(act_fixed<A1>(v[e] + bb[e], p.act1, p.alpha1));
-            });
-            if (second)
-                dispatch_act(p.act2, [&](auto t2) {
-                    constexpr int A2 = decltype(t2)::value;
+            for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-x[e])));
+        } else if (p.act1 == ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = round_to_half(act_fixed<A2>((float)o[e] + (float)rv[e], p.act2, p.alpha2));
-                });
-            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = o;
+            for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] > 0.f ? x[e] : 0.f);
+        } else if (p.act1 == ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e]);
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (co + e >= p.Cout) break;
-                float x = act_apply(v[e] + (p.bias ? p.bias[co + e] : 0.f), p.act1, p.alpha1);
-                if (second) x = act_apply((float)round_to_half(x) + (res ? (float)res[(size_t)m * p.ld_res + co + e] : 0.f), p.act2, p.alpha2);
-                out[(size_t)m * p.ld_out + co + e] = round_to_half(x);
+#pragma nounroll
+            for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_slow(x[e], p.act1, p.alpha1));
+        }
+        const bool vec = !p.scalar_out;
+        if (second) {
+            half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (res) {
+                if (vec) {
+                    rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                } else {
+#pragma nounroll
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < p.Cout) rv[e] = res[(size_t)m * p.ld_res + co + e];
+                }
             }
+            if (p.act2 == ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
+            } else if (p.act2 == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = (float)v[e] + (float)rv[e];
+                    v[e] = round_to_half(t > 0.f ? t : 0.f);
+                }
+            } else {
+#pragma nounroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2));
+            }
+        }
+        if (vec) {
+            *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+        } else {
+#pragma nounroll
+            for (int e = 0; e < 8; ++e)
+                if (co + e < p.Cout) out[(size_t)m * p.ld_out + co + e] = v[e];
         }
     }
 }

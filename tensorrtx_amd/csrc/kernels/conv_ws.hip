@@ -56,34 +56,19 @@ struct WsGeom {
 };
 
 __device__ __forceinline__ float act_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-// activation kinds other than the two hot ones: wave-uniform branches, inlined
-__device__ __forceinline__ float ws_act_any(float v, int act, float alpha) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_SILU) return act_silu(v);
+// the rare activation kinds, out of line (one copy in the kernel instead of one per call site: code size is a cost here)
+__device__ __attribute__((noinline)) float ws_act_rare(float v, int act, float alpha) {
     if (act == ACT_LEAKY) return v > 0.f ? v : v * alpha;
     if (act == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     if (act == ACT_TANH) return tanhf(v);
     return v;
 }
-template <int ACT>
-__device__ __forceinline__ float ws_act(float x, int act, float alpha) {
-    if (ACT == ACT_NONE) return x;
-    if (ACT == ACT_SILU) return act_silu(x);
-    return ws_act_any(x, act, alpha);
+__device__ __forceinline__ float ws_act_any(float v, int act, float alpha) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SILU) return act_silu(v);
+    if (act == ACT_NONE) return v;
+    return ws_act_rare(v, act, alpha);
 }
-// act1: SiLU / none / anything else; act2 (after the residual add): none / anything else
-template <typename F>
-__device__ __forceinline__ void ws_dispatch_act1(int act, F&& f) {
-    if (act == ACT_SILU) f(std::integral_constant<int, ACT_SILU>{});
-    else if (act == ACT_NONE) f(std::integral_constant<int, ACT_NONE>{});
-    else f(std::integral_constant<int, -1>{});
-}
-template <typename F>
-__device__ __forceinline__ void ws_dispatch_act2(int act, F&& f) {
-    if (act == ACT_NONE) f(std::integral_constant<int, ACT_NONE>{});
-    else f(std::integral_constant<int, -1>{});
-}
-
 // exact x / d for 0 <= x < 2^22 with a float reciprocal estimate fixed up by one step
 __device__ __forceinline__ int div_small(int x, int d, float inv) {
     int q = (int)((float)x * inv);
@@ -262,49 +247,60 @@ __global__ __launch_bounds__(256, ws_min_waves(ws_regs(TAPS, KC, NFW, WC, NF, RO
         constexpr int CPR = NFW * 2;             // 16-byte chunks per staged row
         constexpr int ITEMS = 16 * CPR;
         char* stg = smem + 2 * buf_bytes + wave * (16 * RS);
-        auto emit = [&](auto t1, auto t2) {
-            constexpr int A1 = decltype(t1)::value;
-            constexpr int A2 = decltype(t2)::value;
+        // The activation kind is a wave-uniform RUN-TIME branch around each small group of elements, and the row-major pass is a
+        // rolled loop: the finishing code exists once per accumulator fragment instead of once per (fragment, act1, act2)
+        // combination - a sixth of the instructions, and the kernel stays inside the instruction cache next to its neighbours
+        // (see the epilogue of conv_igemm_f16_kernel).
 #pragma unroll
-            for (int f = 0; f < AFW; ++f) {
+        for (int f = 0; f < AFW; ++f) {
 #pragma unroll
-                for (int j = 0; j < NFW; ++j) {
-                    const float b4[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
-                    half4 o;
+            for (int j = 0; j < NFW; ++j) {
+                const float b4[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
+                half4 o;
+                if (p.act1 == ACT_SILU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(ws_act<A1>(acc[f][j][e] + b4[e], p.act1, p.alpha1));
-                    *reinterpret_cast<half4*>(stg + (lane & 15) * RS + j * 32 + (lane >> 4) * 8) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(act_silu(acc[f][j][e] + b4[e]));
+                } else if (p.act1 == ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(acc[f][j][e] + b4[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = round_to_half(ws_act_any(acc[f][j][e] + b4[e], p.act1, p.alpha1));
                 }
-#pragma unroll
-                for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
-                    const int q = it * 64 + lane;
-                    const int row = q / CPR, cc = q - row * CPR;
-                    // the pixel this lane now stores: row `row` of fragment f
-                    int oy, ox;
-                    if (ROWS) {
-                        oy = wp * AFW + f;
-                        ox = row;
-                    } else {
-                        const int t = (wp * AFW + f) * 16 + row;
-                        oy = div_small(t, g.TW, g.inv_tw);
-                        ox = t - oy * g.TW;
-                    }
-                    const int ho = ty * g.TH + oy, wo = tx * g.TW + ox;
-                    const int co = wc * NFW * 16 + cc * 8;
-                    if (q >= ITEMS || oy >= g.TH || ho >= p.Ho || wo >= p.Wo || co >= p.Cout || (g.dbg & 4)) continue;
-                    const size_t m = (size_t)(n * p.Ho + ho) * p.Wo + wo;
-                    half8 v = *reinterpret_cast<const half8*>(stg + row * RS + cc * 16);
-                    if (second) {
-                        half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                        if (res) rv = *reinterpret_cast<const half8*>(res + m * p.ld_res + co);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = round_to_half(ws_act<A2>((float)v[e] + (float)rv[e], p.act2, p.alpha2));
-                    }
-                    *reinterpret_cast<half8*>(out + m * p.ld_out + co) = v;
-                }
+                *reinterpret_cast<half4*>(stg + (lane & 15) * RS + j * 32 + (lane >> 4) * 8) = o;
             }
-        };
-        ws_dispatch_act1(p.act1, [&](auto t1) { ws_dispatch_act2(p.act2, [&](auto t2) { emit(t1, t2); }); });
+#pragma nounroll
+            for (int q = lane; q < ITEMS; q += 64) {
+                const int row = q / CPR, cc = q - row * CPR;
+                // the pixel this lane now stores: row `row` of fragment f
+                int oy, ox;
+                if (ROWS) {
+                    oy = wp * AFW + f;
+                    ox = row;
+                } else {
+                    const int t = (wp * AFW + f) * 16 + row;
+                    oy = div_small(t, g.TW, g.inv_tw);
+                    ox = t - oy * g.TW;
+                }
+                const int ho = ty * g.TH + oy, wo = tx * g.TW + ox;
+                const int co = wc * NFW * 16 + cc * 8;
+                if (oy >= g.TH || ho >= p.Ho || wo >= p.Wo || co >= p.Cout || (g.dbg & 4)) continue;
+                const size_t m = (size_t)(n * p.Ho + ho) * p.Wo + wo;
+                half8 v = *reinterpret_cast<const half8*>(stg + row * RS + cc * 16);
+                if (second) {
+                    half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (res) rv = *reinterpret_cast<const half8*>(res + m * p.ld_res + co);
+                    if (p.act2 == ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = round_to_half(ws_act_any((float)v[e] + (float)rv[e], p.act2, p.alpha2));
+                    }
+                }
+                *reinterpret_cast<half8*>(out + m * p.ld_out + co) = v;
+            }
+        }
     }
 }
 
