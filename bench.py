@@ -297,7 +297,6 @@ def main():
         for k in range(min(args.warmup, 5)):
             one[0].run(inputs[k % len(inputs)])
         dt_single = timed(one, args.steps)
-        eng1.close()
 
     # Host-fed variant (not `value`): what a caller pays when the boundary hands over HOST images, as the reference's demo does
     # (yolov8_det.cpp:146-160: cuda_batch_preprocess of cv::Mat frames, infer, D2H).  Raw uint8 HWC frames sit in pinned host
@@ -354,27 +353,37 @@ def main():
 
     # per-kernel timing with HIP events on the launch stream (IProfiler analogue): roofline of the dominant kernel
     prof_runs = 5
-    conv_ms = tot_ms = 0.0
-    n_conv = 0
-    for _ in range(prof_runs):
-        rows = eng.profile(batch, slots[0].bindings(inputs[0]))
-        conv = [r for r, o in zip(rows, low["ops"]) if o["kind"] == "conv" and o.get("igemm")]
-        n_conv = len(conv)
-        conv_ms += sum(r["ms"] for r in conv)
-        tot_ms += sum(r["ms"] for r in rows)
-    tac = eng.tactics()
-    moved = [t for t in tac if t["tactic"] != t["default"]]
-    tactic_summary = {"convs_timed": len(tac), "moved_off_default": len(moved),
-                      "default_sum_us": round(sum(t["default_us"] for t in tac if t["default_us"] > 0), 1),
-                      "chosen_sum_us": round(sum(t["us"] for t in tac if t["us"] > 0), 1),
-                      "what": "in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp); TRTX_TUNE=0 disables"}
+
+    def profile_convs(e, bindings):
+        """mean over prof_runs of (sum of the MFMA conv launches, sum of all launches) in ms, launch count, last per-op rows, tactics"""
+        c_ms = t_ms = 0.0
+        n = 0
+        rows = []
+        for _ in range(prof_runs):
+            rows = e.profile(batch, bindings)
+            conv = [r for r, o in zip(rows, low["ops"]) if o["kind"] == "conv" and o.get("igemm")]
+            n = len(conv)
+            c_ms += sum(r["ms"] for r in conv)
+            t_ms += sum(r["ms"] for r in rows)
+        tac = e.tactics()
+        moved = [t for t in tac if t["tactic"] != t["default"]]
+        summary = {"convs_timed": len(tac), "moved_off_default": len(moved),
+                   "default_sum_us": round(sum(t["default_us"] for t in tac if t["default_us"] > 0), 1),
+                   "chosen_sum_us": round(sum(t["us"] for t in tac if t["us"] > 0), 1)}
+        return c_ms / prof_runs, t_ms / prof_runs, n, rows, tac, summary
+
+    conv_ms, tot_ms, n_conv, rows, tac, tactic_summary = profile_convs(eng, slots[0].bindings(inputs[0]))
+    tactic_summary["what"] = ("in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp; TRTX_TUNE=0 disables)" +
+                              ("; this engine was built with setMaxAuxStreams(0) = contexts in flight: it chooses among the work-efficient configurations only" if n_ctx > 1 else ""))
+    single_prof = None
+    if n_ctx > 1:
+        conv1_ms, tot1_ms, n1, _, _, tac1 = profile_convs(eng1, one[0].bindings(inputs[0]))
+        single_prof = (conv1_ms, tot1_ms, n1, tac1)
+        eng1.close()
     if args.dump_ops and rank == 0:
         json.dump(tac, open(args.dump_ops + ".tactics.json", "w"), indent=0)
-    if args.dump_ops and rank == 0:
         json.dump([dict(r, **{k: o.get(k) for k in ("cin", "cout", "k", "hw_in", "hw_out", "residual", "flops", "kernel")})
                    for r, o in zip(rows, low["ops"])], open(args.dump_ops, "w"), indent=0)
-    conv_ms /= prof_runs
-    tot_ms /= prof_runs
     # Dominant kernel family = the fused MFMA convolutions.  ALGORITHMIC bytes per launch = fp16 activations in + out
     # (+ residual) at this batch + the layer's packed weights once (DESIGN.md "Measurement"); duration = per-op HIP events.
     # YOLOv8n layers sit below the MFMA/HBM ridge (arithmetic intensity 16..290 FLOP/B against 312) -> bound "hbm";
@@ -427,7 +436,11 @@ def main():
     if dt_single is not None:
         res["single_context"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_single, "unit": "images/sec",
                                  "ms_per_step": dt_single / args.steps * 1e3,
-                                 "what": "the same K steps through ONE execution context, strictly one batch after the other (the shape of the reference's loop, yolov8_det.cpp:97-104): the per-batch latency figure"}
+                                 "what": "the same K steps through ONE execution context, strictly one batch after the other (the shape of the reference's loop, yolov8_det.cpp:97-104): the per-batch latency figure; this engine uses 3 auxiliary streams and the full tactic set"}
+        c1_ms, t1_ms, n1, tac1 = single_prof
+        res["single_context"]["roofline"] = {"avg_launch_us": c1_ms * 1e3 / max(n1, 1), "conv_ms_per_step": c1_ms, "all_kernels_ms_per_step": t1_ms,
+                                             "hbm_frac": alg_bytes / (c1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "mfma_frac": flop_per_step / (c1_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                             "tactics": tac1}
     if cfg["nms"]:
         res["d2h_inclusive"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_d2h, "unit": "images/sec",
                                 "ms_per_step": dt_d2h / args.steps * 1e3,

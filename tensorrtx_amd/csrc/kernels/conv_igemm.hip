@@ -92,7 +92,8 @@ __device__ __forceinline__ int swz(int row) {
 // instead of 32 halfs; the host passes the input-side geometry in 2-byte units (see ConvArgs), so the whole operand path
 // below is byte-for-byte the fp16 one - only the MFMA and the epilogue's dequantise / requantise differ.
 // MI = 16-row MFMA fragments per wave along M: 2 -> a 128-row tile (the default), 1 -> a 64-row tile (twice the workgroups for
-// layers whose 128-row tiling leaves most of the 256 CUs idle; chosen per layer by the tactic tuner, runtime/tune.cpp).
+// layers whose 128-row tiling leaves most of the 256 CUs idle), 4 -> a 256-row tile (half the tiles, prologues and weight
+// traffic for the large maps); chosen per layer by the tactic tuner, runtime/tune.cpp.
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
@@ -718,6 +719,15 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
 
 template <int BKT, int TPS, bool I8 = false, int MI = 2>
 int32_t launch_bn(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    if constexpr (MI == 4) {  // 256-row tiles: instantiated for the column widths of the large-map layers
+        switch (a.bn) {
+            case 32: launch<2, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+            case 64: launch<4, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+            case 80: launch<5, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
+            default: return TRTX_ERR_UNSUPPORTED;
+        }
+        return TRTX_OK;
+    }
     switch (a.bn) {
         case 16: launch<1, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
         case 32: launch<2, BKT, TPS, I8, MI>(a, in_bytes, w_bytes, s); break;
@@ -743,6 +753,8 @@ bool wsk_default(const ConvArgs& a) {
 }
 // 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
+// ... 256-row tiles too, for 32/64/80-wide column tiles
+bool bm256_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16 && (a.bn == 32 || a.bn == 64 || a.bn == 80); }
 
 }  // namespace
 
@@ -781,14 +793,14 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
     return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
            a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9 &&
-           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)));
+           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && bm256_possible(a)));
 }
 
 // ---- tactics: the launch configurations of one layer that produce the SAME packed-weight layout, so that they can be exchanged
 // at run time.  Entry 0 is what the untuned dispatch does.  Tiles of any width / height accumulate every output element over
 // K in the same order (bit-identical results); the wave-split-K and weight-stationary kernels sum in a different order (fp16
 // results may differ in the last place).
-int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out) {
+int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_efficient_only) {
     int n = 0;
     auto push = [&](int bn, int bk, int bm, int wsk, int ws) {
         for (int i = 0; i < n; ++i)
@@ -809,14 +821,16 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out) {
         const int bn = bns[bi];
         if (a.Cout_pad % bn) continue;
         if (bn == 16 && a.Cout_pad > 32 && bn != a.bn) continue;  // 16-wide tiles re-read the A tile Cout/16 times: only for tiny Cout
+        if (work_efficient_only && bn != a.bn) continue;
         for (int ki = 0; ki < 2; ++ki) {
             ConvArgs t = a;
             t.bn = bn;
             t.bk = bks[ki];
             if (ki == 1 && bks[1] == bks[0]) continue;
             push(bn, t.bk, 128, 1, 1);
-            if (bm64_possible(t)) push(bn, t.bk, 64, 1, 1);
-            if (wsk_possible(t)) push(bn, t.bk, 128, 2, 1);
+            if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
+            if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
+            if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
         }
     }
     return n;
@@ -851,7 +865,7 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel); t_wsk: 0 = that rule, 1 = never,
         // 2 = wherever the variant exists
         const bool wsk = a.t_wsk == 1 ? false : (a.t_wsk == 2 ? wsk_possible(a) : wsk_default(a));
-        const bool bm64 = a.bm == 64;
+        const bool bm64 = a.bm == 64, bm256 = a.bm == 256;
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
@@ -859,11 +873,13 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);
         } else if (a.bk == 64) {
-            st = bm64 ? launch_bn<64, 1, false, 1>(a, in_bytes, w_bytes, s) : launch_bn<64, 1>(a, in_bytes, w_bytes, s);
+            st = bm64 ? launch_bn<64, 1, false, 1>(a, in_bytes, w_bytes, s)
+                      : (bm256 ? launch_bn<64, 1, false, 4>(a, in_bytes, w_bytes, s) : launch_bn<64, 1>(a, in_bytes, w_bytes, s));
         } else if (a.CinK == 16) {
             st = launch_bn<32, 2>(a, in_bytes, w_bytes, s);
         } else {
-            st = bm64 ? launch_bn<32, 1, false, 1>(a, in_bytes, w_bytes, s) : launch_bn<32, 1>(a, in_bytes, w_bytes, s);
+            st = bm64 ? launch_bn<32, 1, false, 1>(a, in_bytes, w_bytes, s)
+                      : (bm256 ? launch_bn<32, 1, false, 4>(a, in_bytes, w_bytes, s) : launch_bn<32, 1>(a, in_bytes, w_bytes, s));
         }
         if (st != TRTX_OK) return st;
     }

@@ -42,7 +42,7 @@ struct ConvArgs {
     const float* cscale;   // [Cout_pad]
     float out_inv_scale, res_scale;
     // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
-    int bm;     // igemm rows per tile: 0 / 128, or 64
+    int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
     int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported)
 };
@@ -67,7 +67,9 @@ void conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw
                           int8_t* packed, float* wscale_out);
 int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
 // the tactics applicable to a layer (a.N / a.M at the batch it will run with); out[0] is the untuned default. Returns the count.
-int conv_tactics(const ConvArgs& a, ConvTactic* out, int max_out);
+// work_efficient_only: leave out the configurations that buy latency with extra traffic (narrower column tiles re-read the
+// activations, 64-row tiles re-read the weights) - what an engine whose contexts run side by side should choose from.
+int conv_tactics(const ConvArgs& a, ConvTactic* out, int max_out, bool work_efficient_only = false);
 void conv_apply_tactic(ConvArgs* a, const ConvTactic& t);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it

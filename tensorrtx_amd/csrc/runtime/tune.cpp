@@ -9,8 +9,9 @@
 //     layer using its candidate of that index: each candidate is timed behind its real producer, with the cache state of the
 //     real sequence, instead of alone in a loop (a kernel timed alone keeps its weights in L2 and looks faster than it is -
 //     profiles/r02_ws_per_op.txt);
-//   * a layer leaves its default only for a candidate that is at least 3 % faster; the choice is remembered per layer signature
-//     for the life of the process, so that two engines built from the same plan run the same kernels.
+//   * a layer leaves its default only for a candidate that is at least 3 % faster, and that is still faster than the default was
+//     when all the winners run together (second look); the choice is remembered per layer signature for the life of the
+//     process, so that two engines built from the same plan run the same kernels.
 //
 // Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
 // convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its default.
@@ -29,7 +30,7 @@ using namespace trtx;
 
 namespace {
 
-constexpr int kMaxTactics = 16;
+constexpr int kMaxTactics = 24;
 
 struct SigKey {
     int v[28];
@@ -69,6 +70,11 @@ int32_t tune_engine(trtx_engine* e) {
     static const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
     Plan& plan = e->plan;
     e->tactics.clear();
+    // setMaxAuxStreams(0) is how a caller says "I keep several execution contexts in flight": whole batches overlap, the chip is
+    // shared, and a kernel that finishes sooner by moving more bytes (narrow or short tiles) slows its neighbours down.  Measured
+    // on YOLOv8n b32, 3 contexts: full candidate set 32.1k img/s against 33.6k untuned, although the same choices make a lone
+    // context 5.7 % faster (profiles/r02_tactics_*.txt).  Such engines choose among the work-efficient configurations only.
+    const bool throughput = e->net && e->net->max_aux_streams == 0;
     struct Item {
         int op;
         SigKey key;
@@ -87,8 +93,8 @@ int32_t tune_engine(trtx_engine* e) {
         a.residual = op.in.size() > 1 ? reinterpret_cast<const void*>(1) : nullptr;  // only its presence matters here
         Item it;
         it.op = (int)k;
-        it.key = signature(a, a.act1 * 16 + a.act2);
-        it.n = conv_tactics(a, it.cand, kMaxTactics);
+        it.key = signature(a, a.act1 * 16 + a.act2 + (throughput ? 4096 : 0));
+        it.n = conv_tactics(a, it.cand, kMaxTactics, throughput);
         if (it.n < 1) continue;
         for (int i = 0; i < kMaxTactics; ++i) it.best_ms[i] = 1e30f;
         items.push_back(it);
@@ -139,6 +145,33 @@ int32_t tune_engine(trtx_engine* e) {
                 }
             }
         }
+        // Second look, with every layer on its winner at once: a candidate that won while its neighbours ran THEIR candidate of the
+        // same index may not win next to the kernels that were finally chosen (a different kernel before it, another cache state).
+        // A layer whose winner is not faster here than its default was in the all-default run goes back to the default.
+        if (st == TRTX_OK) {
+            std::vector<int> win(items.size(), 0);
+            for (size_t x = 0; x < items.size(); ++x) {
+                const Item& it = items[x];
+                for (int i = 1; i < it.n; ++i)
+                    if (it.best_ms[i] < it.best_ms[win[x]] && it.best_ms[i] < 0.97f * it.best_ms[0]) win[x] = i;
+                conv_apply_tactic(&plan.ops[it.op].conv, it.cand[win[x]]);
+            }
+            std::vector<float> fin(items.size(), 1e30f);
+            for (int r = 0; r <= reps && st == TRTX_OK; ++r) {
+                std::vector<OpTiming> prof;
+                st = execute_plan(c, plan.max_batch, bindings.data(), stream, &prof);
+                if (st != TRTX_OK || r == 0) continue;
+                for (size_t x = 0; x < items.size(); ++x) fin[x] = std::min(fin[x], prof[items[x].op].ms);
+            }
+            for (size_t x = 0; x < items.size() && st == TRTX_OK; ++x) {
+                Item& it = items[x];
+                if (win[x] == 0) continue;
+                const bool keep = fin[x] < 0.99f * it.best_ms[0];
+                for (int i = 1; i < it.n; ++i)
+                    if (i != win[x] || !keep) it.best_ms[i] = 1e30f;  // only the verified winner (or nothing) stays in the race
+                if (keep) it.best_ms[win[x]] = fin[x];               // what it costs where it will run
+            }
+        }
         for (const Item& it : items) conv_apply_tactic(&plan.ops[it.op].conv, it.cand[0]);
         cleanup();
         if (st != TRTX_OK) {
@@ -156,7 +189,7 @@ int32_t tune_engine(trtx_engine* e) {
                 if (same(it.cand[i], found->second)) pick = i;
         } else {
             for (int i = 1; i < it.n; ++i)
-                if (it.best_ms[i] < it.best_ms[pick] && it.best_ms[i] < 0.97f * it.best_ms[0]) pick = i;
+                if (it.best_ms[i] < it.best_ms[pick] && it.best_ms[i] < 0.99f * it.best_ms[0]) pick = i;
             g_choice[it.key] = it.cand[pick];
         }
         conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);

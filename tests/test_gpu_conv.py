@@ -117,6 +117,8 @@ TACTIC_CASES = [
     (2, 10, 10, 128, 256, 3, 2, 1, "silu", False, "none"),   # stride 2
     (1, 14, 14, 256, 64, 1, 1, 0, "none", True, "relu"),     # residual + second activation
     (1, 9, 9, 24, 40, 5, 1, 2, "leaky", False, "none"),      # Cin 24 (one ragged k-chunk), Cout 40 -> 48
+    (6, 160, 160, 64, 64, 3, 1, 1, "silu", True, "none"),    # 600 tiles of 256 rows: the 256-row tile joins the candidates
+    (8, 160, 160, 48, 32, 1, 1, 0, "silu", False, "none"),   # 1x1 over a large map, 32-wide column tiles, Cin 48 in a 64-wide slice
 ]
 
 

@@ -1,0 +1,70 @@
+"""Tactic selection by measurement at deserializeCudaEngine (runtime/tune.cpp; what TensorRT's builder does with its tactics behind
+IBuilder::buildSerializedNetwork, yolov8/src/model.cpp:327): every MFMA convolution gets a record, the choice is stable inside a
+process (two engines from one plan run the same kernels and give the same bits), engines built for contexts in flight
+(setMaxAuxStreams(0)) choose among the work-efficient configurations only, and a tuned engine is the same network as an untuned one."""
+import numpy as np
+import pytest
+import torch
+
+from tensorrtx_amd import engine, synth
+from util import synth_wts
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(e, x, gpu):
+    bufs = [x.to(gpu) if e.is_input[i] else torch.zeros(x.shape[0] * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu)
+            for i in range(e.nb_bindings)]
+    e.enqueue(x.shape[0], bufs)
+    torch.cuda.synchronize()
+    return {e.names[i]: bufs[i].cpu() for i in range(e.nb_bindings) if not e.is_input[i]}
+
+
+def test_tactics_are_recorded_stable_and_change_nothing_but_speed(gpu):
+    path, _ = synth_wts("yolov8n")
+    B, S = 6, 288   # a shape no other test builds: the process-wide choice cache is empty for it
+    plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1)
+    low = engine.describe_plan(plan, lowered=True)
+    n_igemm = sum(1 for o in low["ops"] if o["kind"] == "conv" and o.get("igemm"))
+    x = torch.from_numpy(synth.images(B, S, S, seed=21))
+    e1 = engine.Engine(plan)
+    try:
+        t1 = e1.tactics()
+        assert len(t1) == n_igemm and all(r["candidates"] >= 1 and r["tactic"] and r["default"] for r in t1)
+        # timed in place: every record of the first engine of this shape carries measured times, and a moved layer was faster
+        assert all(r["default_us"] > 0 for r in t1)
+        assert all(r["us"] < r["default_us"] for r in t1 if r["tactic"] != r["default"])
+        o1 = _run(e1, x, gpu)
+        e2 = engine.Engine(plan)          # same process: the remembered choice, no second timing run
+        try:
+            t2 = e2.tactics()
+            assert [r["tactic"] for r in t2] == [r["tactic"] for r in t1]
+            o2 = _run(e2, x, gpu)
+            for k in o1:
+                if k == "output":         # decode buffer: [count, count x 90 floats, untouched tail]
+                    a, b = o1[k].reshape(B, -1), o2[k].reshape(B, -1)
+                    assert torch.equal(a[:, 0], b[:, 0])
+                    for i in range(B):
+                        m = 1 + int(a[i, 0]) * 90
+                        assert torch.equal(a[i, :m], b[i, :m])
+                else:
+                    assert torch.equal(o1[k], o2[k]), f"two engines of one plan differ on '{k}'"
+        finally:
+            e2.close()
+    finally:
+        e1.close()
+
+
+def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu):
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=6, h=352, w=352, fp16=1, aux_streams=0)
+    e = engine.Engine(plan)
+    try:
+        for r in e.tactics():
+            if r["tactic"].startswith("igemm") and r["default"].startswith("igemm"):
+                rows, cols, _ = (int(v) for v in r["tactic"].split()[1].split("x"))
+                _, dcols, _ = (int(v) for v in r["default"].split()[1].split("x"))
+                assert rows >= 128 and cols == dcols, r   # no 64-row tiles, no narrower column tiles
+            assert not (r["tactic"].startswith("wsk") and not r["default"].startswith("wsk")), r
+    finally:
+        e.close()

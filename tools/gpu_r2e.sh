@@ -1,0 +1,24 @@
+#!/bin/bash
+# round-2 call E: 256-row tiles + second-look tuner: tactic tests, then tuned/untuned at 1 and 3 contexts (3-context runs twice: variance)
+set -u
+O=gpurun_out/r2e
+mkdir -p $O
+python -m pytest tests/test_gpu_conv.py -x -q -k "tactic" > $O/pytest.log 2>&1
+tail -3 $O/pytest.log
+run() { local tag=$1; shift; local c=$1; shift
+  env "$@" timeout 300 python bench.py --contexts $c --no-cpu-baseline --steps 100 --dump-ops $O/ops_$tag.json > $O/bench_$tag.json 2> $O/bench_$tag.err; }
+run tune_c1 1 TRTX_TUNE_VERBOSE=1
+run notune_c1 1 TRTX_TUNE=0
+run tune_c3a 3 TRTX_TUNE=1
+run notune_c3a 3 TRTX_TUNE=0
+run tune_c3b 3 TRTX_TUNE=1
+run notune_c3b 3 TRTX_TUNE=0
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r2e/bench_*.json")):
+    try:
+        r=json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], round(r["value"]), round(r["ms_per_step"],3), "single", round(r.get("single_context",{}).get("ms_per_step",0),3), "d2h", round(r["d2h_inclusive"]["ms_per_step"],3), "host", round(r["host_fed"]["ms_per_step"],3), "frac", round(r["roofline"]["frac"],4), "avg_us", round(r["roofline"]["avg_launch_us"],2), "all_ms", round(r["roofline"]["all_kernels_ms_per_step"],3), r["roofline"]["tactics"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY
