@@ -248,11 +248,11 @@ def conv2d_nhwc_f16(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", re
 
 
 def conv2d_tactics(N, H, W, Cin, Cout, k, stride, pad, residual=False, ld_in=None, ld_out=None, ld_res=None, max_out=32):
-    """The exchangeable launch configurations of one conv layer (host only): list of (bn, bk, bm, wsk, ws); [0] is the default."""
-    arr = (ctypes.c_int32 * (5 * max_out))()
+    """The exchangeable launch configurations of one conv layer (host only): list of (bn, bk, bm, wsk, ws, r3); [0] is the default."""
+    arr = (ctypes.c_int32 * (6 * max_out))()
     n = lib().trtx_op_conv2d_tactics(N, H, W, Cin, ld_in or Cin, Cout, ld_out or Cout, k, k, stride, stride, pad, pad, 1 if residual else 0,
                                      (ld_res or Cout) if residual else 0, arr, max_out)
-    return [tuple(arr[5 * i + j] for j in range(5)) for i in range(n)]
+    return [tuple(arr[6 * i + j] for j in range(6)) for i in range(n)]
 
 
 def conv_force_tactic(tactic=None):
@@ -260,7 +260,7 @@ def conv_force_tactic(tactic=None):
     if tactic is None:
         check(lib().trtx_op_conv_force_tactic(None), "trtx_op_conv_force_tactic")
     else:
-        check(lib().trtx_op_conv_force_tactic((ctypes.c_int32 * 5)(*tactic)), "trtx_op_conv_force_tactic")
+        check(lib().trtx_op_conv_force_tactic((ctypes.c_int32 * 6)(*tactic)), "trtx_op_conv_force_tactic")
 
 
 # ---------------------------------------------------------------------------------------------------- kINT8 conv (tests / tools)

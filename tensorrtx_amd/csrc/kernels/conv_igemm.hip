@@ -86,6 +86,124 @@ __device__ __forceinline__ int swz(int row) {
     return (row >> 1) & 7;
 }
 
+// ---- epilogue shared by the implicit-GEMM kernels.  The accumulators (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel
+// 16i + (lane&15) of its wave's WR rows) go through a wave-private fp32 LDS tile, 16 rows at a time, and come back row-major:
+// one lane = 8 consecutive channels of one pixel, so residual reads and output stores are whole 16-byte chunks (128-byte lines
+// per 8 lanes) and - this is the point - the code that finishes them (bias, act1, rounding, residual, act2, requantisation, ragged
+// stores) exists ONCE, in a rolled loop with wave-uniform branches, instead of once per accumulator fragment and activation
+// kind.  Unrolled, that code was 80 % of a 45-90 KB kernel against a 64 KB instruction cache shared by two CUs
+// (profiles/r02_code_size.txt).  `pixel_of(t)` maps row t of the tile (0 .. 64 * MI) to the output pixel index, or -1.
+template <int NFRAG, int MI, bool I8, int LDS_BYTES, typename PixelOf>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[MI][NFRAG], intx4 (&acci)[MI][NFRAG], char* smem, int wave, int lane,
+                                              int n0, PixelOf&& pixel_of) {
+    constexpr int BN = 16 * NFRAG;
+    constexpr int WR = 16 * MI;
+    _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
+    const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
+    const int px_in = lane & 15;
+    const int ch_in = (lane >> 4) * 4;
+    const bool second = res || p.act2 != ACT_NONE;
+    constexpr int PS = BN * 4 + 16;   // fp32 row stride of the staging tile (padded: 16 consecutive rows start in distinct bank groups)
+    static_assert(4 * 16 * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
+    constexpr int CPR = BN / 8;       // 8-channel items per row
+    constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
+    __syncthreads();  // every wave is done reading the last stage
+    char* mine = smem + wave * 16 * PS;
+#pragma nounroll
+    for (int i = 0; i < MI; ++i) {
+        // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
+#pragma unroll
+        for (int ii = 0; ii < MI; ++ii) {
+            if (ii != i) continue;
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) {
+                floatx4 v = acc[ii][j];
+                if constexpr (I8) {
+                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
+                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
+                }
+                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
+            }
+        }
+        // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
+#pragma nounroll
+        for (int q = lane; q < ITEMS; q += 64) {
+            const int row = q / CPR, cc = q % CPR;
+            const int m = pixel_of(wave * WR + i * 16 + row);
+            const int co = n0 + cc * 8;
+            if (m < 0 || co >= p.Cout) continue;
+            const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
+            const floatx4 hi = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32 + 16);
+            float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
+                x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+            }
+            half8 v;
+            if (p.act1 == ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-x[e])));
+            } else if (p.act1 == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] > 0.f ? x[e] : 0.f);
+            } else if (p.act1 == ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e]);
+            } else {
+#pragma nounroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_slow(x[e], p.act1, p.alpha1));
+            }
+            const bool vec = !p.scalar_out;
+            if (second) {
+                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (res) {
+                    if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
+                        const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = round_to_half((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
+                    } else if (vec) {
+                        rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
+                    } else {
+#pragma nounroll
+                        for (int e = 0; e < 8; ++e)
+                            if (co + e < p.Cout) rv[e] = res[(size_t)m * p.ld_res + co + e];
+                    }
+                }
+                if (p.act2 == ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
+                } else if (p.act2 == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = (float)v[e] + (float)rv[e];
+                        v[e] = round_to_half(t > 0.f ? t : 0.f);
+                    }
+                } else {
+#pragma nounroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2));
+                }
+            }
+            if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
+                unsigned long long qv = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = rintf((float)v[e] * p.out_inv_scale);
+                    t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+                    qv |= (unsigned long long)(unsigned char)(int8_t)(int)t << (8 * e);
+                }
+                *reinterpret_cast<unsigned long long*>(static_cast<int8_t*>(p.out) + (size_t)m * p.ld_out + co) = qv;
+            } else if (vec) {
+                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
+            } else {  // ragged channel counts / unaligned slices: element-wise stores
+#pragma nounroll
+                for (int e = 0; e < 8; ++e)
+                    if (co + e < p.Cout) out[(size_t)m * p.ld_out + co + e] = v[e];
+            }
+        }
+    }
+}
+
 // TPS = filter taps per k-step: 1 normally; 2 for Cin <= 16 (CinK = 16), where one 32-wide step covers taps 2kt and 2kt+1
 // and the tap a lane fetches depends on which half of the row it fills.
 // I8: int8 activations / weights on v_mfma_i32_16x16x64_i8 (kINT8 engines).  A 64-byte LDS row then holds 64 int8 channels
@@ -343,119 +461,203 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue.  The accumulators (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15) of its wave's WR
-    // rows) go through a wave-private fp32 LDS tile, 16 rows at a time, and come back row-major: one lane = 8 consecutive channels
-    // of one pixel, so residual reads and output stores are whole 16-byte chunks (128-byte lines per 8 lanes) and - this is the
-    // point - the code that finishes them (bias, act1, rounding, residual, act2, requantisation, ragged stores) exists ONCE, in a
-    // rolled loop with wave-uniform branches, instead of once per accumulator fragment and activation kind.  Unrolled, that code
-    // was 80 % of a 45-90 KB kernel against a 64 KB instruction cache shared by two CUs: every switch between two of the ~10
-    // instantiations a network uses started with instruction-fetch misses on all 256 CUs (measured: +10-20 us on the first
-    // launch after a switch, profiles/r02_icache_*.txt).
-    _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
-    const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
-    const int px_in = lane & 15;
-    const int ch_in = (lane >> 4) * 4;
-    const bool second = res || p.act2 != ACT_NONE;
     if (dbg & 8) return;
-    constexpr int PS = BN * 4 + 16;   // fp32 row stride of the staging tile (padded: 16 consecutive rows start in distinct bank groups)
-    static_assert(4 * 16 * PS <= NST * STAGE_BYTES, "epilogue tile must fit in the stage buffers");
-    constexpr int CPR = BN / 8;       // 8-channel items per row
-    constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
-    __syncthreads();  // every wave is done reading the last stage
-    char* mine = smem + wave * 16 * PS;
-#pragma nounroll
-    for (int i = 0; i < MI; ++i) {
-        // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
+    conv_epilogue<NFRAG, MI, I8, NST * STAGE_BYTES>(p, acc, acci, smem, wave, lane, n0, [&](int t) {
+        const int m = m0 + t;
+        return m < p.M ? m : -1;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 variant with ROW REUSE ("r3").  In the kernel above the three taps (r, 0), (r, 1), (r, 2) of a filter row
+// fetch three A tiles that are the same pixels shifted by one: every input pixel crosses the L1 -> LDS path 9 times.  Here the
+// GEMM's M axis runs over the image with its two padding COLUMNS made explicit (pitch Wp = W + 2, position t <-> (n, h, wp),
+// input column wp - 1), so that "one pixel to the right" is always t + 1: ONE A tile per (filter row, channel slice) is loaded
+// and the three taps read it at row offsets 0, 1, 2.  A tile of BM rows therefore finishes BM - 2 positions (the last two rows
+// lack their right neighbours and are recomputed by the next tile); positions in the padding columns are computed and thrown
+// away (2 / Wp of the work).  A traffic through L1 -> LDS drops 3x; the weights of the three taps arrive as three B tiles per
+// step.  Same packed weights, so it is one more exchangeable tactic (ConvArgs::t_r3); K is walked (filter row, channel slice,
+// tap) instead of (tap, channel slice), so fp16 results may differ from the kernel above in the last place.
+template <int NFRAG, int BKT, int MI>
+__global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int total_tiles,
+                                                                int xcd_chunk) {
+    constexpr int BN = 16 * NFRAG;
+    constexpr int BM = 64 * MI;
+    constexpr int BME = BM - 2;                    // positions finished per tile
+    constexpr int WR = 16 * MI;
+    constexpr int ROW_B = BKT * 2;
+    constexpr int CH = BKT / 8;
+    constexpr int RPI = 64 / CH;
+    constexpr int A_LOADS = BM / (4 * RPI);
+    constexpr int B_PASSES = (BN + 4 * RPI - 1) / (4 * RPI);
+    constexpr int B_ROWS = B_PASSES * 4 * RPI;
+    constexpr int A_BYTES = BM * ROW_B;
+    constexpr int BT_BYTES = B_ROWS * ROW_B;       // weight tile of one tap
+    constexpr int STAGE_BYTES = A_BYTES + 3 * BT_BYTES;
+    constexpr int LOADS_PER_TILE = A_LOADS + 3 * B_PASSES;
+    constexpr int KSUB = BKT / 32;
+    constexpr int NST = BKT == 64 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    if (xcd_chunk) {
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    const int t0 = (tile / tiles_n) * BME;         // first position of the tile in the padded-column index space
+    const int n0 = (tile % tiles_n) * BN;
+    const int Wp = p.W + 2;
+    const int HWp = p.H * Wp;
+    const int Mp = p.N * HWp;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
+
+    // exact position -> (image, row, padded column) with float reciprocals fixed up by one step (quotients are small)
+    const float inv_hwp = __builtin_amdgcn_rcpf((float)HWp), inv_wp = __builtin_amdgcn_rcpf((float)Wp);
+    auto split = [&](int t, int& n, int& h, int& wp) {
+        n = (int)((float)t * inv_hwp);
+        int rem = t - n * HWp;
+        if (rem < 0) { --n; rem += HWp; }
+        if (rem >= HWp) { ++n; rem -= HWp; }
+        h = (int)((float)rem * inv_wp);
+        wp = rem - h * Wp;
+        if (wp < 0) { --h; wp += Wp; }
+        if (wp >= Wp) { ++h; wp -= Wp; }
+    };
+
+    // ---- per-lane A source: LDS row rho holds position t0 - 1 + rho (the left neighbour of the tile's first position comes first)
+    const int lrow = lane / CH;
+    const int lswz = BKT == 32 ? swz<32>(lrow) : ((lrow >> 1) | ((wave & 1) << 2));
+    const int lchunk = (lane % CH) ^ lswz;
+    unsigned a_base[A_LOADS];   // byte offset of (n, h - 1, wp - 1, channel lchunk * 8): filter row 0; wraps for border pixels (masked)
+    unsigned a_rows[A_LOADS];   // bit r: filter row r of this position lies inside the image (0: padding column / outside the tensor)
 #pragma unroll
-        for (int ii = 0; ii < MI; ++ii) {
-            if (ii != i) continue;
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int t = t0 - 1 + (4 * i + wave) * RPI + lrow;
+        const bool in = t >= 0 && t < Mp;
+        int n, h, wp;
+        split(in ? t : 0, n, h, wp);
+        const bool col = wp >= 1 && wp <= p.W;
+        a_base[i] = (unsigned)(((n * p.H + h - 1) * p.W + wp - 1) * p.ld_in + lchunk * 8) * 2u;
+        a_rows[i] = (in && col) ? tap_range_mask(h - 1, 3, p.H) : 0u;
+    }
+    const int cmax = p.Cin - lchunk * 8;  // this lane's chunk holds real channels while uc < cmax
+    unsigned b_off[B_PASSES];
 #pragma unroll
-            for (int j = 0; j < NFRAG; ++j) {
-                floatx4 v = acc[ii][j];
-                if constexpr (I8) {
-                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
-                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
-                }
-                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
-            }
+    for (int j = 0; j < B_PASSES; ++j) {
+        const int row = (4 * j + wave) * RPI + lrow;
+        b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;
+    }
+
+    // wave-uniform walk: step e = (filter row r, channel slice uc)
+    const int spt = p.CinK / BKT;
+    const int nk = 3 * spt;
+    int s_kt = 0, s_r = 0, s_uc = 0;
+    const unsigned row_bytes = (unsigned)(p.W * p.ld_in) * 2u;   // one image row down
+    const unsigned tap_bytes = (unsigned)p.CinK * 2u;            // one tap along the packed K axis
+
+    auto issue_tile = [&](int stage) {
+        char* sbase = smem + stage * STAGE_BYTES;
+        const bool live = s_kt < nk;
+        const unsigned add = (unsigned)s_r * row_bytes + (unsigned)s_uc * 2u;
+        const bool chunk_ok = s_uc < cmax;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const bool ok = ((a_rows[i] >> s_r) & 1u) && chunk_ok && live;
+            const unsigned voff = ok ? a_base[i] + add : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
         }
-        // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
-#pragma nounroll
-        for (int q = lane; q < ITEMS; q += 64) {
-            const int row = q / CPR, cc = q % CPR;
-            const int m = m0 + wave * WR + i * 16 + row;
-            const int co = n0 + cc * 8;
-            if (m >= p.M || co >= p.Cout) continue;
-            const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
-            const floatx4 hi = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32 + 16);
-            float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (p.bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-                x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
-                x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+        const unsigned kadd = (unsigned)(s_r * 3) * tap_bytes + (unsigned)s_uc * 2u;   // tap (r, 0) of this channel slice
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < B_PASSES; ++j) {
+                const unsigned voff = (live && b_off[j] != kOOB) ? b_off[j] + kadd + (unsigned)q * tap_bytes : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + q * BT_BYTES + (4 * j + wave) * RPI * ROW_B), 16, voff,
+                                                         0, 0, 0);
             }
-            half8 v;
-            if (p.act1 == ACT_SILU) {
+        ++s_kt;
+        s_uc += BKT;
+        const int wrap = s_uc >= p.CinK;
+        s_uc = wrap ? 0 : s_uc;
+        s_r += wrap;
+    };
+
+    floatx4 acc[MI][NFRAG];
+    intx4 acci[MI][NFRAG];  // unused (the shared epilogue's int8 leg)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-x[e])));
-            } else if (p.act1 == ACT_RELU) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] > 0.f ? x[e] : 0.f);
-            } else if (p.act1 == ACT_NONE) {
+        for (int j = 0; j < NFRAG; ++j) {
+            acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            acci[i][j] = intx4{0, 0, 0, 0};
+        }
+
+    // fragment read offsets: B rows (lane & 15) as in the kernel above; A rows (lane & 15) + q for tap q.  The swizzle is keyed by
+    // the LDS row, and tile / fragment bases are multiples of 16 rows, so it is the swizzle of (lane & 15) + q.
+    const int frow = lane & 15;
+    int fb_off[KSUB], fa_off[3][KSUB];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e]);
-            } else {
-#pragma nounroll
-                for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_slow(x[e], p.act1, p.alpha1));
-            }
-            const bool vec = !p.scalar_out;
-            if (second) {
-                half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (res) {
-                    if (p.res_i8) {  // int8 residual: 8 bytes, dequantised with its tensor scale
-                        const long long rq = *reinterpret_cast<const long long*>(static_cast<const int8_t*>(p.residual) + (size_t)m * p.ld_res + co);
+    for (int h = 0; h < KSUB; ++h) {
+        fb_off[h] = frow * ROW_B + ((((lane >> 4) + 4 * h) ^ swz<BKT>(frow)) * 16);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rv[e] = round_to_half((float)(int8_t)(rq >> (8 * e)) * p.res_scale);
-                    } else if (vec) {
-                        rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + co);
-                    } else {
-#pragma nounroll
-                        for (int e = 0; e < 8; ++e)
-                            if (co + e < p.Cout) rv[e] = res[(size_t)m * p.ld_res + co + e];
-                    }
-                }
-                if (p.act2 == ACT_NONE) {
+        for (int q = 0; q < 3; ++q) fa_off[q][h] = (frow + q) * ROW_B + ((((lane >> 4) + 4 * h) ^ swz<BKT>(frow + q)) * 16);
+    }
+    const int a_frag = wave * WR * ROW_B;
+
+    auto compute = [&](int stage) {
+        const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
-                } else if (p.act2 == ACT_RELU) {
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t = (float)v[e] + (float)rv[e];
-                        v[e] = round_to_half(t > 0.f ? t : 0.f);
-                    }
-                } else {
-#pragma nounroll
-                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(act_apply((float)v[e] + (float)rv[e], p.act2, p.alpha2));
+            for (int h = 0; h < KSUB; ++h) {
+                half8 af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + fa_off[q][h]);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + q * BT_BYTES + j * 16 * ROW_B + fb_off[h]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
                 }
             }
-            if (p.out_i8) {  // requantise: round to nearest even, clamp to +-127, 8 channels = one 8-byte store
-                unsigned long long qv = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = rintf((float)v[e] * p.out_inv_scale);
-                    t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
-                    qv |= (unsigned long long)(unsigned char)(int8_t)(int)t << (8 * e);
-                }
-                *reinterpret_cast<unsigned long long*>(static_cast<int8_t*>(p.out) + (size_t)m * p.ld_out + co) = qv;
-            } else if (vec) {
-                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + co) = v;
-            } else {  // ragged channel counts / unaligned slices: element-wise stores
-#pragma nounroll
-                for (int e = 0; e < 8; ++e)
-                    if (co + e < p.Cout) out[(size_t)m * p.ld_out + co + e] = v[e];
-            }
+    };
+
+#define TRTX_R3STEP(S)                                                                        \
+    {                                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory");     \
+        __builtin_amdgcn_s_barrier();                                                         \
+        issue_tile(((S) + NST - 1) % NST);                                                    \
+        compute(S);                                                                           \
+    }
+    issue_tile(0);
+    if (NST == 3) issue_tile(1);
+    for (int kt = 0;;) {
+        TRTX_R3STEP(0);
+        if (++kt == nk) break;
+        TRTX_R3STEP(1);
+        if (++kt == nk) break;
+        if (NST == 3) {
+            TRTX_R3STEP(2);
+            if (++kt == nk) break;
         }
     }
+#undef TRTX_R3STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // row t of the tile is position t0 + t: a real output pixel unless it sits in a padding column, past the tensor, or in the
+    // two rows this tile leaves to the next one
+    conv_epilogue<NFRAG, MI, false, NST * STAGE_BYTES>(p, acc, acci, smem, wave, lane, n0, [&](int t) {
+        const int pos = t0 + t;
+        if (t >= BME || pos >= Mp) return -1;
+        int n, h, wp;
+        split(pos, n, h, wp);
+        return (wp >= 1 && wp <= p.W) ? (n * p.H + h) * p.W + wp - 1 : -1;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -751,6 +953,26 @@ bool wsk_default(const ConvArgs& a) {
     const int tiles128 = ((a.M + 127) / 128) * (a.Cout_pad / a.bn);
     return !no_wsk && wsk_possible(a) && tiles128 <= 256 && a.Kpad / 32 >= 16;
 }
+// the row-reuse kernel: fp16 3x3 stride 1 pad 1 with 16-byte output stores, 128-row tiles, 32..128-wide column tiles
+bool r3_possible(const ConvArgs& a) {
+    return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
+           a.dil_h == 1 && a.dil_w == 1 && a.CinK % 32 == 0 && a.CinK != 16 && !a.scalar_out && a.Ho == a.H && a.Wo == a.W &&
+           (a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) && (a.bm == 0 || a.bm == 128) && (a.bk == 32 || a.CinK % 64 == 0) &&
+           (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
+}
+template <int BKT>
+int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
+    const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
+    switch (a.bn) {
+        case 32: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<2, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 64: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<4, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 80: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<5, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 128: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<8, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+    return TRTX_OK;
+}
 // 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 // ... 256-row tiles too, for 32/64/80-wide column tiles
@@ -793,7 +1015,8 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
     return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
            a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9 &&
-           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && bm256_possible(a)));
+           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && bm256_possible(a))) &&
+           (a.t_r3 == 0 || r3_possible(a));
 }
 
 // ---- tactics: the launch configurations of one layer that produce the SAME packed-weight layout, so that they can be exchanged
@@ -802,13 +1025,13 @@ bool conv_igemm_supported(const ConvArgs& a) {
 // results may differ in the last place).
 int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_efficient_only) {
     int n = 0;
-    auto push = [&](int bn, int bk, int bm, int wsk, int ws) {
+    auto push = [&](int bn, int bk, int bm, int wsk, int ws, int r3 = 0) {
         for (int i = 0; i < n; ++i)
-            if (out[i].bn == bn && out[i].bk == bk && out[i].bm == bm && out[i].wsk == wsk && out[i].ws == ws) return;
-        if (n < max_out) out[n++] = ConvTactic{bn, bk, bm, wsk, ws};
+            if (out[i].bn == bn && out[i].bk == bk && out[i].bm == bm && out[i].wsk == wsk && out[i].ws == ws && out[i].r3 == r3) return;
+        if (n < max_out) out[n++] = ConvTactic{bn, bk, bm, wsk, ws, r3};
     };
     ConvArgs a = a0;
-    a.bm = 0; a.t_wsk = 0; a.t_ws = 0;
+    a.bm = 0; a.t_wsk = 0; a.t_ws = 0; a.t_r3 = 0;
     if (!conv_igemm_supported(a)) return 0;
     const bool fp16 = !a.in_i8 && !a.out_i8 && !a.res_i8;
     const bool ws_ok = fp16 && conv_ws_supported(a);
@@ -831,6 +1054,7 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
             if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
+            if (r3_possible(t)) push(bn, t.bk, 128, 1, 1, 1);
         }
     }
     return n;
@@ -842,6 +1066,7 @@ void conv_apply_tactic(ConvArgs* a, const ConvTactic& t) {
     a->bm = t.bm;
     a->t_wsk = t.wsk;
     a->t_ws = t.ws;
+    a->t_r3 = t.r3;
 }
 
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
@@ -869,6 +1094,8 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
+        } else if (a.t_r3 == 1 && r3_possible(a)) {
+            st = a.bk == 64 ? launch_r3<64>(a, in_bytes, w_bytes, s) : launch_r3<32>(a, in_bytes, w_bytes, s);
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);

@@ -88,19 +88,20 @@ static ConvTactic g_forced{};
 
 extern "C" int32_t trtx_op_conv_force_tactic(const int32_t* t) {
     g_force_tactic = t != nullptr;
-    if (t) g_forced = ConvTactic{t[0], t[1], t[2], t[3], t[4]};
+    if (t) g_forced = ConvTactic{t[0], t[1], t[2], t[3], t[4], t[5]};
     return TRTX_OK;
 }
 
 extern "C" int32_t trtx_op_conv2d_tactics(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph,
-                                          int pw, int has_residual, int ld_res, int32_t* out5, int32_t max_out) {
-    if (!out5 || max_out < 1 || N < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1) return 0;
+                                          int pw, int has_residual, int ld_res, int32_t* out6, int32_t max_out) {
+    if (!out6 || max_out < 1 || N < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1) return 0;
     ConvArgs a = op_conv_args(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, 0, has_residual, ld_res, 0);
     a.residual = has_residual ? reinterpret_cast<const void*>(1) : nullptr;
     std::vector<ConvTactic> t(max_out);
     const int n = conv_tactics(a, t.data(), max_out);
     for (int i = 0; i < n; ++i) {
-        out5[5 * i + 0] = t[i].bn; out5[5 * i + 1] = t[i].bk; out5[5 * i + 2] = t[i].bm; out5[5 * i + 3] = t[i].wsk; out5[5 * i + 4] = t[i].ws;
+        out6[6 * i + 0] = t[i].bn; out6[6 * i + 1] = t[i].bk; out6[6 * i + 2] = t[i].bm; out6[6 * i + 3] = t[i].wsk; out6[6 * i + 4] = t[i].ws;
+        out6[6 * i + 5] = t[i].r3;
     }
     return n;
 }

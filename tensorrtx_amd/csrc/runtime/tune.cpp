@@ -3,7 +3,8 @@
 // the network, not kernels, and lowering is re-run at deserializeCudaEngine - so that is where the timing happens:
 //
 //   * every MFMA convolution of the plan has a small set of exchangeable launch configurations (conv_tactics(): column-tile
-//     width, 64- or 128-row tiles, 32- or 64-wide k-steps, the wave-split-K and the weight-stationary kernel where they apply);
+//     width, 64- / 128- / 256-row tiles, 32- or 64-wide k-steps, the wave-split-K, the weight-stationary and the 3x3 row-reuse
+//     kernel where they apply);
 //     they share the layer's packed weights, so nothing is re-packed;
 //   * the WHOLE plan is run in place (profile mode: one stream, HIP events around every op) once per candidate index, every
 //     layer using its candidate of that index: each candidate is timed behind its real producer, with the cache state of the
@@ -49,14 +50,16 @@ SigKey signature(const ConvArgs& a, int act_pair) {
 std::mutex g_mu;
 std::map<SigKey, ConvTactic> g_choice;  // process-wide: layer signature -> tactic in use
 
-bool same(const ConvTactic& a, const ConvTactic& b) { return a.bn == b.bn && a.bk == b.bk && a.bm == b.bm && a.wsk == b.wsk && a.ws == b.ws; }
+bool same(const ConvTactic& a, const ConvTactic& b) {
+    return a.bn == b.bn && a.bk == b.bk && a.bm == b.bm && a.wsk == b.wsk && a.ws == b.ws && a.r3 == b.r3;
+}
 
 std::string tactic_name(const ConvTactic& t) {
     std::ostringstream o;
     if (t.ws == 2) {
         o << "ws";
     } else {
-        o << (t.wsk == 2 ? "wsk" : "igemm") << " " << (t.wsk == 2 ? 64 : t.bm) << "x" << t.bn << "x" << t.bk;
+        o << (t.r3 ? "r3" : (t.wsk == 2 ? "wsk" : "igemm")) << " " << (t.wsk == 2 ? 64 : t.bm) << "x" << t.bn << "x" << t.bk;
     }
     return o.str();
 }

@@ -117,6 +117,8 @@ TACTIC_CASES = [
     (2, 10, 10, 128, 256, 3, 2, 1, "silu", False, "none"),   # stride 2
     (1, 14, 14, 256, 64, 1, 1, 0, "none", True, "relu"),     # residual + second activation
     (1, 9, 9, 24, 40, 5, 1, 2, "leaky", False, "none"),      # Cin 24 (one ragged k-chunk), Cout 40 -> 48
+    (2, 20, 20, 80, 80, 3, 1, 1, "silu", False, "none"),     # Cin 80: a ragged third channel slice per filter row (row-reuse kernel)
+    (3, 7, 5, 64, 128, 3, 1, 1, "none", False, "none"),      # tiny map: padding columns are 2 of 7, tiles straddle rows and images
     (6, 160, 160, 64, 64, 3, 1, 1, "silu", True, "none"),    # 600 tiles of 256 rows: the 256-row tile joins the candidates
     (8, 160, 160, 48, 32, 1, 1, 0, "silu", False, "none"),   # 1x1 over a large map, 32-wide column tiles, Cin 48 in a 64-wide slice
 ]
@@ -150,7 +152,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
             got = y.float().cpu()
             err = (got - ref).abs().max().item()
             assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"tactic {t}: max err {err} (scale {scale})"
-            if t[3] == 1 and t[4] == 1:  # plain implicit-GEMM tiles
+            if t[3] == 1 and t[4] == 1 and t[5] == 0:  # plain implicit-GEMM tiles
                 if exact is None:
                     exact = got
                 else:
