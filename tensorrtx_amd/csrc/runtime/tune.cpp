@@ -50,6 +50,37 @@ SigKey signature(const ConvArgs& a, int act_pair) {
 std::mutex g_mu;
 std::map<SigKey, ConvTactic> g_choice;  // process-wide: layer signature -> tactic in use
 
+// TRTX_TACTIC_CACHE=<file>: the choices outlive the process (TensorRT's ITimingCache, IBuilderConfig::setTimingCache): read once,
+// every new choice appended as one line of integers (28 signature words, 6 tactic words).  A layer found there is not timed again.
+void cache_load_locked() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* path = getenv("TRTX_TACTIC_CACHE");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    for (;;) {
+        SigKey k{};
+        int t[6];
+        bool ok = true;
+        for (int i = 0; i < 28 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
+        for (int i = 0; i < 6 && ok; ++i) ok = fscanf(f, "%d", &t[i]) == 1;
+        if (!ok) break;
+        g_choice[k] = ConvTactic{t[0], t[1], t[2], t[3], t[4], t[5]};
+    }
+    fclose(f);
+}
+void cache_append_locked(const SigKey& k, const ConvTactic& t) {
+    const char* path = getenv("TRTX_TACTIC_CACHE");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    for (int i = 0; i < 28; ++i) fprintf(f, "%d ", k.v[i]);
+    fprintf(f, "%d %d %d %d %d %d\n", t.bn, t.bk, t.bm, t.wsk, t.ws, t.r3);
+    fclose(f);
+}
+
 bool same(const ConvTactic& a, const ConvTactic& b) {
     return a.bn == b.bn && a.bk == b.bk && a.bm == b.bm && a.wsk == b.wsk && a.ws == b.ws && a.r3 == b.r3;
 }
@@ -107,6 +138,7 @@ int32_t tune_engine(trtx_engine* e) {
     bool all_known = true;
     {
         std::lock_guard<std::mutex> lock(g_mu);
+        cache_load_locked();
         for (const Item& it : items)
             if (!g_choice.count(it.key)) all_known = false;
     }
@@ -194,6 +226,7 @@ int32_t tune_engine(trtx_engine* e) {
             for (int i = 1; i < it.n; ++i)
                 if (it.best_ms[i] < it.best_ms[pick] && it.best_ms[i] < 0.99f * it.best_ms[0]) pick = i;
             g_choice[it.key] = it.cand[pick];
+            cache_append_locked(it.key, it.cand[pick]);
         }
         conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
         trtx_engine::TacticRecord rec;

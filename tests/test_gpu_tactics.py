@@ -68,3 +68,34 @@ def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu):
             assert not (r["tactic"].startswith("wsk") and not r["default"].startswith("wsk")), r
     finally:
         e.close()
+
+
+def test_tactic_cache_file_spares_a_second_process_the_timing(gpu, tmp_path):
+    """TRTX_TACTIC_CACHE (the ITimingCache analogue): the first process times and writes, the second reads and launches no
+    candidate at all (records carry no measured times) but runs the same kernels."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = tmp_path / "tactics.txt"
+    script = (
+        "import json, sys, os\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))\n"
+        "import torch\n"
+        "from tensorrtx_amd import engine\n"
+        "from util import synth_wts\n"
+        "path, _ = synth_wts('yolov8n')\n"
+        "e = engine.Engine(engine.build_plan('yolov8n', path, batch=4, h=224, w=224, fp16=1))\n"
+        "print(json.dumps(e.tactics()))\n"
+        "e.close()\n")
+    env = dict(os.environ, TRTX_TACTIC_CACHE=str(cache))
+    runs = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    first, second = runs
+    assert cache.exists() and len(cache.read_text().splitlines()) >= 10
+    assert all(r["default_us"] > 0 for r in first) and all(r["default_us"] < 0 and r["us"] < 0 for r in second)
+    assert [r["tactic"] for r in first] == [r["tactic"] for r in second]

@@ -15,6 +15,8 @@ bias = torch.zeros(cp, device=dev)
 x = torch.randn(32, hin, hin, cin, device=dev).half()
 ho = (hin + 2 * p - k) // s + 1
 y = torch.empty(32, ho, ho, cout, device=dev, dtype=torch.float16)
+if os.environ.get("TRTX_TACTIC"):  # "bn,bk,bm,wsk,ws,r3": pin the launch configuration (capi.conv2d_tactics lists them)
+    capi.conv_force_tactic(tuple(int(v) for v in os.environ["TRTX_TACTIC"].split(",")))
 for _ in range(5):
     capi.conv2d_nhwc_f16(x, wp, bias, cout, k, k, s, p, "silu", out=y)
 torch.cuda.synchronize()
