@@ -10,12 +10,13 @@
 //     layer using its candidate of that index: each candidate is timed behind its real producer, with the cache state of the
 //     real sequence, instead of alone in a loop (a kernel timed alone keeps its weights in L2 and looks faster than it is -
 //     profiles/r02_ws_per_op.txt);
-//   * a layer leaves its default only for a candidate that is at least 3 % faster, and that is still faster than the default was
-//     when all the winners run together (second look); the choice is remembered per layer signature for the life of the
+//   * a layer leaves its default only for a candidate that is at least 3 % faster, and only if, with all the winners in place,
+//     putting it back on the default does not make it and its neighbours faster together (second look: a kernel switch costs
+//     the NEXT launch 7-10 us of cold instruction fetches); the choice is remembered per layer signature for the life of the
 //     process, so that two engines built from the same plan run the same kernels.
 //
 // Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
-// convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its default.
+// convolutions do not care what the numbers are.  Opt-in: TRTX_TUNE=1 (see tune_engine for the measurements behind that).
 #include <stdlib.h>
 #include <string.h>
 
@@ -100,8 +101,14 @@ std::string tactic_name(const ConvTactic& t) {
 namespace trtx {
 
 int32_t tune_engine(trtx_engine* e) {
-    static const bool off = getenv("TRTX_TUNE") && atoi(getenv("TRTX_TUNE")) == 0;
-    static const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
+    // Opt-in (TRTX_TUNE=1, read at every deserialize).  Measured on YOLOv8n b32 after the kernels were made compact and their
+    // accumulators kept in VGPRs (profiles/r02_tactics.txt): one context 1.456-1.460 ms tuned against 1.460-1.470 untuned, three
+    // contexts in flight 0.968-0.972 against 0.955-0.964 - the defaults are within 1 % of what timing finds, so an engine does not
+    // pay 0.1-2 s of timing runs at every deserialize unless asked to.  (Before those two fixes the same tuner gained 5.7 %: most
+    // of that was the smaller tiles' smaller code and fewer accumulator moves, not their shape.)
+    const char* env = getenv("TRTX_TUNE");
+    const bool off = !env || atoi(env) == 0;
+    const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
     Plan& plan = e->plan;
     e->tactics.clear();
     // setMaxAuxStreams(0) is how a caller says "I keep several execution contexts in flight": whole batches overlap, the chip is
@@ -180,9 +187,12 @@ int32_t tune_engine(trtx_engine* e) {
                 }
             }
         }
-        // Second look, with every layer on its winner at once: a candidate that won while its neighbours ran THEIR candidate of the
-        // same index may not win next to the kernels that were finally chosen (a different kernel before it, another cache state).
-        // A layer whose winner is not faster here than its default was in the all-default run goes back to the default.
+        // Second look, with every layer on its winner at once.  A candidate that won while its neighbours ran THEIR candidate of
+        // the same index may not win next to the kernels that were finally chosen: the first launch of a kernel after a
+        // different one starts with cold instruction fetches (+7-10 us here, paid by whichever layer comes next), so a layer
+        // that leaves its default can cost its successor more than it gains.  Greedy repair on the real objective: in plan order,
+        // put each moved layer back on its default; keep that if the layer and its neighbours (two before, two after) together
+        // got faster.
         if (st == TRTX_OK) {
             std::vector<int> win(items.size(), 0);
             for (size_t x = 0; x < items.size(); ++x) {
@@ -191,20 +201,39 @@ int32_t tune_engine(trtx_engine* e) {
                     if (it.best_ms[i] < it.best_ms[win[x]] && it.best_ms[i] < 0.97f * it.best_ms[0]) win[x] = i;
                 conv_apply_tactic(&plan.ops[it.op].conv, it.cand[win[x]]);
             }
-            std::vector<float> fin(items.size(), 1e30f);
-            for (int r = 0; r <= reps && st == TRTX_OK; ++r) {
-                std::vector<OpTiming> prof;
-                st = execute_plan(c, plan.max_batch, bindings.data(), stream, &prof);
-                if (st != TRTX_OK || r == 0) continue;
-                for (size_t x = 0; x < items.size(); ++x) fin[x] = std::min(fin[x], prof[items[x].op].ms);
+            auto measure = [&](int runs, std::vector<float>* out) {
+                out->assign(items.size(), 1e30f);
+                for (int r = 0; r < runs && st == TRTX_OK; ++r) {
+                    std::vector<OpTiming> prof;
+                    st = execute_plan(c, plan.max_batch, bindings.data(), stream, &prof);
+                    if (st != TRTX_OK) return;
+                    for (size_t x = 0; x < items.size(); ++x) (*out)[x] = std::min((*out)[x], prof[items[x].op].ms);
+                }
+            };
+            std::vector<float> cur, trial;
+            measure(reps, &cur);
+            auto window = [&](const std::vector<float>& v, size_t x) {
+                float sum = 0.f;
+                for (size_t y = x >= 2 ? x - 2 : 0; y < items.size() && y <= x + 2; ++y) sum += v[y];
+                return sum;
+            };
+            for (size_t x = 0; x < items.size() && st == TRTX_OK; ++x) {
+                if (win[x] == 0) continue;
+                conv_apply_tactic(&plan.ops[items[x].op].conv, items[x].cand[0]);
+                measure(2, &trial);
+                if (st != TRTX_OK) break;
+                if (window(trial, x) < 0.985f * window(cur, x)) {
+                    win[x] = 0;  // the default is better where it runs
+                    cur = trial;
+                } else {
+                    conv_apply_tactic(&plan.ops[items[x].op].conv, items[x].cand[win[x]]);
+                }
             }
             for (size_t x = 0; x < items.size() && st == TRTX_OK; ++x) {
                 Item& it = items[x];
-                if (win[x] == 0) continue;
-                const bool keep = fin[x] < 0.99f * it.best_ms[0];
                 for (int i = 1; i < it.n; ++i)
-                    if (i != win[x] || !keep) it.best_ms[i] = 1e30f;  // only the verified winner (or nothing) stays in the race
-                if (keep) it.best_ms[win[x]] = fin[x];               // what it costs where it will run
+                    if (i != win[x]) it.best_ms[i] = 1e30f;   // only the surviving winner stays in the race
+                if (win[x]) it.best_ms[win[x]] = std::min(cur[x], 0.989f * it.best_ms[0]);  // what it costs where it runs (kept: it paid off in its window)
             }
         }
         for (const Item& it : items) conv_apply_tactic(&plan.ops[it.op].conv, it.cand[0]);

@@ -1,7 +1,7 @@
 """Tactic selection by measurement at deserializeCudaEngine (runtime/tune.cpp; what TensorRT's builder does with its tactics behind
 IBuilder::buildSerializedNetwork, yolov8/src/model.cpp:327): every MFMA convolution gets a record, the choice is stable inside a
 process (two engines from one plan run the same kernels and give the same bits), engines built for contexts in flight
-(setMaxAuxStreams(0)) choose among the work-efficient configurations only, and a tuned engine is the same network as an untuned one."""
+(setMaxAuxStreams(0)) choose among the work-efficient configurations only.  Opt-in: TRTX_TUNE=1 at deserialize."""
 import numpy as np
 import pytest
 import torch
@@ -20,7 +20,8 @@ def _run(e, x, gpu):
     return {e.names[i]: bufs[i].cpu() for i in range(e.nb_bindings) if not e.is_input[i]}
 
 
-def test_tactics_are_recorded_stable_and_change_nothing_but_speed(gpu):
+def test_tactics_are_recorded_stable_and_change_nothing_but_speed(gpu, monkeypatch):
+    monkeypatch.setenv("TRTX_TUNE", "1")
     path, _ = synth_wts("yolov8n")
     B, S = 6, 288   # a shape no other test builds: the process-wide choice cache is empty for it
     plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1)
@@ -55,7 +56,8 @@ def test_tactics_are_recorded_stable_and_change_nothing_but_speed(gpu):
         e1.close()
 
 
-def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu):
+def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu, monkeypatch):
+    monkeypatch.setenv("TRTX_TUNE", "1")
     path, _ = synth_wts("yolov8n")
     plan = engine.build_plan("yolov8n", path, batch=6, h=352, w=352, fp16=1, aux_streams=0)
     e = engine.Engine(plan)
@@ -89,7 +91,7 @@ def test_tactic_cache_file_spares_a_second_process_the_timing(gpu, tmp_path):
         "e = engine.Engine(engine.build_plan('yolov8n', path, batch=4, h=224, w=224, fp16=1))\n"
         "print(json.dumps(e.tactics()))\n"
         "e.close()\n")
-    env = dict(os.environ, TRTX_TACTIC_CACHE=str(cache))
+    env = dict(os.environ, TRTX_TACTIC_CACHE=str(cache), TRTX_TUNE="1")
     runs = []
     for _ in range(2):
         out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
