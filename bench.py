@@ -378,7 +378,7 @@ def main():
         return c_ms / prof_runs, t_ms / prof_runs, n, rows, tac, summary
 
     conv_ms, tot_ms, n_conv, rows, tac, tactic_summary = profile_convs(eng, slots[0].bindings(inputs[0]))
-    tactic_summary["what"] = ("in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp): opt-in, TRTX_TUNE=1 in the environment; off = every layer on its default configuration" +
+    tactic_summary["what"] = ("in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp); TRTX_TUNE=0 in the environment keeps every layer on its static default" +
                               ("; this engine was built with setMaxAuxStreams(0) = contexts in flight: it chooses among the work-efficient configurations only" if n_ctx > 1 else ""))
     single_prof = None
     if n_ctx > 1:

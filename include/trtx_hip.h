@@ -481,8 +481,7 @@ size_t trtx_engine_device_memory(const trtx_engine* e);
 /* Tactic selection (TensorRT's builder times several kernels per layer and keeps the fastest; buildSerializedNetwork,
  * yolov8/src/model.cpp:327).  Here it runs inside trtx_engine_deserialize: every MFMA convolution's exchangeable launch
  * configurations are timed in place, behind their real producers, and a layer leaves its default for one that is >= 3 % faster
- * (opt-in: TRTX_TUNE=1 in the environment at deserialize; without it every layer runs its default configuration and this
- * returns []; TRTX_TACTIC_CACHE=<file>: choices are read from / appended to that file, the ITimingCache
+ * (TRTX_TUNE=0 in the environment at deserialize: every layer keeps its static default and this returns []; TRTX_TACTIC_CACHE=<file>: choices are read from / appended to that file, the ITimingCache
  * analogue, so a later process does not time again).  Returns JSON [{op, name, tactic, default, us, default_us, candidates}, ...]; free with
  * trtx_string_free. */
 int32_t trtx_engine_tactics(const trtx_engine* e, char** json_out);

@@ -1044,7 +1044,7 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
         const int bn = bns[bi];
         if (a.Cout_pad % bn) continue;
         if (bn == 16 && a.Cout_pad > 32 && bn != a.bn) continue;  // 16-wide tiles re-read the A tile Cout/16 times: only for tiny Cout
-        if (work_efficient_only && bn != a.bn) continue;
+        if (work_efficient_only && bn != a.bn && bn != 64) continue;  // 64-wide tiles stay: they let a whole network share one kernel
         for (int ki = 0; ki < 2; ++ki) {
             ConvArgs t = a;
             t.bn = bn;

@@ -6,7 +6,10 @@
 //     width, 64- / 128- / 256-row tiles, 32- or 64-wide k-steps, the wave-split-K, the weight-stationary and the 3x3 row-reuse
 //     kernel where they apply);
 //     they share the layer's packed weights, so nothing is re-packed;
-//   * the WHOLE plan is run in place (profile mode: one stream, HIP events around every op) once per candidate index, every
+//   * first a few whole-network "palettes" (every layer that can takes the same tile shape) are timed against the static
+//     defaults: launches of different kernels back to back are expensive here, and only a whole-network move reaches a
+//     configuration where long runs of layers share one kernel; the fastest becomes the baseline;
+//   * then the WHOLE plan is run in place (profile mode: one stream, HIP events around every op) once per candidate index, every
 //     layer using its candidate of that index: each candidate is timed behind its real producer, with the cache state of the
 //     real sequence, instead of alone in a loop (a kernel timed alone keeps its weights in L2 and looks faster than it is -
 //     profiles/r02_ws_per_op.txt);
@@ -16,7 +19,7 @@
 //     process, so that two engines built from the same plan run the same kernels.
 //
 // Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
-// convolutions do not care what the numbers are.  Opt-in: TRTX_TUNE=1 (see tune_engine for the measurements behind that).
+// convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its static default.
 #include <stdlib.h>
 #include <string.h>
 
@@ -101,13 +104,11 @@ std::string tactic_name(const ConvTactic& t) {
 namespace trtx {
 
 int32_t tune_engine(trtx_engine* e) {
-    // Opt-in (TRTX_TUNE=1, read at every deserialize).  Measured on YOLOv8n b32 after the kernels were made compact and their
-    // accumulators kept in VGPRs (profiles/r02_tactics.txt): one context 1.456-1.460 ms tuned against 1.460-1.470 untuned, three
-    // contexts in flight 0.968-0.972 against 0.955-0.964 - the defaults are within 1 % of what timing finds, so an engine does not
-    // pay 0.1-2 s of timing runs at every deserialize unless asked to.  (Before those two fixes the same tuner gained 5.7 %: most
-    // of that was the smaller tiles' smaller code and fewer accumulator moves, not their shape.)
+    // On by default; TRTX_TUNE=0 (read at every deserialize) keeps every layer on its static default.  Measured on YOLOv8n b32
+    // (profiles/r02_tactics.txt, same box, alternating runs): one context 1.309-1.310 ms against 1.413-1.421 untuned (conv launches
+    // 19.9 against 21.6 us); three contexts in flight 0.936-0.945 against 0.945-0.950 ms.  Costs 0.1-2 s per deserialize.
     const char* env = getenv("TRTX_TUNE");
-    const bool off = !env || atoi(env) == 0;
+    const bool off = env && atoi(env) == 0;
     const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
     Plan& plan = e->plan;
     e->tactics.clear();
@@ -175,6 +176,58 @@ int32_t tune_engine(trtx_engine* e) {
         }
         if (st == TRTX_OK && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) st = TRTX_ERR_HIP;
         const int reps = 3;
+        // Phase 0, the starting point.  Consecutive launches of DIFFERENT kernels are expensive here (cold instruction fetches:
+        // +7-10 us on the launch after a switch, ~25 switches in a YOLOv8n step), and no sequence of single-layer moves gets
+        // from the static defaults (widest column tile per layer: 3-4 kernels interleaved) to a configuration where long runs
+        // of layers share ONE kernel.  So a few whole-network "palettes" are timed first - every layer that can takes the same
+        // tile shape - and the fastest whole step becomes the baseline the per-layer search starts from.
+        if (st == TRTX_OK) {
+            struct Palette { int bn, bm, bk; };
+            // (engines for contexts in flight have no 64-row candidates: only the first two palettes can apply to them)
+            static const Palette palettes[] = {{64, 128, 32}, {64, 128, 64}, {64, 64, 32}, {64, 64, 64}, {128, 64, 32}, {32, 128, 32}};
+            auto total = [&](float* out) {
+                float best = 1e30f;
+                for (int r = 0; r <= reps && st == TRTX_OK; ++r) {
+                    std::vector<OpTiming> prof;
+                    st = execute_plan(c, plan.max_batch, bindings.data(), stream, &prof);
+                    if (st != TRTX_OK || r == 0) continue;
+                    float sum = 0.f;
+                    for (const Item& it : items) sum += prof[it.op].ms;
+                    best = std::min(best, sum);
+                }
+                *out = best;
+            };
+            float base = 0.f;
+            total(&base);
+            int best_p = -1;
+            float best_t = 0.98f * base;
+            for (int pi = 0; pi < (int)(sizeof(palettes) / sizeof(palettes[0])) && st == TRTX_OK; ++pi) {
+                const Palette& P = palettes[pi];
+                int hits = 0;
+                for (const Item& it : items) {
+                    int pick = 0;
+                    for (int i = 1; i < it.n; ++i)
+                        if (it.cand[i].bn == P.bn && it.cand[i].bm == P.bm && it.cand[i].bk == P.bk && it.cand[i].wsk == 1 && it.cand[i].ws == 1 && !it.cand[i].r3) pick = i;
+                    hits += pick != 0;
+                    conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
+                }
+                if (hits < 4) continue;
+                float t = 0.f;
+                total(&t);
+                if (verbose) fprintf(stderr, "[trtx_hip] palette %dx%dx%d on %d layers: %.1f us (static defaults %.1f us)\n", P.bm, P.bn, P.bk, hits, t * 1e3f, base * 1e3f);
+                if (st == TRTX_OK && t < best_t) {
+                    best_t = t;
+                    best_p = pi;
+                }
+            }
+            if (best_p >= 0) {  // the palette's tactic becomes entry 0 (the baseline) of every layer that has it
+                const Palette& P = palettes[best_p];
+                for (Item& it : items)
+                    for (int i = 1; i < it.n; ++i)
+                        if (it.cand[i].bn == P.bn && it.cand[i].bm == P.bm && it.cand[i].bk == P.bk && it.cand[i].wsk == 1 && it.cand[i].ws == 1 && !it.cand[i].r3)
+                            std::swap(it.cand[0], it.cand[i]);
+            }
+        }
         for (int p = 0; p < passes && st == TRTX_OK; ++p) {
             for (const Item& it : items) conv_apply_tactic(&plan.ops[it.op].conv, it.cand[p < it.n ? p : 0]);
             for (int r = 0; r <= reps && st == TRTX_OK; ++r) {  // r == 0: untimed (first launch of a kernel loads its code object)

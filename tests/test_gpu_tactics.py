@@ -1,7 +1,7 @@
 """Tactic selection by measurement at deserializeCudaEngine (runtime/tune.cpp; what TensorRT's builder does with its tactics behind
 IBuilder::buildSerializedNetwork, yolov8/src/model.cpp:327): every MFMA convolution gets a record, the choice is stable inside a
 process (two engines from one plan run the same kernels and give the same bits), engines built for contexts in flight
-(setMaxAuxStreams(0)) choose among the work-efficient configurations only.  Opt-in: TRTX_TUNE=1 at deserialize."""
+(setMaxAuxStreams(0)) choose among the work-efficient configurations only.  TRTX_TUNE=0 at deserialize switches it off."""
 import numpy as np
 import pytest
 import torch
@@ -66,7 +66,7 @@ def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu, monke
             if r["tactic"].startswith("igemm") and r["default"].startswith("igemm"):
                 rows, cols, _ = (int(v) for v in r["tactic"].split()[1].split("x"))
                 _, dcols, _ = (int(v) for v in r["default"].split()[1].split("x"))
-                assert rows >= 128 and cols == dcols, r   # no 64-row tiles, no narrower column tiles
+                assert rows >= 128 and cols in (dcols, 64), r   # no 64-row tiles; column tiles: the default or the shared 64-wide one
             assert not (r["tactic"].startswith("wsk") and not r["default"].startswith("wsk")), r
     finally:
         e.close()

@@ -2,14 +2,17 @@
 # Round-2 final evidence (after tactic tuning, compact epilogues, contexts in flight): bench lines for every BASELINE config,
 # rocprofv3 kernel stats of the same commands, PMC HBM traffic of the conv kernels, SQ counters of the 64->64 3x3 80x80 layer.
 export TMPDIR=/tmp
+# tactic timing is on by default; the runs marked "untuned" set TRTX_TUNE=0 (static default launch configurations)
 # one tactic cache for every process of this script: the bench runs time the layers once, the rocprofv3 runs then see only the
 # real launches (no candidate timing runs inside their kernel statistics)
 export TRTX_TACTIC_CACHE=/tmp/trtx_tactics.txt
 R=$GRAFT_REPO_ROOT
 E=$R/gpurun_out/evidence_r02b
 mkdir -p $E
-timeout 400 python bench.py --dump-ops $E/ops_c3.json > $E/bench_c3.log 2>&1; tail -1 $E/bench_c3.log | cut -c1-200
+TRTX_TUNE_VERBOSE=1 timeout 400 python bench.py --dump-ops $E/ops_c3.json > $E/bench_c3.log 2> $E/bench_c3.err; tail -1 $E/bench_c3.log | cut -c1-200
 timeout 300 python bench.py --contexts 1 --no-cpu-baseline --dump-ops $E/ops_c3_1ctx.json > $E/bench_c3_1ctx.log 2>&1; tail -1 $E/bench_c3_1ctx.log | cut -c1-200
+TRTX_TUNE=0 timeout 300 python bench.py --contexts 1 --no-cpu-baseline --dump-ops $E/ops_c3_1ctx_untuned.json > $E/bench_c3_1ctx_untuned.log 2>&1; tail -1 $E/bench_c3_1ctx_untuned.log | cut -c1-200
+TRTX_TUNE=0 timeout 300 python bench.py --no-cpu-baseline > $E/bench_c3_untuned.log 2>&1; tail -1 $E/bench_c3_untuned.log | cut -c1-200
 for cfg in resnet50 retinaface_r50 rcnn_r50c4; do
   timeout 400 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_$cfg.log 2>&1; tail -1 $E/bench_$cfg.log | cut -c1-200
 done
@@ -39,8 +42,7 @@ for r in csv.DictReader(open(f)):
     key = (r["Dispatch_Id"], fam)
     if key not in seen:
         seen.add(key); n[fam] += 1
-lines = ["# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -- python bench.py --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline (round 2, final build;",
-         "# tactics come from the cache written by the bench runs before it: no timing runs inside)",
+lines = ["# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -- python bench.py --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline (round 2, final build)",
          "# bytes = (2 x RDREQ + WRREQ) x 64 B  (reads doubled: gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section)"]
 res = {}
 for fam, d in per.items():
