@@ -235,7 +235,7 @@ int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, int Cin, in
                                 trtx_stream_t stream);
 /* Tactics of that launch (tests / tools): the exchangeable launch configurations of the layer trtx_op_conv2d_nhwc_f16 would
  * run, 6 ints each {column-tile width, k-step width, rows per tile, wave-split-K (1 off / 2 on), weight-stationary (1 off / 2 on),
- * 3x3 row-reuse kernel (0 / 1)}; entry 0 is the default.  Returns the count (<= max_out).  trtx_op_conv_force_tactic pins the configuration used by the following
+ * 3x3 row-reuse kernel (0 no / 1 three LDS stages / 2 two)}; entry 0 is the default.  Returns the count (<= max_out).  trtx_op_conv_force_tactic pins the configuration used by the following
  * trtx_op_conv2d_nhwc_f16 calls of this process (NULL: back to the default). */
 int32_t trtx_op_conv2d_tactics(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
                                int has_residual, int ld_res, int32_t* out6, int32_t max_out);

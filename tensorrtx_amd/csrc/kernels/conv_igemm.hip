@@ -478,7 +478,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 // away (2 / Wp of the work).  A traffic through L1 -> LDS drops 3x; the weights of the three taps arrive as three B tiles per
 // step.  Same packed weights, so it is one more exchangeable tactic (ConvArgs::t_r3); K is walked (filter row, channel slice,
 // tap) instead of (tap, channel slice), so fp16 results may differ from the kernel above in the last place.
-template <int NFRAG, int BKT, int MI>
+// NSTAGES: LDS pipeline depth.  A step here carries three taps of MFMA work, so two stages already hide what three hide in the
+// kernel above - and 40 KB instead of 60 KB of LDS (64-wide column tile) lets four workgroups share a CU instead of two
+// (SQ counters of the 64 -> 64 3x3 80x80 layer, profiles/r02_sq_counters_64x64_3x3_80.txt: at two workgroups per CU this kernel
+// already matches the kernel above at four, with half the wave-cycles and a third of the wait cycles).
+template <int NFRAG, int BKT, int MI, int NSTAGES>
 __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int total_tiles,
                                                                 int xcd_chunk) {
     constexpr int BN = 16 * NFRAG;
@@ -496,7 +500,8 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
     constexpr int STAGE_BYTES = A_BYTES + 3 * BT_BYTES;
     constexpr int LOADS_PER_TILE = A_LOADS + 3 * B_PASSES;
     constexpr int KSUB = BKT / 32;
-    constexpr int NST = BKT == 64 ? 2 : 3;
+    constexpr int NST = NSTAGES;
+    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
 
     const int tid = threadIdx.x;
@@ -960,15 +965,15 @@ bool r3_possible(const ConvArgs& a) {
            (a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) && (a.bm == 0 || a.bm == 128) && (a.bk == 32 || a.CinK % 64 == 0) &&
            (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
 }
-template <int BKT>
+template <int BKT, int NSTAGES>
 int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
     const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
     switch (a.bn) {
-        case 32: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<2, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 64: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<4, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 80: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<5, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 128: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<8, BKT, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 32: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<2, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 64: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<4, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 80: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<5, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 128: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<8, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return TRTX_OK;
@@ -1054,7 +1059,10 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
             if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
-            if (r3_possible(t)) push(bn, t.bk, 128, 1, 1, 1);
+            if (r3_possible(t)) {
+                push(bn, t.bk, 128, 1, 1, t.bk == 64 ? 2 : 1);   // 64-wide k-steps: always two LDS stages
+                if (t.bk == 32) push(bn, t.bk, 128, 1, 1, 2);    // 32-wide: three stages or two (more workgroups per CU)
+            }
         }
     }
     return n;
@@ -1094,8 +1102,9 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
-        } else if (a.t_r3 == 1 && r3_possible(a)) {
-            st = a.bk == 64 ? launch_r3<64>(a, in_bytes, w_bytes, s) : launch_r3<32>(a, in_bytes, w_bytes, s);
+        } else if (a.t_r3 != 0 && r3_possible(a)) {
+            st = a.bk == 64 ? launch_r3<64, 2>(a, in_bytes, w_bytes, s)
+                            : (a.t_r3 == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);

@@ -45,7 +45,7 @@ struct ConvArgs {
     int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
     int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported)
-    int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel): 0 = no, 1 = yes (only where it exists)
+    int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two
 };
 
 // One launch configuration of an implicit-GEMM layer.  All tactics of a layer share its packed weights (Cout_pad, CinK, Kpad), so

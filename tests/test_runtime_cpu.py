@@ -404,7 +404,7 @@ def test_conv_tactics_are_enumerated_on_the_host():
     t = capi.conv2d_tactics(32, 20, 20, 128, 128, 3, 1, 1)
     assert t[0] == (128, 32, 128, 1, 1, 0) and len(set(t)) == len(t) >= 8
     assert (64, 32, 128, 2, 1, 0) in t and (64, 64, 64, 1, 1, 0) in t    # wave-split-K on 64-wide tiles; 64-row tiles with 64-wide k-steps
-    assert (128, 32, 128, 1, 1, 1) in t and (64, 64, 128, 1, 1, 1) in t  # the 3x3 row-reuse kernel, both k-step widths
+    assert (128, 32, 128, 1, 1, 1) in t and (128, 32, 128, 1, 1, 2) in t and (64, 64, 128, 1, 1, 2) in t  # the 3x3 row-reuse kernel: 3 / 2 LDS stages, 64-wide k-steps
     assert all(128 % bn == 0 and bk in (32, 64) and bm in (64, 128) for bn, bk, bm, _, _, _ in t)
     t = capi.conv2d_tactics(32, 80, 80, 32, 32, 3, 1, 1)                  # weight-stationary kernel is the default where it applies
     assert t[0][4] == 2 and all(x[4] == 1 for x in t[1:]) and all(x[1] == 32 for x in t)
