@@ -66,8 +66,10 @@ def test_engines_for_contexts_in_flight_choose_work_efficient_tactics(gpu, monke
             if r["tactic"].startswith("igemm") and r["default"].startswith("igemm"):
                 rows, cols, _ = (int(v) for v in r["tactic"].split()[1].split("x"))
                 _, dcols, _ = (int(v) for v in r["default"].split()[1].split("x"))
-                assert rows >= 128 and cols in (dcols, 64), r   # no 64-row tiles; column tiles: the default or the shared 64-wide one
-            assert not (r["tactic"].startswith("wsk") and not r["default"].startswith("wsk")), r
+                # no 64-row tiles; column tiles: the default or the shared 64-wide one.  ("default" is the baseline the search started
+                # from - the static default or the winning whole-network palette; a layer whose static default is the
+                # wave-split-K kernel may come back to it.)
+                assert rows >= 128 and (cols == dcols or 64 in (cols, dcols)), r
     finally:
         e.close()
 
