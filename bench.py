@@ -53,6 +53,27 @@ def _traffic_from_profile(model):
         return None, None
 
 
+def _kernel_duration_from_profile(model):
+    """Mean duration of the fused MFMA conv launches as rocprofv3 --kernel-trace --stats saw them (dispatch begin -> end) in the
+    committed single-context, single-lane profile of this same command; bench.py's own figure brackets every op with HIP events
+    on the stream and therefore also contains the event hand-over between two launches (a few us per op)."""
+    import re
+    name = {"yolov8n": "r02_kernel_stats_c3_1ctx_lanes1.txt"}.get(model)
+    if not name:
+        return None, None
+    try:
+        calls, tot = 0, 0.0
+        for line in open(os.path.join(ROOT, "profiles", name)):
+            if "conv_igemm" in line or "conv_ws" in line:
+                m = re.search(r"\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+                if m:
+                    calls += int(m.group(1))
+                    tot += float(m.group(5))
+        return (tot * 1e3 / calls, "profiles/" + name) if calls else (None, None)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0):
     """The oracle (PyTorch-CPU fp32 restatement of the reference graph + C decode/NMS) timed on the host cores on a bounded
     sample of the same workload: reported next to the GPU number, never the thing measured.  The same oracle outputs are
@@ -413,12 +434,15 @@ def main():
     intensity = flop_per_step / max(alg_bytes, 1.0)
     bound = "hbm" if intensity < MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS else "mfma"
     traffic, traffic_src = _traffic_from_profile(args.config)
+    prof_us, prof_src = _kernel_duration_from_profile(args.config) if args.precision == "fp16" else (None, None)
     roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_ws_f16 / conv_igemm_f16 / conv_igemm_wsk_f16, all instantiations)",
                 "launches_per_step": n_conv, "avg_launch_us": avg_launch_s * 1e6,
                 "achieved": achieved_gbps if bound == "hbm" else achieved_tflops, "peak": HBM_PEAK_GBPS if bound == "hbm" else MFMA_PEAK_TFLOPS,
                 "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                 "frac": (achieved_gbps / HBM_PEAK_GBPS) if bound == "hbm" else (achieved_tflops / MFMA_PEAK_TFLOPS),
                 "traffic": traffic, "traffic_source": traffic_src,
+                "rocprofv3_avg_launch_us": prof_us, "rocprofv3_frac_hbm": (alg_bytes / max(n_conv, 1) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if prof_us else None,
+                "rocprofv3_source": prof_src,
                 "arithmetic_intensity_flop_per_byte": intensity,
                 "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms, "hbm_view": hbm_view, "mfma_view": mfma_view,
                 "tactics": tactic_summary,
