@@ -30,6 +30,7 @@
 
 #include "../common.h"
 #include "kernels.h"
+#include "launch.h"
 
 #ifndef TRTX_STAMP
 #define TRTX_STAMP(i, kt)
@@ -908,7 +909,7 @@ void launch_wsk(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStrea
     const int tiles_m = (a.M + 63) / 64, tiles_n = a.Cout_pad / BN;
     const int total = tiles_m * tiles_n;
     const int chunk = (total + 7) / 8;
-    hipLaunchKernelGGL((conv_igemm_wsk_f16_kernel<NFRAG>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total,
+    TRTX_LAUNCH((conv_igemm_wsk_f16_kernel<NFRAG>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total,
                        chunk);
 }
 
@@ -920,7 +921,7 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
     const int chunk = plain ? 0 : (total + 7) / 8;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
+    TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
                        w_bytes, tiles_n, total, chunk, dbg);
 }
 
@@ -970,10 +971,10 @@ int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStr
     const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
     const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
     switch (a.bn) {
-        case 32: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<2, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 64: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<4, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 80: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<5, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 128: hipLaunchKernelGGL((conv_igemm_r3_f16_kernel<8, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 32: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<2, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 64: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<4, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 80: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<5, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
+        case 128: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<8, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return TRTX_OK;
@@ -984,6 +985,10 @@ bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 bool bm256_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16 && (a.bn == 32 || a.bn == 64 || a.bn == 80); }
 
 }  // namespace
+
+static thread_local LaunchProbe* g_launch_probe = nullptr;
+void conv_set_launch_probe(LaunchProbe* p) { g_launch_probe = p; }
+LaunchProbe* conv_launch_probe() { return g_launch_probe; }
 
 int conv_igemm_pick_bn(int cout) {
     // widest tile that divides the padded Cout without waste

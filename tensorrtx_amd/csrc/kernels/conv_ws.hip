@@ -32,6 +32,7 @@
 
 #include "../common.h"
 #include "kernels.h"
+#include "launch.h"
 
 namespace trtx {
 namespace {
@@ -437,7 +438,7 @@ int32_t launch_ws(const ConvArgs& a, const WsGeom& g, unsigned in_bytes, hipStre
     static const int dbg = getenv("TRTX_WS_DBG") ? atoi(getenv("TRTX_WS_DBG")) : 0;
     gg.dbg = dbg;
     gg.grid = (std::min(g.total_tiles, 256 * occ) + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(gg.grid), dim3(256), lds, s, a, gg, in_bytes);
+    TRTX_LAUNCH(kern, dim3(gg.grid), dim3(256), lds, s, a, gg, in_bytes);
     return TRTX_OK;
 }
 

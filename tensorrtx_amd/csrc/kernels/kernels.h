@@ -57,6 +57,16 @@ struct ConvTactic {
     int r3;          // value of ConvArgs::t_r3
 };
 
+// Launch probe (IProfiler-style per-layer timing): while one is set for the calling thread, the first MFMA / stem convolution
+// launch records the DISPATCH's own begin and end timestamps into its events (hipExtLaunchKernelGGL) - the kernel's duration as
+// rocprofv3 sees it, without the hand-over between two stream events that bracketing a launch with hipEventRecord includes.
+struct LaunchProbe {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int launches = 0;
+};
+void conv_set_launch_probe(LaunchProbe* p);  // nullptr: off
+LaunchProbe* conv_launch_probe();
+
 // --- conv -------------------------------------------------------------------------------------------
 // fused implicit-GEMM conv on MFMA (conv_igemm.hip): LDS-DMA operands, range-checked gather, 3-stage pipeline
 int conv_igemm_pick_bn(int cout);   // column-tile width for a Cout

@@ -93,11 +93,26 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
     Resolver R{plan, static_cast<char*>(c->d_arena), static_cast<char*>(e->d_weights), bindings};
     char* W = static_cast<char*>(e->d_weights);
     std::vector<hipEvent_t> evs;
+    std::vector<LaunchProbe> probes;  // profiling: per convolution, the dispatch's own begin / end timestamps
+    static const bool no_probe = getenv("TRTX_PROFILE_NO_KERNEL_EVENTS") != nullptr;
     if (prof) {
         evs.resize(plan.ops.size() + 1);
         for (auto& ev : evs) TRTX_HIP_TRY(hipEventCreate(&ev));
+        probes.resize(plan.ops.size());
+        if (!no_probe && !c->tuning)  // the tactic timing keeps its own clock (the interval between the stream events)
+            for (size_t k = 0; k < plan.ops.size(); ++k)
+                if (plan.ops[k].kind == OP_CONV && plan.ops[k].igemm)
+                    if (hipEventCreate(&probes[k].start) != hipSuccess || hipEventCreate(&probes[k].stop) != hipSuccess) (void)hipGetLastError();
         TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
     }
+    auto free_probes = [&]() {
+        conv_set_launch_probe(nullptr);
+        for (auto& pr : probes) {
+            if (pr.start) (void)hipEventDestroy(pr.start);
+            if (pr.stop) (void)hipEventDestroy(pr.stop);
+        }
+        probes.clear();
+    };
     // lanes: independent branches of the plan run on the context's own streams, fenced by events (profiling runs
     // everything on the caller's stream so that the per-op events measure isolated kernels)
     hipStream_t const user_stream = stream;
@@ -138,9 +153,11 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     st = deconv_direct(a, op.dtype, stream);
                 else if (op.stem)
                     st = conv_stem_nchw_f32(a, stream);
-                else if (op.igemm)
+                else if (op.igemm) {
+                    if (prof && probes[k].start && probes[k].stop) conv_set_launch_probe(&probes[k]);
                     st = conv_igemm_f16(a, stream);
-                else
+                    conv_set_launch_probe(nullptr);
+                } else
                     st = conv_direct(a, op.dtype, stream);
                 break;
             }
@@ -310,6 +327,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     if (lane_started[l] && hipEventRecord(c->lane_done[l], c->lane_stream[l]) == hipSuccess)
                         (void)hipStreamWaitEvent(user_stream, c->lane_done[l], 0);
             for (auto& ev : evs) (void)hipEventDestroy(ev);
+            free_probes();
             return st;
         }
         if (c->observer) {  // INT8 calibration: |x| maximum or histogram of every fp16 NHWC tensor this op wrote, per owning storage
@@ -339,9 +357,16 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         for (size_t k = 0; k < plan.ops.size(); ++k) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, evs[k], evs[k + 1]);
-            prof->push_back({plan.ops[k].name, op_kind_name(plan.ops[k].kind), ms});
+            OpTiming t{plan.ops[k].name, op_kind_name(plan.ops[k].kind), ms};
+            if (probes[k].launches == 1 && probes[k].start && probes[k].stop) {
+                float kms = -1.f;
+                if (hipEventElapsedTime(&kms, probes[k].start, probes[k].stop) == hipSuccess && kms > 0.f) t.kernel_ms = kms;
+                else (void)hipGetLastError();
+            }
+            prof->push_back(t);
         }
         for (auto& ev : evs) (void)hipEventDestroy(ev);
+        free_probes();
     }
     return TRTX_OK;
 }
@@ -632,7 +657,7 @@ extern "C" int32_t trtx_context_profile(trtx_context* c, int32_t batch, void* co
     for (size_t k = 0; k < prof.size(); ++k) {
         o << (k ? "," : "") << "{\"name\":\"";
         for (char ch : prof[k].name) o << ((ch == '"' || ch == '\\' || (unsigned char)ch < 0x20) ? ' ' : ch);
-        o << "\",\"kind\":\"" << prof[k].kind << "\",\"ms\":" << prof[k].ms << "}";
+        o << "\",\"kind\":\"" << prof[k].kind << "\",\"ms\":" << prof[k].ms << ",\"kernel_ms\":" << prof[k].kernel_ms << "}";
     }
     o << "]";
     *json_out = strdup(o.str().c_str());

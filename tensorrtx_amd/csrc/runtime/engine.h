@@ -62,7 +62,8 @@ namespace trtx {
 // runs every op of the plan on `stream`; with `prof` != nullptr brackets each op with hipEvents
 struct OpTiming {
     std::string name, kind;
-    float ms;
+    float ms;                // between the stream events before and after the op (includes the hand-over between two launches)
+    float kernel_ms = -1.f;  // convolutions: the dispatch's own begin -> end (LaunchProbe, kernels.h); -1 where not measured
 };
 int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStream_t stream,
                      std::vector<OpTiming>* prof);
