@@ -3,10 +3,13 @@
 
 Default workload (config C3, BASELINE configs[2]): YOLOv8n fp16, 640x640, batch 32 per GPU: one "step" = one pass of
 the hot path over one batch of synthetic images already resident in HBM = IExecutionContext::enqueue (fused MFMA
-convolutions + pools/resizes + DFL tail + YoloLayer decode) followed by the GPU NMS.  Independent image streams are
+convolutions + pools/resizes + DFL tail + YoloLayer decode) followed by the GPU NMS.  K steps are K full batch-32 passes; they are
+issued round-robin through --contexts execution contexts of one engine (ICudaEngine::createExecutionContext, one HIP stream each),
+so batches overlap on the chip; the same K steps through a single context are timed too and printed as `single_context`.  Independent image streams are
 sharded over the ranks (one process per GPU, one engine replica each, no data-path collective).
 
-  python bench.py                                  1 GPU, C3, weak scaling unit
+  python bench.py                                  1 GPU, C3, weak scaling unit; 3 execution contexts in flight (one stream each)
+  python bench.py --contexts 1                     the reference's loop shape: one context, batches strictly in sequence
   python bench.py --gpus 8                         spawns 8 ranks itself (torch.distributed.run, RCCL barrier/all-reduce for timing)
   python -m torch.distributed.run ... bench.py --gpus 8     (how the driver launches it; same code path)
   python bench.py --gpus 8 --mode strong           global batch fixed at 32 -> 4 images per GPU
