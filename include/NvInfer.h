@@ -111,13 +111,13 @@ class Weights {
 class ILogger {
    public:
     enum class Severity : int32_t { kINTERNAL_ERROR = 0, kERROR = 1, kWARNING = 2, kINFO = 3, kVERBOSE = 4 };
-    virtual void log(Severity severity, const char* msg) noexcept = 0;
+    virtual void log(Severity severity, const char* msg) = 0;
     virtual ~ILogger() = default;
 };
 
 class IProfiler {
    public:
-    virtual void reportLayerTime(const char* layerName, float ms) noexcept = 0;
+    virtual void reportLayerTime(const char* layerName, float ms) = 0;
     virtual ~IProfiler() = default;
 };
 
@@ -126,20 +126,20 @@ class IProfiler {
 enum class CalibrationAlgoType : int32_t { kLEGACY_CALIBRATION = 0, kENTROPY_CALIBRATION = 1, kENTROPY_CALIBRATION_2 = 2, kMINMAX_CALIBRATION = 3 };
 class IInt8Calibrator {
    public:
-    virtual int32_t getBatchSize() const noexcept = 0;
-    virtual bool getBatch(void* bindings[], const char* names[], int32_t nbBindings) noexcept = 0;
-    virtual const void* readCalibrationCache(size_t& length) noexcept = 0;
-    virtual void writeCalibrationCache(const void* ptr, size_t length) noexcept = 0;
-    virtual CalibrationAlgoType getAlgorithm() noexcept = 0;
+    virtual int32_t getBatchSize() const = 0;
+    virtual bool getBatch(void* bindings[], const char* names[], int32_t nbBindings) = 0;
+    virtual const void* readCalibrationCache(size_t& length) = 0;
+    virtual void writeCalibrationCache(const void* ptr, size_t length) = 0;
+    virtual CalibrationAlgoType getAlgorithm() = 0;
     virtual ~IInt8Calibrator() = default;
 };
 class IInt8EntropyCalibrator2 : public IInt8Calibrator {
    public:
-    CalibrationAlgoType getAlgorithm() noexcept override { return CalibrationAlgoType::kENTROPY_CALIBRATION_2; }
+    CalibrationAlgoType getAlgorithm() override { return CalibrationAlgoType::kENTROPY_CALIBRATION_2; }
 };
 class IInt8EntropyCalibrator : public IInt8Calibrator {
    public:
-    CalibrationAlgoType getAlgorithm() noexcept override { return CalibrationAlgoType::kENTROPY_CALIBRATION; }
+    CalibrationAlgoType getAlgorithm() override { return CalibrationAlgoType::kENTROPY_CALIBRATION; }
 };
 class IGpuAllocator;
 
@@ -337,59 +337,59 @@ struct PluginFieldCollection {
 class IPluginV2 {
    public:
     virtual ~IPluginV2() = default;
-    virtual int32_t getNbOutputs() const noexcept = 0;
-    virtual Dims getOutputDimensions(int32_t index, const Dims* inputs, int32_t nbInputDims) noexcept = 0;
-    virtual int32_t initialize() noexcept = 0;
-    virtual void terminate() noexcept = 0;
-    virtual size_t getWorkspaceSize(int32_t maxBatchSize) const noexcept = 0;
+    virtual int32_t getNbOutputs() const = 0;
+    virtual Dims getOutputDimensions(int32_t index, const Dims* inputs, int32_t nbInputDims) = 0;
+    virtual int32_t initialize() = 0;
+    virtual void terminate() = 0;
+    virtual size_t getWorkspaceSize(int32_t maxBatchSize) const = 0;
     virtual int32_t enqueue(int32_t batchSize, const void* const* inputs, void* const* outputs, void* workspace,
-                            hipStream_t stream) noexcept = 0;
-    virtual size_t getSerializationSize() const noexcept = 0;
-    virtual void serialize(void* buffer) const noexcept = 0;
-    virtual const char* getPluginType() const noexcept = 0;
-    virtual const char* getPluginVersion() const noexcept = 0;
-    virtual void destroy() noexcept = 0;
-    virtual IPluginV2* clone() const noexcept = 0;
-    virtual void setPluginNamespace(const char* ns) noexcept = 0;
-    virtual const char* getPluginNamespace() const noexcept = 0;
+                            hipStream_t stream) = 0;
+    virtual size_t getSerializationSize() const = 0;
+    virtual void serialize(void* buffer) const = 0;
+    virtual const char* getPluginType() const = 0;
+    virtual const char* getPluginVersion() const = 0;
+    virtual void destroy() = 0;
+    virtual IPluginV2* clone() const = 0;
+    virtual void setPluginNamespace(const char* ns) = 0;
+    virtual const char* getPluginNamespace() const = 0;
     // TRT <= 7 only; default keeps old-style plugins compiling
-    virtual bool supportsFormat(DataType type, PluginFormat format) const noexcept {
+    virtual bool supportsFormat(DataType type, PluginFormat format) const {
         return type == DataType::kFLOAT && format == PluginFormat::kLINEAR;
     }
 };
 
 class IPluginV2Ext : public IPluginV2 {
    public:
-    virtual DataType getOutputDataType(int32_t index, const DataType* inputTypes, int32_t nbInputs) const noexcept = 0;
-    virtual bool isOutputBroadcastAcrossBatch(int32_t outputIndex, const bool* inputIsBroadcasted, int32_t nbInputs) const noexcept = 0;
-    virtual bool canBroadcastInputAcrossBatch(int32_t inputIndex) const noexcept = 0;
+    virtual DataType getOutputDataType(int32_t index, const DataType* inputTypes, int32_t nbInputs) const = 0;
+    virtual bool isOutputBroadcastAcrossBatch(int32_t outputIndex, const bool* inputIsBroadcasted, int32_t nbInputs) const = 0;
+    virtual bool canBroadcastInputAcrossBatch(int32_t inputIndex) const = 0;
     // the 10-argument form the R-CNN plugins learn their shapes from (rcnn/RpnDecodePlugin.h:158-171)
     virtual void configurePlugin(const Dims* inputDims, int32_t nbInputs, const Dims* outputDims, int32_t nbOutputs,
                                  const DataType* inputTypes, const DataType* outputTypes, const bool* inputIsBroadcast,
-                                 const bool* outputIsBroadcast, PluginFormat floatFormat, int32_t maxBatchSize) noexcept {}
-    virtual void attachToContext(cudnnContext*, cublasContext*, IGpuAllocator*) noexcept {}
-    virtual void detachFromContext() noexcept {}
-    IPluginV2Ext* clone() const noexcept override = 0;
+                                 const bool* outputIsBroadcast, PluginFormat floatFormat, int32_t maxBatchSize) {}
+    virtual void attachToContext(cudnnContext*, cublasContext*, IGpuAllocator*) {}
+    virtual void detachFromContext() {}
+    IPluginV2Ext* clone() const override = 0;
 };
 
 class IPluginV2IOExt : public IPluginV2Ext {
    public:
-    virtual void configurePlugin(const PluginTensorDesc* in, int32_t nbInput, const PluginTensorDesc* out, int32_t nbOutput) noexcept = 0;
-    virtual bool supportsFormatCombination(int32_t pos, const PluginTensorDesc* inOut, int32_t nbInputs, int32_t nbOutputs) const noexcept = 0;
+    virtual void configurePlugin(const PluginTensorDesc* in, int32_t nbInput, const PluginTensorDesc* out, int32_t nbOutput) = 0;
+    virtual bool supportsFormatCombination(int32_t pos, const PluginTensorDesc* inOut, int32_t nbInputs, int32_t nbOutputs) const = 0;
     using IPluginV2Ext::configurePlugin;
-    IPluginV2IOExt* clone() const noexcept override = 0;
+    IPluginV2IOExt* clone() const override = 0;
 };
 
 class IPluginCreator {
    public:
     virtual ~IPluginCreator() = default;
-    virtual const char* getPluginName() const noexcept = 0;
-    virtual const char* getPluginVersion() const noexcept = 0;
-    virtual const PluginFieldCollection* getFieldNames() noexcept = 0;
-    virtual IPluginV2* createPlugin(const char* name, const PluginFieldCollection* fc) noexcept = 0;
-    virtual IPluginV2* deserializePlugin(const char* name, const void* serialData, size_t serialLength) noexcept = 0;
-    virtual void setPluginNamespace(const char* ns) noexcept = 0;
-    virtual const char* getPluginNamespace() const noexcept = 0;
+    virtual const char* getPluginName() const = 0;
+    virtual const char* getPluginVersion() const = 0;
+    virtual const PluginFieldCollection* getFieldNames() = 0;
+    virtual IPluginV2* createPlugin(const char* name, const PluginFieldCollection* fc) = 0;
+    virtual IPluginV2* deserializePlugin(const char* name, const void* serialData, size_t serialLength) = 0;
+    virtual void setPluginNamespace(const char* ns) = 0;
+    virtual const char* getPluginNamespace() const = 0;
 };
 
 namespace shim {
@@ -578,10 +578,17 @@ class IPluginRegistry {
     std::vector<std::unique_ptr<shim::CCreatorAdapter>> mAdapters;
 };
 
-inline IPluginRegistry* getPluginRegistry() noexcept {
-    static IPluginRegistry r;
+}  // namespace nvinfer1
+
+// TensorRT declares the registry accessor at GLOBAL scope (extern "C" in NvInferRuntimeCommon.h); reference code calls it unqualified
+// from files without a using-directive (yolov8/src/block.cpp:263) as well as from inside `using namespace nvinfer1`.
+inline nvinfer1::IPluginRegistry* getPluginRegistry() noexcept {
+    static nvinfer1::IPluginRegistry r;
     return &r;
 }
+
+namespace nvinfer1 {
+using ::getPluginRegistry;  // the same entity under both spellings: no ambiguity next to a using-directive
 
 template <typename T>
 class PluginRegistrar {

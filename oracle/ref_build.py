@@ -11,7 +11,7 @@ Two kinds of artefact:
   ``oracle/_ref/gen/*.inc`` and compiles them inside the wrapper ``oracle/ref_harness/host_post.cpp``.
 
 * ``libref_<family>.so`` (hipcc, gfx950): the reference's CUDA plugin sources, UNMODIFIED except for the lexical
-  patches listed in ``PATCHES`` (each one documented), compiled as *user plugins* against this repo's
+  patch listed in ``PATCHES`` (chevron spacing), compiled as *user plugins* against this repo's
   ``include/NvInfer.h`` with the spelling bridge in ``oracle/ref_compat/`` (cudaStream_t -> hipStream_t, cub -> hipcub,
   thrust::cuda -> thrust::hip).  Their ``REGISTER_TENSORRT_PLUGIN`` statics register them with libtrtx_hip.so's plugin
   registry when the library is dlopened, so the tests drive the reference's own kernels through the same C-ABI plugin
@@ -46,9 +46,6 @@ REGIONS = [
 PATCHES = {
     # clang-format split the kernel-launch chevrons (`<< <` ... `>> >`); nvcc tolerates that, hipcc does not
     "*": [(r"<<\s+<", "<<<"), (r">>\s+>", ">>>")],
-    # getSerializationSize() lacks TRT_NOEXCEPT while the class is compiled with NV_TENSORRT_MAJOR >= 8 (all its other
-    # overrides carry it): the reference only builds against TensorRT 7 here.  Add the missing specifier.
-    "rcnn/BatchedNmsPlugin.h": [(r"size_t getSerializationSize\(\) const override", "size_t getSerializationSize() const TRT_NOEXCEPT override")],
 }
 
 # family -> (sources, extra include dirs relative to the reference, headers that need a patched copy)
@@ -58,7 +55,7 @@ FAMILIES = {
     "yolov5_plugin": (["yolov5/plugin/yololayer.cu"], ["yolov5/plugin", "yolov5/src"], []),
     "retinaface_plugin": (["retinaface/decode.cu"], ["retinaface"], []),
     "rcnn_plugins": (["rcnn/RpnDecode.cu", "rcnn/RpnNms.cu", "rcnn/RoiAlign.cu", "rcnn/PredictorDecode.cu", "rcnn/BatchedNms.cu",
-                      "rcnn/MaskRcnnInference.cu"], ["rcnn"], ["rcnn/BatchedNmsPlugin.h"]),
+                      "rcnn/MaskRcnnInference.cu"], ["rcnn"], []),
 }
 
 
