@@ -434,7 +434,7 @@ def main():
         rows = []
         for _ in range(prof_runs):
             rows = e.profile(batch, bindings)
-            conv = [r for r, o in zip(rows, low["ops"]) if o["kind"] == "conv" and o.get("igemm")]
+            conv = [r for r, o in zip(rows, low["ops"]) if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] == "conv_chain"]
             n = len(conv)
             c_ms += sum(r["ms"] for r in conv)
             t_ms += sum(r["ms"] for r in rows)
@@ -469,11 +469,17 @@ def main():
     # (+ residual) at this batch + the layer's packed weights once (DESIGN.md "Measurement"); duration = per-op HIP events.
     # YOLOv8n layers sit below the MFMA/HBM ridge (arithmetic intensity 16..290 FLOP/B against 312) -> bound "hbm";
     # ResNet-50 / RetinaFace / R-CNN are dominated by layers above it -> bound "mfma".  Both views are always printed.
-    igemm_ops = [o for o in low["ops"] if o["kind"] == "conv" and o.get("igemm")]
+    igemm_ops = [o for o in low["ops"] if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] == "conv_chain"]
+    n_chain = sum(1 for o in igemm_ops if o["kind"] == "conv_chain")
+    convs_in_chains = sum(len(o["stages"]) for o in igemm_ops if o["kind"] == "conv_chain")
     alg_bytes = 0.0
     flop_per_step = 0.0
     for o in igemm_ops:
         nb = o.get("nfix") or batch              # images per launch = nb * nmul (nmul: RoIs per image in the R-CNN head)
+        if o["kind"] == "conv_chain":            # a fused chain: its input and its output once, the intermediates never reach memory
+            alg_bytes += 2.0 * o["hw_in"][0] * o["hw_in"][1] * (o["cin"] + o["cout"]) * nb * o.get("nmul", 1) + o["weight_bytes"]
+            flop_per_step += o["flops"] * nb
+            continue
         i8 = o.get("i8", [0, 0, 0])
         es_in, es_out, es_res = (1.0 if i8[0] else 2.0), (1.0 if i8[1] else 2.0), (1.0 if i8[2] else 2.0)
         act_b = (es_in * o["hw_in"][0] * o["hw_in"][1] * o["cin"] + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (es_out + (es_res if o["residual"] else 0.0)))
@@ -490,8 +496,9 @@ def main():
     bound = "hbm" if intensity < MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS else "mfma"
     traffic, traffic_src = _traffic_from_profile(args.config)
     prof_us, prof_src = _kernel_duration_from_profile(args.config) if args.precision == "fp16" else (None, None)
-    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_ws_f16 / conv_igemm_f16 / conv_igemm_wsk_f16, all instantiations)",
-                "launches_per_step": n_conv, "avg_launch_us": avg_launch_s * 1e6,
+    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_chain_f16 / conv_igemm_f16 / conv_ws_f16 / conv_igemm_wsk_f16, all instantiations)",
+                "launches_per_step": n_conv, "fused_chain_launches": n_chain, "convolutions_inside_chains": convs_in_chains,
+                "bytes_priced": "algorithmic: fp16 activations in + out (+ residual) of every launch + its weights once; a fused chain is priced on its input and output only", "avg_launch_us": avg_launch_s * 1e6,
                 "timing": ("dispatch begin -> end of every conv launch (HIP events attached to the launch, hipExtLaunchKernelGGL), mean of 5 serialized profile passes"
                            if conv_ms_kernel else "interval between the HIP stream events around every conv op, mean of 5 serialized profile passes"),
                 "avg_launch_us_between_stream_events": conv_ms_events * 1e3 / max(n_conv, 1),

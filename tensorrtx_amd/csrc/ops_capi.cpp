@@ -177,3 +177,59 @@ extern "C" int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int 
                                                 trtx_stream_t stream) {
     return nhwc_to_nchw_f32(in, DT_F16, out, N, C, H, W, ld_in, stream);
 }
+
+// ---- fused convolution chains (kernels/conv_chain.hip) ---------------------------------------------------------------------
+extern "C" size_t trtx_conv_chain_packed_halfs(int cin, int cout, int k) {
+    if (cin < 1 || cout < 1 || (k != 1 && k != 3)) return 0;
+    return conv_chain_weight_halfs(cin, cout, k);
+}
+
+extern "C" int32_t trtx_conv_chain_pack_weights_f16(const float* w_kcrs, int cout, int cin, int k, const float* ch_scale, uint16_t* packed) {
+    if (!w_kcrs || !packed || cin < 1 || cout < 1 || (k != 1 && k != 3)) return TRTX_ERR_INVALID;
+    conv_chain_pack_weights(w_kcrs, cout, cin, k, ch_scale, packed);
+    return TRTX_OK;
+}
+
+static bool chain_desc(ChainDesc* d, int N, int H, int W, int Cin, int ld_in, int ld_out, int nstages, const int32_t* k, const int32_t* cout,
+                       const int32_t* act, const int32_t* residual, int tile_h, int tile_w) {
+    if (!k || !cout || nstages < 1 || nstages > 3) return false;
+    *d = ChainDesc{};
+    d->N = N; d->H = H; d->W = W; d->Cin = Cin; d->ld_in = ld_in; d->ld_out = ld_out;
+    d->nstages = nstages;
+    d->tile_h = tile_h; d->tile_w = tile_w;
+    for (int s = 0; s < nstages; ++s) {
+        d->st[s].k = k[s];
+        d->st[s].cout = cout[s];
+        d->st[s].act = act ? act[s] : ACT_NONE;
+        d->st[s].alpha = 0.1f;
+        d->st[s].residual = residual ? residual[s] : 0;
+    }
+    return true;
+}
+
+extern "C" int32_t trtx_op_conv_chain_plan(int N, int H, int W, int Cin, int nstages, const int32_t* k, const int32_t* cout, const int32_t* residual,
+                                           int tile_h, int tile_w, int32_t* out4) {
+    ChainDesc d;
+    if (!out4 || !chain_desc(&d, N, H, W, Cin, (Cin + 7) / 8 * 8, 0, nstages, k, cout, nullptr, residual, tile_h, tile_w)) return TRTX_ERR_INVALID;
+    d.ld_out = d.st[nstages - 1].cout;
+    int th = 0, tw = 0, lds = 0, nst = 0;
+    const int32_t st = conv_chain_describe(d, &th, &tw, &lds, &nst);
+    if (st != TRTX_OK) return st;
+    out4[0] = th; out4[1] = tw; out4[2] = lds; out4[3] = nst;
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_op_conv_chain_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, void* out, int ld_out, int nstages,
+                                               const int32_t* k, const int32_t* cout, const int32_t* act, const int32_t* residual,
+                                               const void* const* wpacked, const float* const* bias, int tile_h, int tile_w, trtx_stream_t stream) {
+    ChainDesc d;
+    if (!in || !out || !wpacked || !bias || !chain_desc(&d, N, H, W, Cin, ld_in, ld_out, nstages, k, cout, act, residual, tile_h, tile_w)) return TRTX_ERR_INVALID;
+    d.in = in;
+    d.out = out;
+    for (int s = 0; s < nstages; ++s) {
+        if (!wpacked[s] || !bias[s]) return TRTX_ERR_INVALID;
+        d.st[s].wgt = wpacked[s];
+        d.st[s].bias = bias[s];
+    }
+    return conv_chain_f16(d, static_cast<hipStream_t>(stream));
+}

@@ -101,7 +101,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         probes.resize(plan.ops.size());
         if (!no_probe && !c->tuning)  // the tactic timing keeps its own clock (the interval between the stream events)
             for (size_t k = 0; k < plan.ops.size(); ++k)
-                if (plan.ops[k].kind == OP_CONV && plan.ops[k].igemm)
+                if ((plan.ops[k].kind == OP_CONV && plan.ops[k].igemm) || plan.ops[k].kind == OP_CONV_CHAIN)
                     if (hipEventCreate(&probes[k].start) != hipSuccess || hipEventCreate(&probes[k].stop) != hipSuccess) (void)hipGetLastError();
         TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
     }
@@ -159,6 +159,28 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     conv_set_launch_probe(nullptr);
                 } else
                     st = conv_direct(a, op.dtype, stream);
+                break;
+            }
+            case OP_CONV_CHAIN: {
+                ChainDesc d{};
+                d.in = R.ptr(op.in[0]);
+                d.out = R.ptr(op.out[0]);
+                d.N = nb(t0);
+                d.H = op.conv.H; d.W = op.conv.W; d.Cin = op.conv.Cin; d.ld_in = t0.ld; d.ld_out = to.ld;
+                d.nstages = (int)op.chain.size();
+                for (size_t s = 0; s < op.chain.size(); ++s) {
+                    const POp::ChainStage& cs = op.chain[s];
+                    d.st[s].k = cs.k;
+                    d.st[s].cout = cs.cout;
+                    d.st[s].act = cs.act;
+                    d.st[s].alpha = cs.alpha;
+                    d.st[s].residual = cs.residual ? 1 : 0;
+                    d.st[s].wgt = W + cs.w_off;
+                    d.st[s].bias = reinterpret_cast<const float*>(W + cs.b_off);
+                }
+                if (prof && probes[k].start && probes[k].stop) conv_set_launch_probe(&probes[k]);
+                st = conv_chain_f16(d, stream);
+                conv_set_launch_probe(nullptr);
                 break;
             }
             case OP_POOL:

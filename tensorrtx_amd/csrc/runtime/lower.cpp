@@ -16,8 +16,8 @@ const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
                               "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head",
-                              "pool_chain", "depth_to_space", "roi_align"};
-    return (k >= 0 && k <= OP_ROI_ALIGN) ? n[k] : "?";
+                              "pool_chain", "depth_to_space", "roi_align", "conv_chain"};
+    return (k >= 0 && k <= OP_CONV_CHAIN) ? n[k] : "?";
 }
 
 namespace {
@@ -1091,6 +1091,123 @@ struct Lowerer {
         }
     }
 
+    // Convolution chains -> one launch (kernels/conv_chain.hip).  A chain is 3x3 -> 3x3 [-> 1x1] or 3x3 -> 1x1, all stride 1 with the
+    // same Cout, every intermediate tensor read by the next stage only: the C2f bottleneck (block.cpp:98-110; its shortcut adds the
+    // chain's own input) and the three-convolution arms of the detect head (model.cpp:188-251).  The fused op takes the first stage's
+    // place in the schedule (its only activation input is that stage's input) and the intermediate tensors lose their storage.
+    // TRTX_FUSE_CHAINS=0 keeps the layers apart (A/B measurements).
+    void fuse_conv_chains() {
+        if (dt != DT_F16) return;
+        if (const char* e = getenv("TRTX_FUSE_CHAINS"))
+            if (atoi(e) == 0) return;
+        std::vector<int> readers(plan.tensors.size(), 0);
+        auto top_of = [&](int t) {
+            while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
+            return t;
+        };
+        std::vector<int> views_of(plan.tensors.size(), 0);  // tensors (other than itself) that alias an owner's storage
+        for (const PTensor& t : plan.tensors)
+            if (t.parent >= 0) ++views_of[top_of(t.id)];
+        for (const POp& op : plan.ops)
+            for (int t : op.in) ++readers[t];
+        auto plain = [&](const POp& op, int k) {
+            const ConvArgs& a = op.conv;
+            return op.kind == OP_CONV && op.igemm && !op.stem && !op.from_deconv && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == k && a.kw == k &&
+                   a.stride_h == 1 && a.stride_w == 1 && a.pad_h == k / 2 && a.pad_w == k / 2 && a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 &&
+                   a.act2 == ACT_NONE && !a.scalar_out && a.Ho == a.H && a.Wo == a.W && plan.tensors[op.in[0]].nmul == 1;
+        };
+        // an intermediate: written by `op`, read exactly once (by the next stage, as its convolution input), owns its storage, no view
+        // of it exists and it is not a binding
+        auto private_out = [&](const POp& op) {
+            const int t = op.out[0];
+            const PTensor& pt = plan.tensors[t];
+            return readers[t] == 1 && pt.parent < 0 && views_of[t] == 0 && !is_binding_tensor(t) && pt.dtype == DT_F16;
+        };
+        auto consumer_of = [&](int tensor, size_t from) -> int {
+            for (size_t k = from; k < plan.ops.size(); ++k)
+                if (!plan.ops[k].in.empty() && plan.ops[k].in[0] == tensor) return (int)k;
+            return -1;
+        };
+        auto same_tensor = [&](int a, int b) {
+            const PTensor &x = plan.tensors[a], &y = plan.tensors[b];
+            return a == b || (x.storage == y.storage && x.rcoff == y.rcoff && x.C == y.C && x.layout == y.layout);
+        };
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            POp& first = plan.ops[k];
+            if (!plain(first, 3) || first.in.size() != 1) continue;
+            std::vector<int> members = {(int)k};
+            const int cout = first.conv.Cout;
+            // second stage: 3x3 (optionally + the chain input as shortcut) or 1x1
+            if (!private_out(first)) continue;
+            int nx = consumer_of(first.out[0], k + 1);
+            if (nx < 0) continue;
+            auto stage_ok = [&](const POp& op, int kk, bool allow_res) {
+                if (!plain(op, kk) || op.conv.Cout != cout || op.conv.Cin != cout) return false;
+                if (op.in.size() > 1) return allow_res && same_tensor(op.in[1], first.in[0]) && first.conv.Cin == cout;
+                return true;
+            };
+            if (stage_ok(plan.ops[nx], 3, true)) {
+                members.push_back(nx);
+                if (private_out(plan.ops[nx])) {
+                    const int n3 = consumer_of(plan.ops[nx].out[0], nx + 1);
+                    if (n3 >= 0 && stage_ok(plan.ops[n3], 1, false)) members.push_back(n3);
+                }
+            } else if (stage_ok(plan.ops[nx], 1, false)) {
+                members.push_back(nx);
+            } else {
+                continue;
+            }
+            // does the kernel take it (tile / LDS plan at the largest batch)?
+            ChainDesc d{};
+            const PTensor& tin = plan.tensors[first.in[0]];
+            const PTensor& tout = plan.tensors[plan.ops[members.back()].out[0]];
+            d.N = (tin.nfix ? tin.nfix : plan.max_batch) * tin.nmul;
+            d.H = first.conv.H; d.W = first.conv.W; d.Cin = first.conv.Cin; d.ld_in = tin.ld; d.ld_out = tout.ld;
+            d.nstages = (int)members.size();
+            if (tin.rcoff % 8 || tout.rcoff % 8 || tin.dtype != DT_F16 || tout.dtype != DT_F16) continue;
+            for (size_t s = 0; s < members.size(); ++s) {
+                const POp& m = plan.ops[members[s]];
+                d.st[s].k = m.conv.kh;
+                d.st[s].cout = m.conv.Cout;
+                d.st[s].act = m.conv.act1;
+                d.st[s].alpha = m.conv.alpha1;
+                d.st[s].residual = m.in.size() > 1 ? 1 : 0;
+            }
+            if (!conv_chain_supported(d)) continue;
+            POp fused = first;
+            fused.kind = OP_CONV_CHAIN;
+            fused.igemm = false;
+            fused.in = {first.in[0]};
+            fused.out = {plan.ops[members.back()].out[0]};
+            fused.flops = 0;
+            fused.bytes = 0;
+            fused.name = "";
+            for (size_t s = 0; s < members.size(); ++s) {
+                const POp& m = plan.ops[members[s]];
+                POp::ChainStage st;
+                st.src_layer = m.src_layer;
+                st.scale_layer = m.scale_layer;
+                st.k = m.conv.kh;
+                st.cin = m.conv.Cin;
+                st.cout = m.conv.Cout;
+                st.act = m.conv.act1;
+                st.alpha = m.conv.alpha1;
+                st.residual = m.in.size() > 1;
+                fused.chain.push_back(st);
+                fused.flops += m.flops;
+                fused.name += (s ? " + " : "") + m.name;
+            }
+            fused.name += " [fused chain]";
+            fused.conv.Cout = cout;
+            fused.conv.ld_out = tout.ld;
+            // algorithmic bytes per sample: the chain's input and output once (the intermediates never exist in memory)
+            fused.bytes = 2.0 * first.conv.H * first.conv.W * (first.conv.Cin + cout);
+            plan.ops[k] = fused;
+            for (size_t s = members.size() - 1; s >= 1; --s) plan.ops.erase(plan.ops.begin() + members[s]);
+            // reader counts of the erased ops' inputs no longer matter: their tensors are gone from the schedule
+        }
+    }
+
     bool finalize() {
         assign_int8();
         // 1. storages for owners
@@ -1234,6 +1351,7 @@ struct Lowerer {
             a.out = {a.out[0], b.out[0], c3.out[0]};
             plan.ops.erase(plan.ops.begin() + k + 1, plan.ops.begin() + k + 3);
         }
+        fuse_conv_chains();
         // 5. op dependencies at (storage, channel/element range) granularity: RAW, WAR and WAW
         const int nops = (int)plan.ops.size();
         struct Access { int storage; long lo, hi; int op; bool write; };
@@ -1493,6 +1611,29 @@ bool pack_weights(const Network& net, Plan* plan) {
             op.b_off = reserve(bias.size() * 4);
             memcpy(blob.data() + op.b_off, bias.data(), bias.size() * 4);
             op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * 2 : (size_t)cout * a.K * 4);
+        } else if (op.kind == OP_CONV_CHAIN) {
+            for (POp::ChainStage& st : op.chain) {
+                const LayerDef& l = net.layers[st.src_layer];
+                std::vector<float> sc(st.cout, 1.f), bias(st.cout, 0.f);
+                for (int c = 0; c < st.cout && c < (int)l.w1.size(); ++c) bias[c] = l.w1[c];
+                if (st.scale_layer >= 0) {
+                    const LayerDef& sl = net.layers[st.scale_layer];
+                    for (int c = 0; c < st.cout; ++c) {
+                        const float scale = sl.w1.empty() ? 1.f : (sl.w1.size() == 1 ? sl.w1[0] : sl.w1[c]);
+                        const float shift = sl.w0.empty() ? 0.f : (sl.w0.size() == 1 ? sl.w0[0] : sl.w0[c]);
+                        sc[c] = scale;
+                        bias[c] = bias[c] * scale + shift;
+                    }
+                }
+                const TensorDef& tin = net.tensors[l.inputs[0]];
+                const int cin_logical = (int)tin.dims.d[tin.dims.nb - 3];
+                const size_t halfs = conv_chain_weight_halfs(st.cin, st.cout, st.k);
+                st.w_off = reserve(halfs * 2);
+                conv_chain_pack_weights(l.w0.data(), st.cout, cin_logical, st.k, sc.data(), reinterpret_cast<uint16_t*>(blob.data() + st.w_off));
+                st.b_off = reserve(bias.size() * 4);
+                memcpy(blob.data() + st.b_off, bias.data(), bias.size() * 4);
+                op.bytes += (double)halfs * 2;
+            }
         } else if (op.kind == OP_YOLO_HEAD) {
             const LayerDef& l = net.layers[op.src_layer];
             op.w_off = reserve(16 * 4);
@@ -1551,6 +1692,21 @@ std::string Plan::describe_json() const {
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
               << ",\"ld_out\":" << a.ld_out << ",\"i8\":[" << a.in_i8 << "," << a.out_i8 << "," << a.res_i8 << "],\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
               << (op.stem ? 0 : tensors[op.in[0]].nfix);
+        }
+        if (op.kind == OP_CONV_CHAIN) {
+            const ConvArgs& a = op.conv;
+            o << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout << ",\"hw_in\":[" << a.H << "," << a.W << "],\"hw_out\":[" << a.H << "," << a.W
+              << "],\"ld_in\":" << a.ld_in << ",\"ld_out\":" << a.ld_out << ",\"nmul\":" << tensors[op.in[0]].nmul << ",\"nfix\":" << tensors[op.in[0]].nfix
+              << ",\"weight_bytes\":";
+            double wb = 0;
+            for (const auto& st : op.chain) wb += 2.0 * (double)conv_chain_weight_halfs(st.cin, st.cout, st.k);
+            o << wb << ",\"stages\":[";
+            for (size_t j = 0; j < op.chain.size(); ++j) {
+                const auto& st = op.chain[j];
+                o << (j ? "," : "") << "{\"k\":" << st.k << ",\"cin\":" << st.cin << ",\"cout\":" << st.cout << ",\"act\":" << st.act << ",\"residual\":"
+                  << (st.residual ? "true" : "false") << "}";
+            }
+            o << "]";
         }
         o << ",\"lane\":" << op.lane << ",\"waits\":[";
         for (size_t j = 0; j < op.wait_ops.size(); ++j) o << (j ? "," : "") << op.wait_ops[j];

@@ -44,6 +44,7 @@ enum OpKind : int {
     OP_POOL_CHAIN,    // three chained k x k stride-1 'same' max-pools (SPPF) in one launch, three outputs
     OP_D2S,           // depth-to-space: [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c] (second half of a kernel == stride deconvolution)
     OP_ROI_ALIGN,     // detectron2 ROIAlign on the NHWC feature map, NHWC [P][res][res][C] out (fused form of the "RoiAlign" plugin)
+    OP_CONV_CHAIN,    // two or three stride-1 convolutions in one launch, intermediates in LDS (kernels/conv_chain.hip)
 };
 const char* op_kind_name(int k);
 
@@ -90,6 +91,15 @@ struct POp {
     bool igemm = false;
     bool stem = false;         // conv_stem kernel: reads the LINEAR fp32 input directly
     bool from_deconv = false;  // 1x1 conv standing in for a kernel == stride deconvolution (weights re-laid from CKRS)
+    // OP_CONV_CHAIN: the fused stages in order (stage 0 reads in[0]; the last one writes out[0]); `conv` keeps stage 0's geometry
+    struct ChainStage {
+        int src_layer = -1, scale_layer = -1;
+        int k = 3, cin = 0, cout = 0, act = ACT_NONE;
+        float alpha = 0.f;
+        bool residual = false;  // adds the chain input (C2f shortcut)
+        size_t w_off = 0, b_off = 0;
+    };
+    std::vector<ChainStage> chain;
     int src_layer = -1;        // network layer holding the kernel weights
     int scale_layer = -1;      // folded IScaleLayer (BatchNorm) or -1
     size_t w_off = 0, b_off = 0, s_off = 0;  // byte offsets into the device weight blob
