@@ -250,6 +250,8 @@ int32_t trtx_conv_chain_pack_weights_f16(const float* w_kcrs, int cout, int cin,
 int32_t trtx_op_conv_chain_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, void* out, int ld_out, int nstages,
                                     const int32_t* k, const int32_t* cout, const int32_t* act, const int32_t* residual,
                                     const void* const* wpacked, const float* const* bias, int tile_h, int tile_w, trtx_stream_t stream);
+int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream); /* test support: NaN patterns into every CU's LDS */
+int32_t trtx_op_conv_chain_set_stamps(void* device_buffer_512x16_u64); /* timing experiments: per-workgroup phase stamps; NULL = off */
 int32_t trtx_op_conv_chain_plan(int N, int H, int W, int Cin, int nstages, const int32_t* k, const int32_t* cout, const int32_t* residual,
                                 int tile_h, int tile_w, int32_t* out4);
 int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad, int ld_out,

@@ -112,6 +112,8 @@ int32_t conv_chain_f16(const ChainDesc& d, hipStream_t s);
 // the tile, LDS bytes and weight-ring depth the launcher would use (host only)
 int32_t conv_chain_describe(const ChainDesc& d, int* th, int* tw, int* lds_bytes, int* nst);
 size_t conv_chain_weight_halfs(int cin, int cout, int k);
+int32_t conv_chain_poison_lds(unsigned* device_word, hipStream_t s);  // test support: NaN patterns into every CU's LDS
+void conv_chain_set_stamps(unsigned long long* device_buffer_512x16);  // timing experiments (tools/chain_stamps.py); nullptr = off
 void conv_chain_pack_weights(const float* w_kcrs, int cout, int cin, int k, const float* ch_scale, uint16_t* packed);
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);

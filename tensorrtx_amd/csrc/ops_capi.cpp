@@ -231,5 +231,23 @@ extern "C" int32_t trtx_op_conv_chain_nhwc_f16(const void* in, int N, int H, int
         d.st[s].wgt = wpacked[s];
         d.st[s].bias = bias[s];
     }
-    return conv_chain_f16(d, static_cast<hipStream_t>(stream));
+    // micro-benchmarks (tools/chain_bench.py): TRTX_OP_REPEAT launches back to back from C, so that the host side of the Python binding
+    // does not pace the measurement
+    int repeat = 1;
+    if (const char* e = getenv("TRTX_OP_REPEAT")) repeat = atoi(e) > 0 ? atoi(e) : 1;
+    int32_t st = TRTX_OK;
+    for (int r = 0; r < repeat && st == TRTX_OK; ++r) st = conv_chain_f16(d, static_cast<hipStream_t>(stream));
+    return st;
+}
+
+// timing experiments: per-workgroup s_memtime stamps of the chain kernel into a caller-owned device buffer [512][16] u64 (nullptr: off)
+extern "C" int32_t trtx_op_conv_chain_set_stamps(void* device_buffer) {
+    conv_chain_set_stamps(static_cast<unsigned long long*>(device_buffer));
+    return TRTX_OK;
+}
+
+// test support: fill the LDS of every CU with fp16 NaN patterns (LDS survives kernel boundaries; see tests/test_gpu_conv_chain.py)
+extern "C" int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream) {
+    if (!device_word) return TRTX_ERR_INVALID;
+    return conv_chain_poison_lds(static_cast<unsigned*>(device_word), static_cast<hipStream_t>(stream));
 }

@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "../common.h"
+#include "engine.h"
 #include "graph.h"
 #include "int8.h"
 #include "plan.h"
@@ -401,7 +402,27 @@ extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_
         return TRTX_ERR_UNSUPPORTED;
     }
     std::vector<uint8_t> blob;
+    n->net.tactics.clear();
+    n->net.tactics_timed = false;
     n->net.serialize(blob);
+    // Kernel tactics by timing, where there is a GPU to time on (what TensorRT's builder does at this point): a throw-away engine
+    // of this plan times the launch configurations of its convolutions (runtime/tune.cpp) and the choices are stored IN the plan, so
+    // that every deserialize of it runs the same kernels.  Without a GPU (or with TRTX_TUNE=0) the plan carries no choices and
+    // engines made from it run the static defaults.
+    const char* tune_env = getenv("TRTX_TUNE");
+    if (n->net.fp16 && !(tune_env && atoi(tune_env) == 0) && trtx_device_count() > 0) {
+        trtx_engine* e = nullptr;
+        if (engine_from_plan(blob.data(), blob.size(), true, &e) == TRTX_OK && e) {
+            n->net.tactics = e->net->tactics;
+            n->net.tactics_timed = e->net->tactics_timed;
+            trtx_engine_destroy(e);
+            blob.clear();
+            n->net.serialize(blob);
+        } else {
+            (void)hipGetLastError();
+            fprintf(stderr, "[trtx_hip] buildSerializedNetwork: tactic timing skipped, the plan carries the static defaults\n");
+        }
+    }
     *out = trtx_hostmem_from(std::move(blob));
     return TRTX_OK;
 }

@@ -455,6 +455,10 @@ static int32_t check_device(const trtx_engine* e, const char* what) {
 extern "C" int32_t trtx_engine_device(const trtx_engine* e) { return e ? e->device : -1; }
 
 extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, trtx_engine** out) {
+    return trtx::engine_from_plan(plan_data, size, false, out);
+}
+
+int32_t trtx::engine_from_plan(const void* plan_data, size_t size, bool time_tactics, trtx_engine** out) {
     if (!plan_data || !out) return TRTX_ERR_INVALID;
     if (trtx_device_count() < 1) {
         fprintf(stderr, "[trtx_hip] no HIP device: engines only run on the GPU (there is no CPU fallback)\n");
@@ -488,7 +492,13 @@ extern "C" int32_t trtx_engine_deserialize(const void* plan_data, size_t size, t
         }
         ++e->plugins_initialized;
     }
-    if (const int32_t st = tune_engine(e.get())) return st;
+    // kernel tactics: the plan's own (chosen by timing when it was built on a GPU machine); a plan built without a GPU has none and
+    // is timed here only on request (TRTX_TUNE=1) - by default it runs the static defaults, reproducibly
+    if (!time_tactics && !e->net->tactics_timed) {
+        const char* env = getenv("TRTX_TUNE");
+        time_tactics = env && atoi(env) == 1;
+    }
+    if (const int32_t st = tune_engine(e.get(), time_tactics)) return st;
     *out = e.release();
     return TRTX_OK;
 }

@@ -67,6 +67,11 @@ struct OpTiming {
 };
 int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStream_t stream,
                      std::vector<OpTiming>* prof);
-// times the exchangeable launch configurations of every MFMA convolution in place and keeps the fastest (runtime/tune.cpp)
-int32_t tune_engine(trtx_engine* e);
+// runtime/tune.cpp.  time_now = false: apply the kernel tactics the plan carries (deserializeCudaEngine).  time_now = true: time the
+// exchangeable launch configurations of every MFMA convolution in place, keep the fastest and record the choices in
+// e->net->tactics (buildSerializedNetwork on a machine with a GPU).
+int32_t tune_engine(trtx_engine* e, bool time_now);
+// deserializeCudaEngine with the choice of the above (trtx_engine_deserialize = engine_from_plan(..., false) unless TRTX_TUNE=1 and the
+// plan was built without a GPU)
+int32_t engine_from_plan(const void* plan_data, size_t size, bool time_tactics, trtx_engine** out);
 }  // namespace trtx

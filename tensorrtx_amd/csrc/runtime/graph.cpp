@@ -393,13 +393,16 @@ void Network::serialize(std::vector<uint8_t>& out, std::vector<std::array<size_t
     Writer w{out};
     if (w_offsets) w_offsets->assign(layers.size(), {0, 0, 0});
     w.raw(kMagic, 8);
-    w.pod<uint32_t>(3);  // format version (2: + int8 flag and per-tensor calibration scales; 3: + max_aux_streams)
+    w.pod<uint32_t>(4);  // format version (2: + int8 flag and per-tensor calibration scales; 3: + max_aux_streams; 4: + kernel tactics)
     w.pod<uint8_t>(explicit_batch);
     w.pod<uint8_t>(fp16);
     w.pod<uint8_t>(int8);
     w.pod<uint32_t>((uint32_t)tensor_scale.size());
     for (float sc : tensor_scale) w.pod<float>(sc);
     w.pod<int32_t>(max_aux_streams);
+    w.pod<uint8_t>(tactics_timed);
+    w.pod<uint32_t>((uint32_t)tactics.size());
+    for (const TacticEntry& t : tactics) w.raw(&t, sizeof t);
     w.pod<int32_t>(max_batch);
     w.pod<uint32_t>((uint32_t)tensors.size());
     for (const auto& t : tensors) {
@@ -461,7 +464,7 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
         return nullptr;
     }
     const uint32_t version = r.pod<uint32_t>();
-    if (version < 1 || version > 3) {
+    if (version < 1 || version > 4) {
         if (err) *err = "unsupported plan version";
         return nullptr;
     }
@@ -483,6 +486,16 @@ std::unique_ptr<Network> Network::deserialize(const uint8_t* data, size_t size, 
             if (err) *err = "corrupt plan (max_aux_streams)";
             return nullptr;
         }
+    }
+    if (version >= 4) {
+        n->tactics_timed = r.pod<uint8_t>() != 0;
+        const uint32_t ntac = r.pod<uint32_t>();
+        if (!r.ok || ntac > (r.n - r.pos) / sizeof(TacticEntry)) {
+            if (err) *err = "truncated or corrupt plan";
+            return nullptr;
+        }
+        n->tactics.resize(ntac);
+        for (uint32_t i = 0; i < ntac; ++i) r.raw(&n->tactics[i], sizeof(TacticEntry));
     }
     n->max_batch = r.pod<int32_t>();
     const uint32_t nt = r.pod<uint32_t>();

@@ -104,6 +104,15 @@ class Network {
     int max_aux_streams = -1;  // IBuilderConfig::setMaxAuxStreams: extra streams (lanes) a context may use; -1 = runtime default
     bool int8 = false;  // BuilderFlag::kINT8: tensor_scale holds the calibrated activation scales (0 = not calibrated)
     std::vector<float> tensor_scale;  // per network tensor: real value = int8 value * scale
+    // Kernel tactics chosen by timing when the plan was BUILT on a machine with a GPU (TensorRT's builder does the same behind
+    // buildSerializedNetwork and stores the result in the engine): (layer signature, launch configuration) pairs, runtime/tune.cpp.
+    // A plan that carries them runs the same kernels - and returns the same bits - wherever and however often it is deserialized.
+    struct TacticEntry {
+        int32_t sig[28];
+        int32_t tac[6];
+    };
+    std::vector<TacticEntry> tactics;
+    bool tactics_timed = false;  // the builder ran the timing (an empty list then means "the defaults won everywhere")
     std::vector<TensorDef> tensors;
     std::vector<LayerDef> layers;
     std::string error;  // last shape-inference / validation error

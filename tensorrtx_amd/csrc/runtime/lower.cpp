@@ -1132,6 +1132,10 @@ struct Lowerer {
             const PTensor &x = plan.tensors[a], &y = plan.tensors[b];
             return a == b || (x.storage == y.storage && x.rcoff == y.rcoff && x.C == y.C && x.layout == y.layout);
         };
+        // TRTX_FUSE_CHAINS_MASK: bit i set = fuse the i-th candidate chain (bisecting / per-chain A/B); default all
+        unsigned long long mask = ~0ull;
+        if (const char* e = getenv("TRTX_FUSE_CHAINS_MASK")) mask = strtoull(e, nullptr, 0);
+        int cand_index = 0;
         for (size_t k = 0; k < plan.ops.size(); ++k) {
             POp& first = plan.ops[k];
             if (!plain(first, 3) || first.in.size() != 1) continue;
@@ -1174,6 +1178,7 @@ struct Lowerer {
                 d.st[s].residual = m.in.size() > 1 ? 1 : 0;
             }
             if (!conv_chain_supported(d)) continue;
+            if (!((mask >> (cand_index++ & 63)) & 1ull)) continue;
             POp fused = first;
             fused.kind = OP_CONV_CHAIN;
             fused.igemm = false;

@@ -1,6 +1,9 @@
 // Tactic selection by measurement, the part of TensorRT's builder (IBuilder::buildSerializedNetwork, yolov8/src/model.cpp:327;
-// "tactics" in its verbose log) that picks one of several kernels for a layer by timing them on the device.  Here a plan stores
-// the network, not kernels, and lowering is re-run at deserializeCudaEngine - so that is where the timing happens:
+// "tactics" in its verbose log) that picks one of several kernels for a layer by timing them on the device.  As in TensorRT the
+// timing runs when the plan is BUILT (trtx_build_serialized, when a GPU is present) and the choices are stored in the plan
+// (Network::tactics, plan format 4): deserializeCudaEngine only applies them, so one plan file runs the same kernels - and
+// returns the same bits - in every process.  A plan built on a machine without a GPU carries no choices and runs the static
+// defaults (TRTX_TUNE=1 at deserialize times such a plan there, the round-2 behaviour).  How the timing works:
 //
 //   * every MFMA convolution of the plan has a small set of exchangeable launch configurations (conv_tactics(): column-tile
 //     width, 64- / 128- / 256-row tiles, 32- or 64-wide k-steps, the wave-split-K, the weight-stationary and the 3x3 row-reuse
@@ -47,6 +50,7 @@ SigKey signature(const ConvArgs& a, int act_pair) {
     const int f[] = {a.N, a.H, a.W, a.Cin, a.ld_in, a.Ho, a.Wo, a.Cout, a.Cout_pad, a.ld_out, a.residual || a.ld_res ? a.ld_res : -1, a.kh, a.kw,
                      a.stride_h, a.stride_w, a.pad_h, a.pad_w, a.CinK, a.Kpad, a.in_i8, a.out_i8, a.res_i8, a.scalar_out, a.bn, a.bk, act_pair};
     static_assert(sizeof(f) / sizeof(int) <= 28, "signature too long");
+    static_assert(sizeof(SigKey) == sizeof(Network::TacticEntry::sig), "plan tactic entries hold a whole signature");
     memcpy(k.v, f, sizeof(f));
     return k;
 }
@@ -103,10 +107,10 @@ std::string tactic_name(const ConvTactic& t) {
 
 namespace trtx {
 
-int32_t tune_engine(trtx_engine* e) {
-    // On by default; TRTX_TUNE=0 (read at every deserialize) keeps every layer on its static default.  Measured on YOLOv8n b32
-    // (profiles/r02_tactics.txt, same box, alternating runs): one context 1.309-1.310 ms against 1.413-1.421 untuned (conv launches
-    // 19.9 against 21.6 us); three contexts in flight 0.936-0.945 against 0.945-0.950 ms.  Costs 0.1-2 s per deserialize.
+int32_t tune_engine(trtx_engine* e, bool time_now) {
+    // TRTX_TUNE=0 (read at every build / deserialize) keeps every layer on its static default, whatever the plan carries.  Measured
+    // on YOLOv8n b32 (profiles/r02_tactics.txt, same box, alternating runs): one context 1.309-1.310 ms against 1.413-1.421 untuned
+    // (conv launches 19.9 against 21.6 us); three contexts in flight 0.936-0.945 against 0.945-0.950 ms.  Timing costs 0.1-2 s.
     const char* env = getenv("TRTX_TUNE");
     const bool off = env && atoi(env) == 0;
     const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
@@ -142,6 +146,28 @@ int32_t tune_engine(trtx_engine* e) {
         items.push_back(it);
     }
     if (off || items.empty()) return TRTX_OK;
+    if (!time_now) {
+        // deserializeCudaEngine: the plan's own choices, no timing.  A layer the plan says nothing about keeps its default.
+        const auto& stored = e->net->tactics;
+        for (Item& it : items) {
+            int pick = 0;
+            for (const Network::TacticEntry& te : stored) {
+                if (memcmp(te.sig, it.key.v, sizeof(te.sig)) != 0) continue;
+                const ConvTactic want{te.tac[0], te.tac[1], te.tac[2], te.tac[3], te.tac[4], te.tac[5]};
+                for (int i = 0; i < it.n; ++i)
+                    if (same(it.cand[i], want)) pick = i;
+                break;
+            }
+            conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
+            trtx_engine::TacticRecord rec;
+            rec.op = it.op;
+            rec.chosen = tactic_name(it.cand[pick]);
+            rec.dflt = tactic_name(it.cand[0]);
+            rec.candidates = it.n;
+            e->tactics.push_back(rec);
+        }
+        return TRTX_OK;
+    }
     // layers this process has already decided: same kernels as before
     bool all_known = true;
     {
@@ -302,6 +328,8 @@ int32_t tune_engine(trtx_engine* e) {
         }
     }
     std::lock_guard<std::mutex> lock(g_mu);
+    e->net->tactics.clear();
+    e->net->tactics_timed = true;
     for (Item& it : items) {
         auto found = g_choice.find(it.key);
         int pick = 0;
@@ -315,6 +343,16 @@ int32_t tune_engine(trtx_engine* e) {
             cache_append_locked(it.key, it.cand[pick]);
         }
         conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
+        {   // what goes into the plan: one entry per distinct layer signature
+            Network::TacticEntry te{};
+            memcpy(te.sig, it.key.v, sizeof(te.sig));
+            const ConvTactic& c = it.cand[pick];
+            const int32_t tv[6] = {c.bn, c.bk, c.bm, c.wsk, c.ws, c.r3};
+            memcpy(te.tac, tv, sizeof(tv));
+            bool dup = false;
+            for (const Network::TacticEntry& o : e->net->tactics) dup = dup || memcmp(o.sig, te.sig, sizeof(te.sig)) == 0;
+            if (!dup) e->net->tactics.push_back(te);
+        }
         trtx_engine::TacticRecord rec;
         rec.op = it.op;
         rec.chosen = tactic_name(it.cand[pick]);

@@ -79,6 +79,7 @@ CASES = [
 def test_chain_vs_layerwise_torch(gpu, case):
     import torch
     x, stages = _make(case, gpu, seed=hash(str(case)) & 0xFFFF)
+    capi.poison_lds()   # whatever the kernel reads from LDS without having written it is now NaN
     y = capi.conv_chain_nhwc_f16(x.to(gpu), stages)
     torch.cuda.synchronize()
     _check(y.float().cpu(), _ref_chain(x, stages), str(case))
@@ -93,6 +94,22 @@ def test_every_tile_and_fragment_count(gpu, tile, cout):
     if capi.conv_chain_plan(case[0], case[1], case[2], case[3], [3, 3], [cout, cout], [0, int(cout != 80)], tile) is None:
         pytest.skip("does not fit")
     x, stages = _make(case, gpu, seed=7)
+    capi.poison_lds()
+    y = capi.conv_chain_nhwc_f16(x.to(gpu), stages, tile=tile)
+    torch.cuda.synchronize()
+    _check(y.float().cpu(), _ref_chain(x, stages), f"tile {tile} cout {cout}")
+
+
+@pytest.mark.parametrize("tile", [(8, 16), (8, 8), (4, 8)])
+@pytest.mark.parametrize("cout", [64, 80])
+def test_three_stage_arm_at_every_tile(gpu, tile, cout):
+    """detect-head arm 3x3 -> 3x3 -> 1x1 at the tiles the launcher uses on 80x80 / 40x40 / 20x20 maps (LDS buffers of the stages alias)"""
+    import torch
+    case = (2, 27, 45, 64, [(3, cout, "silu", False), (3, cout, "silu", False), (1, cout, "none", False)])
+    if capi.conv_chain_plan(case[0], case[1], case[2], case[3], [3, 3, 1], [cout] * 3, None, tile) is None:
+        pytest.skip("does not fit")
+    x, stages = _make(case, gpu, seed=5)
+    capi.poison_lds()
     y = capi.conv_chain_nhwc_f16(x.to(gpu), stages, tile=tile)
     torch.cuda.synchronize()
     _check(y.float().cpu(), _ref_chain(x, stages), f"tile {tile} cout {cout}")
