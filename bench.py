@@ -241,7 +241,17 @@ def main():
     # Several execution contexts in flight (each on its own stream, over one set of weights) is how a throughput-oriented caller
     # drives an engine; with them the concurrency comes from whole batches overlapping, so the contexts themselves stay on their
     # caller's stream (setMaxAuxStreams(0)).  A single context instead spreads independent branches over 3 auxiliary streams.
-    plan = build(0 if n_ctx > 1 else -1)
+    def build_shared(aux):
+        """rank 0 builds (and, next to its GPU, times the kernel tactics into the plan); every rank runs THAT plan: all replicas launch the
+        same kernels and return the same bits (the optional splitter's one-off broadcast; not on the data path)"""
+        plan = build(aux) if rank == 0 else None
+        if dist:
+            box = [plan]
+            dist.broadcast_object_list(box, src=0)
+            plan = box[0]
+        return plan
+
+    plan = build_shared(0 if n_ctx > 1 else -1)
     low = engine.describe_plan(plan, lowered=True)
     eng = engine.Engine(plan)
 
@@ -341,7 +351,7 @@ def main():
     # after seconds of host-only set-up
     eng1 = one = None
     if n_ctx > 1:
-        eng1 = engine.Engine(build(-1))
+        eng1 = engine.Engine(build_shared(-1))
         one = make_slots(eng1, 1)
     # settle (set-up, untimed, before the W warm-up steps the contract asks for): every slot, stream and input batch has been used
     # and the clocks are up: at least 24 steps AND at least 0.4 s of back-to-back work
@@ -454,7 +464,7 @@ def main():
     # The figure the roofline is priced with: the kernels' own durations where the runtime could record them (they agree with what
     # rocprofv3 --kernel-trace reports for the same launches); otherwise the interval between the stream events around each op.
     conv_ms = conv_ms_kernel if conv_ms_kernel else conv_ms_events
-    tactic_summary["what"] = ("in-place timing of every MFMA convolution's launch configurations at deserializeCudaEngine (runtime/tune.cpp); TRTX_TUNE=0 in the environment keeps every layer on its static default" +
+    tactic_summary["what"] = ("in-place timing of every MFMA convolution's launch configurations when the plan is built (runtime/tune.cpp; the choices and the measured times travel in the plan, deserialize only applies them); TRTX_TUNE=0 keeps every layer on its static default" +
                               ("; this engine was built with setMaxAuxStreams(0) = contexts in flight: it chooses among the work-efficient configurations only" if n_ctx > 1 else ""))
     single_prof = None
     if n_ctx > 1:

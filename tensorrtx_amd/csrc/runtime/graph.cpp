@@ -610,7 +610,7 @@ std::string Network::describe_json() const {
     }
     std::ostringstream o;
     o << "{\"explicit_batch\":" << (explicit_batch ? "true" : "false") << ",\"fp16\":" << (fp16 ? "true" : "false") << ",\"int8\":" << (int8 ? "true" : "false") << ",\"max_aux_streams\":" << max_aux_streams
-      << ",\"max_batch\":" << max_batch << ",\"tensors\":[";
+      << ",\"max_batch\":" << max_batch << ",\"tactics_timed\":" << (tactics_timed ? "true" : "false") << ",\"tactics\":" << tactics.size() << ",\"tensors\":[";
     for (size_t i = 0; i < tensors.size(); ++i) {
         const auto& t = tensors[i];
         o << (i ? "," : "") << "{\"id\":" << t.id << ",\"name\":";

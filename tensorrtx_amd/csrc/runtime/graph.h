@@ -110,6 +110,7 @@ class Network {
     struct TacticEntry {
         int32_t sig[28];
         int32_t tac[6];
+        int32_t ns[2];  // what the builder measured, in nanoseconds: the chosen configuration, the default one (-1: not measured)
     };
     std::vector<TacticEntry> tactics;
     bool tactics_timed = false;  // the builder ran the timing (an empty list then means "the defaults won everywhere")

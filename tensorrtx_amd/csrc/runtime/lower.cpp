@@ -1095,11 +1095,15 @@ struct Lowerer {
     // same Cout, every intermediate tensor read by the next stage only: the C2f bottleneck (block.cpp:98-110; its shortcut adds the
     // chain's own input) and the three-convolution arms of the detect head (model.cpp:188-251).  The fused op takes the first stage's
     // place in the schedule (its only activation input is that stage's input) and the intermediate tensors lose their storage.
-    // TRTX_FUSE_CHAINS=0 keeps the layers apart (A/B measurements).
+    // OPT-IN (TRTX_FUSE_CHAINS=1): on MI355X the fused kernel is correct (bit-identical to the layer-by-layer kernels) and cuts YOLOv8n
+    // b32 from 67 to 45 launches and the arena from 277 to 197 MB, but in round 3 it is SLOWER than the implicit-GEMM launches it
+    // replaces (one context 1.73 vs 1.41 ms, three contexts 1.16 vs 0.94 ms on one box; DESIGN.md section 5 has the per-chain table and
+    // the phase stamps): at the one or two workgroups per CU its LDS plan allows, prologue, k-loop bookkeeping and the SiLU epilogues
+    // run back to back instead of under another workgroup's MFMAs.
     void fuse_conv_chains() {
         if (dt != DT_F16) return;
-        if (const char* e = getenv("TRTX_FUSE_CHAINS"))
-            if (atoi(e) == 0) return;
+        const char* fe = getenv("TRTX_FUSE_CHAINS");
+        if (!fe || atoi(fe) == 0) return;
         std::vector<int> readers(plan.tensors.size(), 0);
         auto top_of = [&](int t) {
             while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;

@@ -55,11 +55,16 @@ SigKey signature(const ConvArgs& a, int act_pair) {
     return k;
 }
 
+struct Choice {
+    ConvTactic t;
+    int32_t ns[2];  // measured: chosen, default (-1: unknown)
+};
 std::mutex g_mu;
-std::map<SigKey, ConvTactic> g_choice;  // process-wide: layer signature -> tactic in use
+std::map<SigKey, Choice> g_choice;  // process-wide: layer signature -> tactic in use (+ what it measured)
 
 // TRTX_TACTIC_CACHE=<file>: the choices outlive the process (TensorRT's ITimingCache, IBuilderConfig::setTimingCache): read once,
 // every new choice appended as one line of integers (28 signature words, 6 tactic words).  A layer found there is not timed again.
+const char kCacheHeader[] = "TRTX_TACTIC_CACHE 2";
 void cache_load_locked() {
     static bool done = false;
     if (done) return;
@@ -68,24 +73,30 @@ void cache_load_locked() {
     if (!path || !*path) return;
     FILE* f = fopen(path, "r");
     if (!f) return;
+    char head[64] = {0};
+    if (!fgets(head, sizeof head, f) || strncmp(head, kCacheHeader, strlen(kCacheHeader)) != 0) {  // another format: ignored
+        fclose(f);
+        return;
+    }
     for (;;) {
         SigKey k{};
-        int t[6];
+        int t[8];
         bool ok = true;
         for (int i = 0; i < 28 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
-        for (int i = 0; i < 6 && ok; ++i) ok = fscanf(f, "%d", &t[i]) == 1;
+        for (int i = 0; i < 8 && ok; ++i) ok = fscanf(f, "%d", &t[i]) == 1;
         if (!ok) break;
-        g_choice[k] = ConvTactic{t[0], t[1], t[2], t[3], t[4], t[5]};
+        g_choice[k] = Choice{ConvTactic{t[0], t[1], t[2], t[3], t[4], t[5]}, {t[6], t[7]}};
     }
     fclose(f);
 }
-void cache_append_locked(const SigKey& k, const ConvTactic& t) {
+void cache_append_locked(const SigKey& k, const Choice& c) {
     const char* path = getenv("TRTX_TACTIC_CACHE");
     if (!path || !*path) return;
     FILE* f = fopen(path, "a");
     if (!f) return;
+    if (ftell(f) == 0) fprintf(f, "%s\n", kCacheHeader);
     for (int i = 0; i < 28; ++i) fprintf(f, "%d ", k.v[i]);
-    fprintf(f, "%d %d %d %d %d %d\n", t.bn, t.bk, t.bm, t.wsk, t.ws, t.r3);
+    fprintf(f, "%d %d %d %d %d %d %d %d\n", c.t.bn, c.t.bk, c.t.bm, c.t.wsk, c.t.ws, c.t.r3, c.ns[0], c.ns[1]);
     fclose(f);
 }
 
@@ -151,11 +162,14 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
         const auto& stored = e->net->tactics;
         for (Item& it : items) {
             int pick = 0;
+            int32_t ns[2] = {-1, -1};
             for (const Network::TacticEntry& te : stored) {
                 if (memcmp(te.sig, it.key.v, sizeof(te.sig)) != 0) continue;
                 const ConvTactic want{te.tac[0], te.tac[1], te.tac[2], te.tac[3], te.tac[4], te.tac[5]};
                 for (int i = 0; i < it.n; ++i)
                     if (same(it.cand[i], want)) pick = i;
+                ns[0] = te.ns[0];
+                ns[1] = te.ns[1];
                 break;
             }
             conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
@@ -163,6 +177,8 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
             rec.op = it.op;
             rec.chosen = tactic_name(it.cand[pick]);
             rec.dflt = tactic_name(it.cand[0]);
+            rec.chosen_us = ns[0] >= 0 ? ns[0] * 1e-3f : -1.f;   // what the builder measured (carried by the plan)
+            rec.default_us = ns[1] >= 0 ? ns[1] * 1e-3f : -1.f;
             rec.candidates = it.n;
             e->tactics.push_back(rec);
         }
@@ -333,14 +349,20 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
     for (Item& it : items) {
         auto found = g_choice.find(it.key);
         int pick = 0;
+        int32_t ns[2] = {-1, -1};
         if (found != g_choice.end()) {
             for (int i = 0; i < it.n; ++i)
-                if (same(it.cand[i], found->second)) pick = i;
+                if (same(it.cand[i], found->second.t)) pick = i;
+            ns[0] = found->second.ns[0];
+            ns[1] = found->second.ns[1];
         } else {
             for (int i = 1; i < it.n; ++i)
                 if (it.best_ms[i] < it.best_ms[pick] && it.best_ms[i] < 0.99f * it.best_ms[0]) pick = i;
-            g_choice[it.key] = it.cand[pick];
-            cache_append_locked(it.key, it.cand[pick]);
+            ns[0] = it.best_ms[pick] < 1e29f ? (int32_t)(it.best_ms[pick] * 1e6f) : -1;
+            ns[1] = it.best_ms[0] < 1e29f ? (int32_t)(it.best_ms[0] * 1e6f) : -1;
+            const Choice c{it.cand[pick], {ns[0], ns[1]}};
+            g_choice[it.key] = c;
+            cache_append_locked(it.key, c);
         }
         conv_apply_tactic(&plan.ops[it.op].conv, it.cand[pick]);
         {   // what goes into the plan: one entry per distinct layer signature
@@ -349,6 +371,8 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
             const ConvTactic& c = it.cand[pick];
             const int32_t tv[6] = {c.bn, c.bk, c.bm, c.wsk, c.ws, c.r3};
             memcpy(te.tac, tv, sizeof(tv));
+            te.ns[0] = ns[0];
+            te.ns[1] = ns[1];
             bool dup = false;
             for (const Network::TacticEntry& o : e->net->tactics) dup = dup || memcmp(o.sig, te.sig, sizeof(te.sig)) == 0;
             if (!dup) e->net->tactics.push_back(te);
@@ -357,8 +381,8 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
         rec.op = it.op;
         rec.chosen = tactic_name(it.cand[pick]);
         rec.dflt = tactic_name(it.cand[0]);
-        rec.chosen_us = it.best_ms[pick] < 1e29f ? it.best_ms[pick] * 1e3f : -1.f;
-        rec.default_us = it.best_ms[0] < 1e29f ? it.best_ms[0] * 1e3f : -1.f;
+        rec.chosen_us = ns[0] >= 0 ? ns[0] * 1e-3f : -1.f;
+        rec.default_us = ns[1] >= 0 ? ns[1] * 1e-3f : -1.f;
         rec.candidates = it.n;
         e->tactics.push_back(rec);
         if (verbose)

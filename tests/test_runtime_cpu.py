@@ -124,9 +124,9 @@ def test_yolov8n_builder_matches_pytorch_restatement():
 def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     path, _ = synth_wts("yolov8n")
     plan = engine.build_plan("yolov8n", path, batch=32, h=640, w=640, fp16=1)
-    # layer by layer (TRTX_FUSE_CHAINS=0): Appendix C.1's 63 convolutions = 1 stem (fp32 NCHW in) + 62 MFMA implicit-GEMM; the DFL
+    # layer by layer (the default): Appendix C.1's 63 convolutions = 1 stem (fp32 NCHW in) + 62 MFMA implicit-GEMM; the DFL
     # 1x1 convs are absorbed by the fused head kernel
-    monkeypatch.setenv("TRTX_FUSE_CHAINS", "0")
+    monkeypatch.delenv("TRTX_FUSE_CHAINS", raising=False)
     low = engine.describe_plan(plan, lowered=True)
     convs = [o for o in low["ops"] if o["kind"] == "conv"]
     assert len(convs) == 63 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 62
@@ -137,9 +137,9 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
     assert sum(o["residual"] for o in convs) == 6  # bottleneck shortcuts of model.2/4/6/8
     assert low["arena_bytes"] < 450e6
-    # default: the 10 C2f bottleneck pairs (block.cpp:98-110) and the 6 three-convolution arms of the detect head
+    # TRTX_FUSE_CHAINS=1 (opt-in): the 10 C2f bottleneck pairs (block.cpp:98-110) and the 6 three-convolution arms of the detect head
     # (model.cpp:188-251) run as fused chains: 38 of the 63 convolutions in 16 launches, 45 launches per step
-    monkeypatch.delenv("TRTX_FUSE_CHAINS")
+    monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
     fused = engine.describe_plan(plan, lowered=True)
     chains = [o for o in fused["ops"] if o["kind"] == "conv_chain"]
     assert len(fused["ops"]) == 45 and len(chains) == 16
@@ -191,7 +191,8 @@ def test_retinaface_builder_matches_pytorch_restatement():
     assert np.allclose(out[0, 1:1 + n * 15], dec[0, 1:1 + n * 15], rtol=1e-3, atol=1e-2)
 
 
-def test_retinaface_lowering_at_config4_size():
+def test_retinaface_lowering_at_config4_size(monkeypatch):
+    monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
     path, _ = synth_wts("retinaface_r50")
     plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280)
     low = engine.describe_plan(plan, lowered=True)

@@ -35,7 +35,7 @@ def run(env):
 
 ref = run({"TRTX_FUSE_CHAINS": "0"})
 print("unfused: decode counts", ref["output"].reshape(B, -1)[:, 0])
-for label, env in [("all", {})] + [(f"chain {i}", {"TRTX_FUSE_CHAINS_MASK": hex(1 << i)}) for i in range(16)]:
+for label, env in [("all", {"TRTX_FUSE_CHAINS": "1"})] + [(f"chain {i}", {"TRTX_FUSE_CHAINS": "1", "TRTX_FUSE_CHAINS_MASK": hex(1 << i)}) for i in range(16)]:
     got = run(env)
     d = {n: float(np.nanmax(np.abs(got[n] - ref[n]))) if np.isfinite(got[n]).all() else float("nan") for n in got if n.startswith("head")}
     nan = {n: int((~np.isfinite(got[n])).sum()) for n in got if n.startswith("head")}
