@@ -783,24 +783,28 @@ class IExecutionContext {
 class ICudaEngine {
    public:
     explicit ICudaEngine(trtx_engine* e) : mE(e) {}
+    // An engine that holds its plan and materialises on the device at first use.  What IBuilder::buildEngineWithConfig hands out on a
+    // machine without a HIP device, so that the reference's build flow createEngine(...) -> engine->serialize() -> write file
+    // (resnet/resnet50.cpp:231-246, retinaface/retina_r50.cpp:244-262, rcnn/rcnn.cpp:310-326) works where engines are only built.
+    ICudaEngine(const void* plan, size_t size) : mE(nullptr), mPlan(static_cast<const uint8_t*>(plan), static_cast<const uint8_t*>(plan) + size) {}
     virtual ~ICudaEngine() { trtx_engine_destroy(mE); }
     void destroy() noexcept { delete this; }
     IExecutionContext* createExecutionContext() noexcept {
         trtx_context* c = nullptr;
-        if (trtx_context_create(mE, &c) != TRTX_OK) return nullptr;
+        if (trtx_context_create(eng(), &c) != TRTX_OK) return nullptr;
         return new IExecutionContext(c, this);
     }
-    int32_t getNbBindings() const noexcept { return trtx_engine_nb_bindings(mE); }
-    int32_t getBindingIndex(const char* name) const noexcept { return trtx_engine_binding_index(mE, name); }
-    const char* getBindingName(int32_t i) const noexcept { return trtx_engine_binding_name(mE, i); }
-    bool bindingIsInput(int32_t i) const noexcept { return trtx_engine_binding_is_input(mE, i) != 0; }
+    int32_t getNbBindings() const noexcept { return trtx_engine_nb_bindings(eng()); }
+    int32_t getBindingIndex(const char* name) const noexcept { return trtx_engine_binding_index(eng(), name); }
+    const char* getBindingName(int32_t i) const noexcept { return trtx_engine_binding_name(eng(), i); }
+    bool bindingIsInput(int32_t i) const noexcept { return trtx_engine_binding_is_input(eng(), i) != 0; }
     Dims getBindingDimensions(int32_t i) const noexcept {
         trtx_dims d{};
-        trtx_engine_binding_dims(mE, i, &d);
+        trtx_engine_binding_dims(eng(), i, &d);
         return shim::from_c(d);
     }
     DataType getBindingDataType(int32_t) const noexcept { return DataType::kFLOAT; }
-    int32_t getMaxBatchSize() const noexcept { return trtx_engine_max_batch(mE); }
+    int32_t getMaxBatchSize() const noexcept { return trtx_engine_max_batch(eng()); }
     int32_t getNbIOTensors() const noexcept { return getNbBindings(); }
     const char* getIOTensorName(int32_t i) const noexcept { return getBindingName(i); }
     DataType getTensorDataType(const char*) const noexcept { return DataType::kFLOAT; }
@@ -809,15 +813,21 @@ class ICudaEngine {
         const int32_t i = getBindingIndex(name);
         return i < 0 ? TensorIOMode::kNONE : (bindingIsInput(i) ? TensorIOMode::kINPUT : TensorIOMode::kOUTPUT);
     }
-    size_t getDeviceMemorySize() const noexcept { return trtx_engine_device_memory(mE); }
+    size_t getDeviceMemorySize() const noexcept { return trtx_engine_device_memory(eng()); }
     IHostMemory* serialize() const noexcept {
         trtx_hostmem* m = nullptr;
+        if (!mE && !mPlan.empty()) return trtx_hostmem_create(mPlan.data(), mPlan.size(), &m) == TRTX_OK ? new IHostMemory(m) : nullptr;
         return trtx_engine_serialize(mE, &m) == TRTX_OK ? new IHostMemory(m) : nullptr;
     }
-    trtx_engine* handle() const noexcept { return mE; }
+    trtx_engine* handle() const noexcept { return eng(); }
 
    private:
-    trtx_engine* mE;
+    trtx_engine* eng() const noexcept {
+        if (!mE && !mPlan.empty() && trtx_engine_deserialize(mPlan.data(), mPlan.size(), &mE) != TRTX_OK) mE = nullptr;
+        return mE;
+    }
+    mutable trtx_engine* mE;
+    std::vector<uint8_t> mPlan;
 };
 
 class IRuntime {
@@ -825,6 +835,8 @@ class IRuntime {
     virtual ~IRuntime() = default;
     void destroy() noexcept { delete this; }
     ICudaEngine* deserializeCudaEngine(const void* blob, size_t size, void* /*pluginFactory*/ = nullptr) noexcept {
+        if (trtx_device_count() < 1) return new ICudaEngine(blob, size);  // build-only machine: the engine keeps its plan (serialize() works,
+                                                                          // createExecutionContext fails: there is no CPU fallback)
         trtx_engine* e = nullptr;
         if (trtx_engine_deserialize(blob, size, &e) != TRTX_OK) return nullptr;
         return new ICudaEngine(e);
@@ -882,6 +894,7 @@ class IBuilder {
     ICudaEngine* buildEngineWithConfig(INetworkDefinition& net, IBuilderConfig& cfg) noexcept {
         std::unique_ptr<IHostMemory> m(buildSerializedNetwork(net, cfg));
         if (!m) return nullptr;
+        if (trtx_device_count() < 1) return new ICudaEngine(m->data(), m->size());  // build-only machine: the engine keeps its plan
         IRuntime rt;
         return rt.deserializeCudaEngine(m->data(), m->size());
     }

@@ -473,6 +473,8 @@ int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_hostmem** o
 const void* trtx_hostmem_data(const trtx_hostmem* m);
 size_t trtx_hostmem_size(const trtx_hostmem* m);
 void trtx_hostmem_destroy(trtx_hostmem* m);
+/* a host-memory object holding a copy of `size` bytes (the shim's ICudaEngine::serialize on a machine where engines are only built) */
+int32_t trtx_hostmem_create(const void* data, size_t size, trtx_hostmem** out);
 /* JSON description of a serialized plan: network definition with weight offsets into the plan
  * (used by the test oracle's graph interpreter) and, with lowered != 0, the fused kernel schedule,
  * buffer plan and FLOP/byte counts the engine would execute.  Caller frees with trtx_string_free. */

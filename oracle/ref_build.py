@@ -46,6 +46,8 @@ REGIONS = [
 PATCHES = {
     # clang-format split the kernel-launch chevrons (`<< <` ... `>> >`); nvcc tolerates that, hipcc does not
     "*": [(r"<<\s+<", "<<<"), (r">>\s+>", ">>>")],
+    # the file's own, documented precision switch ("set USE_INT8 or USE_FP16 or USE_FP32"): the INT8 default needs calibration images
+    "retinaface/retina_r50.cpp": [(r"#define USE_INT8", "#define USE_FP16")],
 }
 
 # family -> (sources, extra include dirs relative to the reference, headers that need a patched copy)
@@ -57,6 +59,23 @@ FAMILIES = {
     "rcnn_plugins": (["rcnn/RpnDecode.cu", "rcnn/RpnNms.cu", "rcnn/RoiAlign.cu", "rcnn/PredictorDecode.cu", "rcnn/BatchedNms.cu",
                       "rcnn/MaskRcnnInference.cu"], ["rcnn"], []),
 }
+
+
+# Reference network BUILDERS (plain consumers of the nvinfer1 API), compiled unmodified against include/NvInfer.h and linked with
+# libtrtx_hip.so: name -> (sources, include dirs, harness under oracle/ref_harness/, extra -D flags).  tests/test_ref_builders.py requires
+# the product's own host builders (tensorrtx_amd/host/*.cpp) to emit the same networks.
+BUILDERS = {
+    # yololayer.cu comes along because yololayer.h registers the plugin creator in every TU that includes it (block.cpp does)
+    "yolov8": (["yolov8/src/block.cpp", "yolov8/src/model.cpp", "yolov8/plugin/yololayer.cu"], ["yolov8/include", "yolov8/plugin"], "build_yolov8.cpp", []),
+    # sample programs whose builder shares a file with main(): the harness includes the (generated copy of the) .cpp with main renamed
+    "lenet": (["lenet/lenet.cpp"], ["lenet"], "build_lenet.cpp", []),
+    "resnet50": (["resnet/resnet50.cpp"], ["resnet"], "build_resnet50.cpp", []),
+    "retinaface": (["retinaface/retina_r50.cpp", "retinaface/decode.cu"], ["retinaface"], "build_retinaface.cpp", []),
+    "rcnn": (["rcnn/rcnn.cpp", "rcnn/RpnDecode.cu", "rcnn/RpnNms.cu", "rcnn/RoiAlign.cu", "rcnn/PredictorDecode.cu", "rcnn/BatchedNms.cu",
+              "rcnn/MaskRcnnInference.cu"], ["rcnn"], "build_rcnn.cpp", []),
+}
+# sources that a harness #includes (they carry a main()): generated like the others, not compiled on their own
+INCLUDED_BY_HARNESS = {"lenet/lenet.cpp", "resnet/resnet50.cpp", "retinaface/retina_r50.cpp", "rcnn/rcnn.cpp"}
 
 
 def _patched(rel):
@@ -132,6 +151,34 @@ def build_family(name):
     return so
 
 
+def build_builder(name):
+    srcs, incs, harness, defs = BUILDERS[name]
+    so = os.path.join(OUT, "libref_build_%s.so" % name)
+    gdir = os.path.join(GEN, "build_" + name)
+    gen_srcs = []
+    for rel in srcs:
+        dst = os.path.join(gdir, os.path.basename(rel))
+        _write_if_changed(dst, "// generated from %s by oracle/ref_build.py (lexical patches only; not tracked)\n" % rel + _patched(rel))
+        if rel not in INCLUDED_BY_HARNESS:
+            gen_srcs.append(dst)
+    hsrc = os.path.join(HERE, "ref_harness", harness)
+    deps = [os.path.join(gdir, os.path.basename(r)) for r in srcs] + [hsrc, os.path.join(HERE, "ref_harness", "build_include_main.h"),
+            os.path.join(ROOT, "include", "NvInfer.h"), os.path.join(HERE, "ref_compat", "ref_prelude.h"),
+            os.path.join(HERE, "ref_compat", "opencv2", "opencv.hpp")]
+    if not _newer(so, deps):
+        return so
+    lib_dir = os.path.join(ROOT, "tensorrtx_amd", "lib")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-w",
+           "-include", os.path.join(HERE, "ref_compat", "ref_prelude.h"), "-I" + gdir, "-I" + os.path.join(HERE, "ref_compat"),
+           "-I" + os.path.join(HERE, "ref_harness"), "-I" + os.path.join(ROOT, "include")] + ["-D" + d for d in defs]
+    cmd += ["-I" + os.path.join(REF, i) for i in incs]
+    for s_ in gen_srcs + [hsrc]:
+        cmd += ["-x", "hip", s_]
+    cmd += ["-L" + lib_dir, "-ltrtx_hip", "-Wl,-rpath,$ORIGIN/../../tensorrtx_amd/lib", "-o", so]
+    subprocess.check_call(cmd)
+    return so
+
+
 def build_all(verbose=False):
     if not os.path.isdir(REF):
         if verbose:
@@ -141,6 +188,8 @@ def build_all(verbose=False):
     build_host()
     for name in FAMILIES:
         build_family(name)
+    for name in BUILDERS:
+        build_builder(name)
     return True
 
 

@@ -274,7 +274,7 @@ def poison_lds():
 
 
 def conv_chain_plan(N, H, W, Cin, ks, couts, residuals=None, tile=(0, 0)):
-    """(tile_h, tile_w, LDS bytes, weight-ring stages) the chain launcher would use, or None when the chain is unsupported. Host only."""
+    """(tile_h, tile_w, LDS bytes, k-steps per weight-ring slot; 0 = weights resident) the chain launcher would use, or None when the chain is unsupported. Host only."""
     n = len(ks)
     arr = ctypes.c_int32 * n
     out = (ctypes.c_int32 * 4)()

@@ -409,6 +409,13 @@ trtx_hostmem* trtx_hostmem_from(std::vector<uint8_t>&& v) {
     return m;
 }
 
+extern "C" int32_t trtx_hostmem_create(const void* data, size_t size, trtx_hostmem** out) {
+    if (!out || (!data && size)) return TRTX_ERR_INVALID;
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    *out = trtx_hostmem_from(std::vector<uint8_t>(p, p + size));
+    return TRTX_OK;
+}
+
 extern "C" void trtx_string_free(char* s) { free(s); }
 
 extern "C" int32_t trtx_plan_describe(const void* plan_data, size_t size, int32_t lowered, char** json_out) {

@@ -71,8 +71,15 @@ inline nvinfer1::Weights noWeights() { return nvinfer1::Weights{nvinfer1::DataTy
 // BatchNorm as an IScaleLayer, folded on the host exactly like the reference's addBatchNorm2d
 // (yolov8/src/block.cpp:45-77, resnet/resnet50.cpp:77-109): scale = g/sqrt(var+eps), shift = b - mean*scale.
 // The temporary blobs are stashed in the map so the final freeWeights releases them.
+//
+// `sqrt_in_double`: the reference writes an UNQUALIFIED sqrt(var[i] + eps) on floats.  yolov8/src/block.cpp includes <math.h> (:3), where
+// libstdc++ brings the float overload into the global namespace, so its fold is float arithmetic throughout.  resnet/resnet50.cpp (:10)
+// and retinaface/common.hpp include only <cmath>, which leaves just the C library's ::sqrt(double) visible there: the sum var+eps is
+// formed in float, but the root, the division and (for the shift) the subtraction run in double and round to float once, on the store.
+// The two differ in the last place of ~60 % of the folded values; the reference's own sources compiled against this shim
+// (oracle/ref_build.py, tests/test_ref_builders.py) are what pins which one each model takes.
 inline nvinfer1::IScaleLayer* addBatchNorm2d(nvinfer1::INetworkDefinition* network, WeightMap& m, nvinfer1::ITensor& input,
-                                             const std::string& lname, float eps) {
+                                             const std::string& lname, float eps, bool sqrt_in_double = false) {
     const float* gamma = static_cast<const float*>(need(m, lname + ".weight").values);
     const float* beta = static_cast<const float*>(need(m, lname + ".bias").values);
     const float* mean = static_cast<const float*>(need(m, lname + ".running_mean").values);
@@ -82,8 +89,14 @@ inline nvinfer1::IScaleLayer* addBatchNorm2d(nvinfer1::INetworkDefinition* netwo
     float* sh = static_cast<float*>(std::malloc(sizeof(float) * len));
     float* pw = static_cast<float*>(std::malloc(sizeof(float) * len));
     for (int64_t i = 0; i < len; ++i) {
-        sc[i] = gamma[i] / std::sqrt(var[i] + eps);
-        sh[i] = beta[i] - mean[i] * gamma[i] / std::sqrt(var[i] + eps);
+        if (sqrt_in_double) {
+            const double root = std::sqrt(static_cast<double>(var[i] + eps));
+            sc[i] = static_cast<float>(gamma[i] / root);
+            sh[i] = static_cast<float>(beta[i] - mean[i] * gamma[i] / root);
+        } else {
+            sc[i] = gamma[i] / std::sqrt(var[i] + eps);
+            sh[i] = beta[i] - mean[i] * gamma[i] / std::sqrt(var[i] + eps);
+        }
         pw[i] = 1.0f;
     }
     using nvinfer1::DataType;

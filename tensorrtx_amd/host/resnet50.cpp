@@ -15,7 +15,7 @@ ITensor* convBn(INetworkDefinition* net, WeightMap& wm, ITensor& in, int out, in
     assert(c);
     c->setStrideNd(DimsHW{s, s});
     c->setPaddingNd(DimsHW{p, p});
-    return addBatchNorm2d(net, wm, *c->getOutput(0), bn, 1e-5f)->getOutput(0);
+    return addBatchNorm2d(net, wm, *c->getOutput(0), bn, 1e-5f, /*sqrt_in_double=*/true)->getOutput(0);
 }
 
 // resnet50.cpp:111-151

@@ -21,7 +21,7 @@ ITensor* convBn(Ctx& c, ITensor& in, int out, int k, int s, int p, const std::st
     assert(l);
     l->setStrideNd(DimsHW{s, s});
     l->setPaddingNd(DimsHW{p, p});
-    return addBatchNorm2d(c.net, c.wm, *l->getOutput(0), bn, 1e-5f)->getOutput(0);
+    return addBatchNorm2d(c.net, c.wm, *l->getOutput(0), bn, 1e-5f, /*sqrt_in_double=*/true)->getOutput(0);
 }
 ITensor* relu(Ctx& c, ITensor* t) { return c.net->addActivation(*t, ActivationType::kRELU)->getOutput(0); }
 
@@ -95,14 +95,19 @@ IHostMemory* buildRetinaFaceR50(IBuilder* builder, IBuilderConfig* config, const
     o1 = convBnRelu(c, *o1, 256, 3, 1, 1, true, "fpn.merge1");
     // SSH + heads (:178-202)
     ITensor* feats[3] = {ssh(c, *o1, "ssh1"), ssh(c, *o2, "ssh2"), ssh(c, *o3, "ssh3")};
+    // layer creation order = the reference's (:183-202): the three bbox heads, the three class heads, the three landmark heads, then
+    // one concatenation per level -- the plan of the reference's own createEngine is byte-identical (tests/test_ref_builders.py)
+    const char* kinds[3] = {"BboxHead", "ClassHead", "LandmarkHead"};
+    const int kind_ch[3] = {2 * 4, 2 * 2, 2 * 10};
+    ITensor* heads[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 3; ++l) {
+            const std::string base = std::string(kinds[k]) + "." + std::to_string(l) + ".conv1x1.";
+            heads[k][l] = net->addConvolutionNd(*feats[l], kind_ch[k], DimsHW{1, 1}, need(wm, base + "weight"), need(wm, base + "bias"))->getOutput(0);
+        }
     std::vector<ITensor*> cats;
     for (int l = 0; l < 3; ++l) {
-        const std::string s = std::to_string(l);
-        auto head = [&](const char* name, int ch) {
-            return net->addConvolutionNd(*feats[l], ch, DimsHW{1, 1}, need(wm, std::string(name) + "." + s + ".conv1x1.weight"),
-                                         need(wm, std::string(name) + "." + s + ".conv1x1.bias"))->getOutput(0);
-        };
-        ITensor* parts[] = {head("BboxHead", 8), head("ClassHead", 4), head("LandmarkHead", 20)};
+        ITensor* parts[] = {heads[0][l], heads[1][l], heads[2][l]};
         cats.push_back(net->addConcatenation(parts, 3)->getOutput(0));
     }
     auto* creator = getPluginRegistry()->getPluginCreator("Decode_TRT", "1");

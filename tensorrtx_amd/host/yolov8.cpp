@@ -200,7 +200,11 @@ IHostMemory* buildEngineYolov8Det(IBuilder* builder, IBuilderConfig* config, con
     std::vector<int> strides;
     for (ITensor* t : strideRef) strides.push_back(cfg.input_h / (int)t->getDimensions().d[1]);
 
-    std::vector<ITensor*> dets;
+    // Layers are added in the reference's own order - all three levels' convolution arms first, then the three DFL tails
+    // (model.cpp:188-251, then 263-303) - so that the plan this builder serializes is byte for byte the plan the reference's
+    // buildEngineYolov8Det produces through the same shim on the same .wts (tests/test_ref_builders.py).
+    std::vector<ITensor*> dets, cats;
+    std::vector<std::pair<ITensor*, ITensor*>> tails;
     for (int lv = 0; lv < 3; ++lv) {
         const std::string s = std::to_string(lv);
         ITensor* b = convBnSiLU(c, *feats[lv], base_in, 3, 1, 1, "model.22.cv2." + s + ".0");
@@ -215,21 +219,30 @@ IHostMemory* buildEngineYolov8Det(IBuilder* builder, IBuilderConfig* config, con
                                           need(wm, "model.22.cv3." + s + ".2.bias"));
         cls->setStrideNd(DimsHW{1, 1});
         cls->setPaddingNd(DimsHW{0, 0});
-        ITensor* cat = cat2(c, box->getOutput(0), cls->getOutput(0));
-
+        cats.push_back(cat2(c, box->getOutput(0), cls->getOutput(0)));
+    }
+    for (int lv = 0; lv < 3; ++lv) {
+        const std::string s = std::to_string(lv);
         // model.cpp:263-303: flatten the grid, split box/cls, DFL the box half, re-join
         const int grid = (cfg.input_h / strides[lv]) * (cfg.input_w / strides[lv]);
-        auto* flat = net->addShuffle(*cat);
+        auto* flat = net->addShuffle(*cats[lv]);
         flat->setReshapeDimensions(Dims2{64 + cfg.num_class, grid});
         ITensor* boxPart = net->addSlice(*flat->getOutput(0), Dims2{0, 0}, Dims2{64, grid}, Dims2{1, 1})->getOutput(0);
         ITensor* clsPart = net->addSlice(*flat->getOutput(0), Dims2{64, 0}, Dims2{cfg.num_class, grid}, Dims2{1, 1})->getOutput(0);
         ITensor* dfl = DFL(c, *boxPart, grid, "model.22.dfl.conv.weight");
         if (cfg.task == 0) {
             dets.push_back(cat2(c, dfl, clsPart));
-        } else {  // seg / pose / obb: [dfl(4), classes, cv4 branch] (model.cpp:1253-1272, 1483-1532, 2699-2718)
+        } else if (cfg.task == 2) {  // pose joins each level right after its DFL: [dfl(4), classes, keypoints] (model.cpp:1472-1531)
             ITensor* v[] = {dfl, clsPart, cv4Branch(c, *feats[lv], "model.22.cv4." + s, grid, cfg)};
             dets.push_back(net->addConcatenation(v, 3)->getOutput(0));
+        } else {  // seg / obb finish all three DFL tails first (model.cpp:1218-1250, 2662-2697)
+            tails.push_back({dfl, clsPart});
         }
+    }
+    for (size_t lv = 0; lv < tails.size(); ++lv) {  // seg / obb: [dfl(4), classes, mask coefficients | angle] (model.cpp:1253-1272, 2699-2718)
+        const int grid = (cfg.input_h / strides[lv]) * (cfg.input_w / strides[lv]);
+        ITensor* v[] = {tails[lv].first, tails[lv].second, cv4Branch(c, *feats[lv], "model.22.cv4." + std::to_string(lv), grid, cfg)};
+        dets.push_back(net->addConcatenation(v, 3)->getOutput(0));
     }
     if (cfg.mark_heads)
         for (size_t i = 0; i < dets.size(); ++i) {
