@@ -1054,9 +1054,11 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
     if (!conv_igemm_supported(a)) return 0;
     const bool fp16 = !a.in_i8 && !a.out_i8 && !a.res_i8;
     const bool ws_ok = fp16 && conv_ws_supported(a);
-    // 0: the default
+    // 0: the default.  Work-efficient sets (engines whose contexts share the chip) never split K over the waves, not even as the
+    // starting point: measured on YOLOv8n b32 with three contexts in flight it is worth nothing there (33.0k img/s with, 33.1k without,
+    // two runs each on one box), and "one summation order per plan" is the simpler contract.
     if (ws_ok) push(a.bn, a.bk, 128, 1, 2);
-    else push(a.bn, a.bk, 128, wsk_default(a) ? 2 : 1, 1);
+    else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only) ? 2 : 1, 1);
     const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
     static const int bns[5] = {128, 80, 64, 32, 16};
     for (int bi = 0; bi < 5; ++bi) {

@@ -196,25 +196,45 @@ extern "C" int32_t trtx_batch_preprocess(const void* const* src_host, const int*
                                          int dst_h, hipStream_t stream) {
     if (!g_pre) return TRTX_ERR_STATE;
     if (!src_host || batch < 1 || batch > (int)g_pre->ring.size() || batch > kMaxBatch) return TRTX_ERR_INVALID;
+    for (int i = 0; i < batch; ++i)   // refuse before any ring slot is touched
+        if (!src_host[i] || src_w[i] < 1 || src_h[i] < 1 || (size_t)src_w[i] * src_h[i] * 3 > g_pre->max_bytes) return TRTX_ERR_INVALID;
     std::vector<const void*> dev(batch);
+    const size_t ring = g_pre->ring.size(), first = g_pre->next;
+    int touched = 0;
+    // A failure half way leaves slots whose `consumed` event belongs to an older use: waiting on it would not wait for the copies
+    // issued here.  So the failing call drains the copy stream itself and hands the slots back unused.
+    auto give_up = [&](int32_t st) {
+        (void)hipStreamSynchronize(g_pre->copy_stream);
+        (void)hipGetLastError();
+        for (int i = 0; i < touched; ++i) g_pre->ring[(first + i) % ring].used = false;
+        return st;
+    };
+#define TRTX_PRE_TRY(expr)                                   \
+    do {                                                     \
+        if ((expr) != hipSuccess) return give_up(TRTX_ERR_HIP); \
+    } while (0)
     for (int i = 0; i < batch; ++i) {
         const size_t bytes = (size_t)src_w[i] * src_h[i] * 3;
-        if (bytes > g_pre->max_bytes) return TRTX_ERR_INVALID;
         Stage& s = g_pre->ring[g_pre->next];
-        g_pre->next = (g_pre->next + 1) % g_pre->ring.size();
-        if (s.used) TRTX_HIP_TRY(hipEventSynchronize(s.consumed));  // the warp that read this slot last has finished
-        memcpy(s.host, src_host[i], bytes);
-        TRTX_HIP_TRY(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, g_pre->copy_stream));
-        TRTX_HIP_TRY(hipEventRecord(s.copied, g_pre->copy_stream));
-        TRTX_HIP_TRY(hipStreamWaitEvent(stream, s.copied, 0));
+        g_pre->next = (g_pre->next + 1) % ring;
+        ++touched;
+        if (s.used) TRTX_PRE_TRY(hipEventSynchronize(s.consumed));  // the warp that read this slot last has finished
         s.used = true;
+        memcpy(s.host, src_host[i], bytes);
+        TRTX_PRE_TRY(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, g_pre->copy_stream));
+        TRTX_PRE_TRY(hipEventRecord(s.copied, g_pre->copy_stream));
+        TRTX_PRE_TRY(hipStreamWaitEvent(stream, s.copied, 0));
         dev[i] = s.dev;
     }
     const int32_t st = trtx_letterbox_batch(dev.data(), src_w, src_h, batch, dst, dst_w, dst_h, stream);
-    if (st != TRTX_OK) return st;
+    if (st != TRTX_OK) return give_up(st);
     for (int i = 0; i < batch; ++i) {
-        Stage& s = g_pre->ring[(g_pre->next + g_pre->ring.size() - batch + i) % g_pre->ring.size()];
-        TRTX_HIP_TRY(hipEventRecord(s.consumed, stream));
+        Stage& s = g_pre->ring[(first + i) % ring];
+        if (hipEventRecord(s.consumed, stream) != hipSuccess) {   // the warp is enqueued: wait for it, then the slots are free
+            (void)hipStreamSynchronize(stream);
+            return give_up(TRTX_ERR_HIP);
+        }
     }
+#undef TRTX_PRE_TRY
     return TRTX_OK;
 }

@@ -263,21 +263,38 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
     // ---- phase 1, every cell: the cell can only survive if some sigmoid(logit) >= 0.1, i.e. some logit >= -2.1972.  The
     // maximum of the raw fp16 logits (exact, packed max, no exp) settles that; possible survivors are compacted into a
     // list so that the expensive exact pass below runs on dense lanes instead of a few lanes of every wave.
+    // The class logits are read by the WAVE, not by the cell's own thread: consecutive lanes take consecutive 16-byte pieces of
+    // the 64 cells of the wave (a cell's logits are classes/8 pieces in a row), so one load instruction touches ~15 cache lines
+    // instead of 64 (one per lane, 288 bytes apart) - this pass is what the kernel's time is.  A piece whose packed maximum
+    // passes the test raises its cell's flag in LDS; NaN pieces do not, exactly like NaN fails 'pr > best' in the scan.
+    s_list[threadIdx.x] = 0;   // phase 1 borrows the list as the per-cell flags (same-value races only)
+    __syncthreads();
+    {
+        const int wave0 = threadIdx.x & ~63, lane = threadIdx.x & 63;
+        const int pieces = classes >> 3;                 // classes % 8 == 0 on this path
+        const int g0 = blockIdx.x * 256 + wave0;
+        int cells_here = total_cells - g0;
+        cells_here = cells_here > 64 ? 64 : cells_here;
+        const int n = cells_here * pieces;
+        for (int j = lane; j < n; j += 64) {
+            const int c = j / pieces, q = j - c * pieces;
+            half8_t v = *reinterpret_cast<const half8_t*>(cell_ptr(g0 + c) + 64 + q * 8);
+            float m = fmaxf(fmaxf(fmaxf((float)v[0], (float)v[1]), fmaxf((float)v[2], (float)v[3])),
+                            fmaxf(fmaxf((float)v[4], (float)v[5]), fmaxf((float)v[6], (float)v[7])));
+            if (m > -2.3f) s_list[wave0 + c] = 1;
+        }
+    }
+    __syncthreads();
     bool maybe = false;
     if (g < total_cells) {
-        const _Float16* cl = cell_ptr(g) + 64;
-        half8_t mx8 = *reinterpret_cast<const half8_t*>(cl);
-        for (int c0 = 8; c0 < classes; c0 += 8) mx8 = __builtin_elementwise_max(mx8, *reinterpret_cast<const half8_t*>(cl + c0));
-        float mlogit = (float)mx8[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) mlogit = fmaxf(mlogit, (float)mx8[i]);
-        maybe = mlogit > -2.3f;  // NaN logits fail this test exactly like they fail 'pr > best' in the scan
+        maybe = s_list[threadIdx.x] != 0;
         if (!maybe) {
             const size_t o = (size_t)b * total_cells + g;
             score[o] = -1.0f;
             cls_out[o] = 0;
         }
     }
+    __syncthreads();   // the flags are read; the list proper is written next
     {
         const unsigned long long m = __ballot(maybe);
         int base = 0;

@@ -118,7 +118,20 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
     hipStream_t const user_stream = stream;
     const bool lanes = !prof && !c->observer && plan.num_lanes > 1;  // calibration statistics are collected on one stream
     std::vector<char> lane_started(plan.num_lanes, 0);
-    if (lanes) TRTX_HIP_TRY(hipEventRecord(c->start_event, user_stream));
+    // every failure from here on leaves through this: nothing keeps running behind the caller's back (each lane that was started joins
+    // the caller's stream) and the profiling events are released
+    auto bail = [&](int32_t st) {
+        (void)hipGetLastError();
+        if (lanes)
+            for (int l = 1; l < plan.num_lanes; ++l)
+                if (lane_started[l] && hipEventRecord(c->lane_done[l], c->lane_stream[l]) == hipSuccess)
+                    (void)hipStreamWaitEvent(user_stream, c->lane_done[l], 0);
+        for (auto& ev : evs) (void)hipEventDestroy(ev);
+        evs.clear();
+        free_probes();
+        return st;
+    };
+    if (lanes && hipEventRecord(c->start_event, user_stream) != hipSuccess) return bail(TRTX_ERR_HIP);
     for (size_t k = 0; k < plan.ops.size(); ++k) {
         const POp& op = plan.ops[k];
         hipStream_t stream = user_stream;  // shadows the parameter: the stream THIS op is issued on
@@ -126,11 +139,12 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
             if (op.lane > 0) {
                 stream = c->lane_stream[op.lane];
                 if (!lane_started[op.lane]) {
-                    TRTX_HIP_TRY(hipStreamWaitEvent(stream, c->start_event, 0));
+                    if (hipStreamWaitEvent(stream, c->start_event, 0) != hipSuccess) return bail(TRTX_ERR_HIP);
                     lane_started[op.lane] = 1;
                 }
             }
-            for (int d : op.wait_ops) TRTX_HIP_TRY(hipStreamWaitEvent(stream, c->op_event[d], 0));
+            for (int d : op.wait_ops)
+                if (hipStreamWaitEvent(stream, c->op_event[d], 0) != hipSuccess) return bail(TRTX_ERR_HIP);
         }
         const PTensor& t0 = plan.tensors[op.in.empty() ? op.out[0] : op.in[0]];
         const PTensor& to = plan.tensors[op.out[0]];
@@ -342,15 +356,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         if (st != TRTX_OK) {
             fprintf(stderr, "[trtx_hip] op %zu (%s, %s) failed: %s\n", k, op_kind_name(op.kind), op.name.c_str(),
                     trtx_status_string(st));
-            // leave nothing running behind the caller's back: every lane that was started joins the caller's stream, and the
-            // profiling events are released
-            if (lanes)
-                for (int l = 1; l < plan.num_lanes; ++l)
-                    if (lane_started[l] && hipEventRecord(c->lane_done[l], c->lane_stream[l]) == hipSuccess)
-                        (void)hipStreamWaitEvent(user_stream, c->lane_done[l], 0);
-            for (auto& ev : evs) (void)hipEventDestroy(ev);
-            free_probes();
-            return st;
+            return bail(st);
         }
         if (c->observer) {  // INT8 calibration: |x| maximum or histogram of every fp16 NHWC tensor this op wrote, per owning storage
             for (int t : op.out) {
@@ -362,20 +368,20 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     st = nhwc_absmax_f16(R.ptr(t), pixels, pt.C, pt.ld, ob.d_max + pt.storage, stream);
                 else if (ob.mode == 2 && ob.range[pt.storage] > 0.f)
                     st = nhwc_hist_f16(R.ptr(t), pixels, pt.C, pt.ld, ob.range[pt.storage], ob.d_hist + (size_t)pt.storage * kCalibBins, stream);
-                if (st != TRTX_OK) return st;
+                if (st != TRTX_OK) return bail(st);
             }
         }
-        if (prof) TRTX_HIP_TRY(hipEventRecord(evs[k + 1], stream));
-        if (lanes && op.signal) TRTX_HIP_TRY(hipEventRecord(c->op_event[k], stream));
+        if (prof && hipEventRecord(evs[k + 1], stream) != hipSuccess) return bail(TRTX_ERR_HIP);
+        if (lanes && op.signal && hipEventRecord(c->op_event[k], stream) != hipSuccess) return bail(TRTX_ERR_HIP);
     }
     if (lanes)
         for (int l = 1; l < plan.num_lanes; ++l)
             if (lane_started[l]) {  // join: the caller's stream continues after every lane has drained
-                TRTX_HIP_TRY(hipEventRecord(c->lane_done[l], c->lane_stream[l]));
-                TRTX_HIP_TRY(hipStreamWaitEvent(user_stream, c->lane_done[l], 0));
+                if (hipEventRecord(c->lane_done[l], c->lane_stream[l]) != hipSuccess || hipStreamWaitEvent(user_stream, c->lane_done[l], 0) != hipSuccess)
+                    return bail(TRTX_ERR_HIP);
             }
     if (prof) {
-        TRTX_HIP_TRY(hipStreamSynchronize(stream));
+        if (hipStreamSynchronize(stream) != hipSuccess) return bail(TRTX_ERR_HIP);
         for (size_t k = 0; k < plan.ops.size(); ++k) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, evs[k], evs[k + 1]);

@@ -154,7 +154,13 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
     std::vector<void*> owned;
     std::vector<const char*> in_names;
     std::vector<int> in_slots;
+    hipStream_t stream = nullptr;
     auto cleanup = [&]() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
         for (void* p : owned) (void)hipFree(p);
         if (obs.d_max) (void)hipFree(obs.d_max);
         if (obs.d_hist) (void)hipFree(obs.d_hist);
@@ -184,7 +190,6 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
             bindings[b] = p;
         }
     }
-    hipStream_t stream = nullptr;
     CAL_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     std::vector<void*> in_ptrs(in_names.size(), nullptr);
     std::vector<unsigned> h_max(ns);
@@ -257,7 +262,6 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
             net->tensor_scale[t.net_tensor] = thr / 127.0f;
         }
     }
-    (void)hipStreamDestroy(stream);
     cleanup();
 #undef CAL_TRY
     return st;

@@ -1033,7 +1033,8 @@ struct Lowerer {
     // head, layout conversions, plugins, depth-to-space ...) keeps the tensor in fp16, and a convolution simply dequantises /
     // requantises at that boundary in its epilogue.  The scale is a property of the OWNER, so all producers of a concat
     // buffer quantise to the same scale (TensorRT reaches the same end by forcing equal scales on concat inputs).
-    void assign_int8() {
+    // `veto`: owners that an earlier attempt put in int8 and finalize's kernel choice then could not serve (see finalize()).
+    void assign_int8(const std::vector<char>& veto) {
         if (!net.int8 || dt != DT_F16) return;
         const int nt = (int)plan.tensors.size();
         auto top = [&](int t) {
@@ -1043,7 +1044,7 @@ struct Lowerer {
         std::vector<char> cand(nt, 0);
         for (const PTensor& t : plan.tensors)
             if (t.parent < 0 && t.layout == LAY_NHWC && t.dtype == DT_F16 && t.net_tensor >= 0 && t.net_tensor < (int)net.tensor_scale.size() &&
-                net.tensor_scale[t.net_tensor] > 0.f && t.C % 16 == 0 && t.nmul == 1 && !is_binding_tensor(t.id))
+                net.tensor_scale[t.net_tensor] > 0.f && t.C % 16 == 0 && t.nmul == 1 && !is_binding_tensor(t.id) && !veto[t.id])
                 cand[t.id] = 1;
         auto view_ok = [&](int t) {
             int off = 0;
@@ -1217,8 +1218,126 @@ struct Lowerer {
         }
     }
 
+    // Which kernel runs a convolution, given the (resolved) strides / offsets and the dtypes of the tensors it touches: fills op.conv
+    // and sets op.igemm when the implicit-GEMM MFMA kernel takes it (the direct kernel otherwise).  ONE predicate for finalize() and
+    // for the int8 assignment, which may only put a tensor in int8 if every convolution touching it gets the MFMA path.
+    bool choose_conv_kernel(POp& op) {
+        ConvArgs& a = op.conv;
+        const PTensor& ti = plan.tensors[op.in[0]];
+        const PTensor& to = plan.tensors[op.out[0]];
+        a.ld_in = ti.ld;
+        a.ld_out = to.ld;
+        a.ld_res = op.in.size() > 1 ? plan.tensors[op.in[1]].ld : 0;
+        a.K = a.kh * a.kw * (a.Cin / a.groups);
+        a.Cout_pad = a.Cout;
+        a.Kpad = a.K;
+        op.igemm = false;
+        if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
+            int cin_eff = a.Cin;
+            bool ok = true;
+            if (cin_eff % 8) {
+                // padded channels are zero only for a freshly converted, un-aliased tensor
+                const PTensor& own = plan.tensors[ti.parent >= 0 ? ti.parent : ti.id];
+                ok = ti.parent < 0 && own.pad_zeroed;
+                cin_eff = (a.Cin + 7) / 8 * 8;
+            }
+            ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0;
+            const bool in8 = ti.dtype == DT_I8, out8 = to.dtype == DT_I8;
+            const bool res8 = op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8;
+            if (in8) ok = ok && a.Cin % 16 == 0 && ti.rcoff % 16 == 0 && ti.ld % 16 == 0;
+            // output side: 16-byte stores when everything is a multiple of 8, element-wise stores otherwise
+            bool vec_out = a.Cout % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
+            if (op.in.size() > 1) {
+                const PTensor& tr = plan.tensors[op.in[1]];
+                vec_out = vec_out && tr.rcoff % 8 == 0 && tr.ld % 8 == 0;
+            }
+            // tiny reductions (K < 32, e.g. the DFL 1x1) stay on the direct kernel
+            ok = ok && a.kh * a.kw * cin_eff >= 32;
+            if (ok) {
+                ConvArgs t = a;
+                t.scalar_out = vec_out ? 0 : 1;
+                t.Cin = cin_eff;
+                t.bn = conv_igemm_pick_bn(t.Cout);
+                t.bk = conv_igemm_pick_bk(cin_eff, t.kh * t.kw);
+                {   // few tiles + long K at the largest batch: keep 32-wide steps so the wave-split-K variant applies
+                    const long m_max = (long)(ti.nfix ? ti.nfix : plan.max_batch) * ti.nmul * t.Ho * t.Wo;
+                    const long tiles128 = (m_max + 127) / 128 * ((t.Cout + t.bn - 1) / t.bn);
+                    if (tiles128 <= 256 && (t.bn == 64 || t.bn == 80)) t.bk = 32;
+                }
+                t.CinK = conv_igemm_pick_cink(cin_eff, t.bk);  // a k-step never straddles a filter tap
+                t.K = t.kh * t.kw * t.CinK;
+                t.Kpad = (t.K + t.bk - 1) / t.bk * t.bk;
+                t.bn = conv_igemm_pick_bn(t.Cout);
+                t.Cout_pad = (t.Cout + t.bn - 1) / t.bn * t.bn;
+                if (in8) {  // int8 operands: 64-channel k-steps; the input-side geometry is handed over in 2-byte units (ConvArgs)
+                    t.bk = 32;
+                    t.in_i8 = 1;
+                    t.Cin = a.Cin / 2;
+                    t.ld_in = ti.ld / 2;
+                    t.CinK = (a.Cin + 63) / 64 * 64 / 2;
+                    t.K = t.kh * t.kw * t.CinK;
+                    t.Kpad = t.K;
+                }
+                t.out_i8 = out8 ? 1 : 0;
+                t.res_i8 = res8 ? 1 : 0;
+                t.out_inv_scale = out8 ? 1.0f / to.scale : 0.f;
+                t.res_scale = res8 ? plan.tensors[op.in[1]].scale : 0.f;
+                if (conv_igemm_supported(t)) {
+                    a = t;
+                    op.igemm = true;
+                }
+            }
+        }
+        return op.igemm;
+    }
+
     bool finalize() {
-        assign_int8();
+        // 0. view geometry (element units: independent of the dtypes assigned next)
+        for (auto& t : plan.tensors) {
+            int p = t.id, coff = 0;
+            long eoff = 0;
+            while (plan.tensors[p].parent >= 0) {
+                coff += plan.tensors[p].coff;
+                eoff += plan.tensors[p].eoff;
+                p = plan.tensors[p].parent;
+            }
+            t.rcoff = coff;
+            t.reoff = eoff;
+            t.ld = plan.tensors[p].layout == LAY_NHWC ? plan.tensors[p].Calloc : 0;
+        }
+        // kINT8: assign, then ask the kernel choice itself whether every convolution that touches an int8 tensor gets the MFMA path
+        // (K >= 32, channel / offset / stride alignment, < 2 GB images ... - conditions the assignment's own screen does not repeat).
+        // A convolution that does not takes its tensors out of the race and the assignment runs again; candidates only shrink, so
+        // this ends, with such layers in fp16 as the builder flag promises (capi.cpp: "fall back to fp16").
+        if (net.int8 && dt == DT_F16) {
+            std::vector<char> veto(plan.tensors.size(), 0);
+            auto top = [&](int t) {
+                while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
+                return t;
+            };
+            for (;;) {
+                assign_int8(veto);
+                bool again = false;
+                for (const POp& op : plan.ops) {
+                    if (op.kind != OP_CONV && op.kind != OP_DECONV) continue;
+                    bool any8 = plan.tensors[op.out[0]].dtype == DT_I8;
+                    for (int t : op.in) any8 = any8 || plan.tensors[t].dtype == DT_I8;
+                    if (!any8) continue;
+                    POp probe = op;
+                    if (op.kind == OP_CONV && choose_conv_kernel(probe)) continue;
+                    for (int t : op.in)
+                        if (plan.tensors[t].dtype == DT_I8) veto[top(t)] = 1;
+                    if (plan.tensors[op.out[0]].dtype == DT_I8) veto[top(op.out[0])] = 1;
+                    again = true;
+                }
+                if (!again) break;
+                for (PTensor& t : plan.tensors)
+                    if (t.dtype == DT_I8) {
+                        t.dtype = DT_F16;
+                        t.scale = 0.f;
+                    }
+            }
+        }
         // 1. storages for owners
         for (auto& t : plan.tensors) {
             if (t.parent >= 0 || t.storage >= 0) continue;
@@ -1228,19 +1347,11 @@ struct Lowerer {
             t.storage = (int)plan.storages.size();
             plan.storages.push_back(s);
         }
-        // 2. resolve views
+        // 2. views share their owner's storage
         for (auto& t : plan.tensors) {
-            int p = t.id, coff = 0;
-            long eoff = 0;
-            while (plan.tensors[p].parent >= 0) {
-                coff += plan.tensors[p].coff;
-                eoff += plan.tensors[p].eoff;
-                p = plan.tensors[p].parent;
-            }
+            int p = t.id;
+            while (plan.tensors[p].parent >= 0) p = plan.tensors[p].parent;
             t.storage = plan.tensors[p].storage;
-            t.rcoff = coff;
-            t.reoff = eoff;
-            t.ld = plan.tensors[p].layout == LAY_NHWC ? plan.tensors[p].Calloc : 0;
         }
         // binding storages take their size from the bound tensor
         for (size_t b = 0; b < plan.binding_ptensor.size(); ++b) {
@@ -1253,70 +1364,8 @@ struct Lowerer {
             ConvArgs& a = op.conv;
             const PTensor& ti = plan.tensors[op.in[0]];
             const PTensor& to = plan.tensors[op.out[0]];
-            a.ld_in = ti.ld;
-            a.ld_out = to.ld;
             if (op.stem && (to.ld % 8 || to.rcoff % 8)) return fail(op.name + ": stem convolution output is not 16-byte aligned");
-            a.ld_res = op.in.size() > 1 ? plan.tensors[op.in[1]].ld : 0;
-            a.K = a.kh * a.kw * (a.Cin / a.groups);
-            a.Cout_pad = a.Cout;
-            a.Kpad = a.K;
-            op.igemm = false;
-            if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
-                int cin_eff = a.Cin;
-                bool ok = true;
-                if (cin_eff % 8) {
-                    // padded channels are zero only for a freshly converted, un-aliased tensor
-                    const PTensor& own = plan.tensors[ti.parent >= 0 ? ti.parent : ti.id];
-                    ok = ti.parent < 0 && own.pad_zeroed;
-                    cin_eff = (a.Cin + 7) / 8 * 8;
-                }
-                ok = ok && ti.rcoff % 8 == 0 && ti.ld % 8 == 0;
-                const bool in8 = ti.dtype == DT_I8, out8 = to.dtype == DT_I8;
-                const bool res8 = op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8;
-                if (in8) ok = ok && a.Cin % 16 == 0 && ti.rcoff % 16 == 0 && ti.ld % 16 == 0;
-                // output side: 16-byte stores when everything is a multiple of 8, element-wise stores otherwise
-                bool vec_out = a.Cout % 8 == 0 && to.rcoff % 8 == 0 && to.ld % 8 == 0;
-                if (op.in.size() > 1) {
-                    const PTensor& tr = plan.tensors[op.in[1]];
-                    vec_out = vec_out && tr.rcoff % 8 == 0 && tr.ld % 8 == 0;
-                }
-                // tiny reductions (K < 32, e.g. the DFL 1x1) stay on the direct kernel
-                ok = ok && a.kh * a.kw * cin_eff >= 32;
-                if (ok) {
-                    ConvArgs t = a;
-                    t.scalar_out = vec_out ? 0 : 1;
-                    t.Cin = cin_eff;
-                    t.bn = conv_igemm_pick_bn(t.Cout);
-                    t.bk = conv_igemm_pick_bk(cin_eff, t.kh * t.kw);
-                    {   // few tiles + long K at the largest batch: keep 32-wide steps so the wave-split-K variant applies
-                        const long m_max = (long)(ti.nfix ? ti.nfix : plan.max_batch) * ti.nmul * t.Ho * t.Wo;
-                        const long tiles128 = (m_max + 127) / 128 * ((t.Cout + t.bn - 1) / t.bn);
-                        if (tiles128 <= 256 && (t.bn == 64 || t.bn == 80)) t.bk = 32;
-                    }
-                    t.CinK = conv_igemm_pick_cink(cin_eff, t.bk);  // a k-step never straddles a filter tap
-                    t.K = t.kh * t.kw * t.CinK;
-                    t.Kpad = (t.K + t.bk - 1) / t.bk * t.bk;
-                    t.bn = conv_igemm_pick_bn(t.Cout);
-                    t.Cout_pad = (t.Cout + t.bn - 1) / t.bn * t.bn;
-                    if (in8) {  // int8 operands: 64-channel k-steps; the input-side geometry is handed over in 2-byte units (ConvArgs)
-                        t.bk = 32;
-                        t.in_i8 = 1;
-                        t.Cin = a.Cin / 2;
-                        t.ld_in = ti.ld / 2;
-                        t.CinK = (a.Cin + 63) / 64 * 64 / 2;
-                        t.K = t.kh * t.kw * t.CinK;
-                        t.Kpad = t.K;
-                    }
-                    t.out_i8 = out8 ? 1 : 0;
-                    t.res_i8 = res8 ? 1 : 0;
-                    t.out_inv_scale = out8 ? 1.0f / to.scale : 0.f;
-                    t.res_scale = res8 ? plan.tensors[op.in[1]].scale : 0.f;
-                    if (conv_igemm_supported(t)) {
-                        a = t;
-                        op.igemm = true;
-                    }
-                }
-            }
+            choose_conv_kernel(op);
             if ((ti.dtype == DT_I8 || to.dtype == DT_I8 || (op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8)) && !op.igemm)
                 return fail(op.name + ": int8 tensor on a convolution that cannot take the MFMA path");
             const double es_in = (double)dtype_size(ti.dtype), es_out = (double)dtype_size(to.dtype);

@@ -8,6 +8,7 @@
 #include <dirent.h>
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <algorithm>
 #include <fstream>
 #include <iterator>
@@ -25,7 +26,6 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
         : batchsize_(batchsize), input_w_(input_w), input_h_(input_h), img_dir_(img_dir), calib_table_name_(calib_table_name),
           input_blob_name_(input_blob_name), read_cache_(read_cache) {
         input_count_ = (size_t)3 * input_w * input_h * batchsize;
-        (void)hipMalloc(&device_input_, input_count_ * sizeof(float));
         if (DIR* d = opendir(img_dir)) {
             while (dirent* e = readdir(d)) {
                 const std::string n = e->d_name;
@@ -34,15 +34,15 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
             closedir(d);
         }
         std::sort(img_files_.begin(), img_files_.end());
-        (void)trtx_preprocess_init(4096 * 3112, std::max(2, batchsize));  // kMaxInputImageSize of the reference's config.h
     }
     ~Int8EntropyCalibrator2() override {
-        trtx_preprocess_destroy();
-        (void)hipFree(device_input_);
+        if (owns_preprocess_) trtx_preprocess_destroy();   // never the application's own pipeline
+        if (device_input_) (void)hipFree(device_input_);
     }
     int32_t getBatchSize() const noexcept override { return batchsize_; }
     bool getBatch(void* bindings[], const char* names[], int32_t nbBindings) noexcept override {
         if (img_idx_ + batchsize_ > (int)img_files_.size()) return false;
+        if (!device_ready()) return false;
         std::vector<std::vector<unsigned char>> pix(batchsize_);
         std::vector<const void*> src(batchsize_);
         std::vector<int> ws(batchsize_), hs(batchsize_);
@@ -51,8 +51,11 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
             src[i] = pix[i].data();
         }
         img_idx_ += batchsize_;
-        if (trtx_batch_preprocess(src.data(), ws.data(), hs.data(), batchsize_, static_cast<float*>(device_input_), input_w_, input_h_, nullptr) != TRTX_OK)
+        if (const int32_t st = trtx_batch_preprocess(src.data(), ws.data(), hs.data(), batchsize_, static_cast<float*>(device_input_), input_w_, input_h_, nullptr)) {
+            fprintf(stderr, "[trtx_host] calibrator: trtx_batch_preprocess failed (%s)%s\n", trtx_status_string(st),
+                    owns_preprocess_ ? "" : " - the application's own preprocess pipeline is in use; its staging ring may be smaller than the calibration batch");
             return false;
+        }
         (void)hipDeviceSynchronize();
         for (int b = 0; b < nbBindings; ++b)
             if (input_blob_name_ == names[b]) bindings[b] = device_input_;
@@ -72,6 +75,25 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
     }
 
    private:
+    // Device buffer and the letterbox pipeline, on the first batch (a build that finds a calibration cache never gets here and needs
+    // no GPU).  trtx_preprocess_init is process-wide state: if the application has already initialised it (TRTX_ERR_STATE) its
+    // pipeline is used and left alone; only a pipeline this object created is destroyed with it.
+    bool device_ready() {
+        if (device_input_) return true;
+        if (hipMalloc(&device_input_, input_count_ * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            device_input_ = nullptr;
+            fprintf(stderr, "[trtx_host] calibrator: no device memory for a %d x 3 x %d x %d input batch\n", batchsize_, input_h_, input_w_);
+            return false;
+        }
+        const int32_t st = trtx_preprocess_init(4096 * 3112, std::max(2, batchsize_));  // kMaxInputImageSize of the reference's config.h
+        owns_preprocess_ = st == TRTX_OK;
+        if (st != TRTX_OK && st != TRTX_ERR_STATE) {
+            fprintf(stderr, "[trtx_host] calibrator: trtx_preprocess_init failed (%s)\n", trtx_status_string(st));
+            return false;
+        }
+        return true;
+    }
     // binary PPM: "P6 <w> <h> 255\n" + RGB bytes; returned as BGR rows (what cv::imread yields and the letterbox expects)
     static bool read_ppm(const std::string& path, std::vector<unsigned char>* bgr, int* w, int* h) {
         std::ifstream f(path, std::ios::binary);
@@ -92,6 +114,7 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
     std::string calib_table_name_, input_blob_name_;
     bool read_cache_;
     void* device_input_ = nullptr;
+    bool owns_preprocess_ = false;
     std::vector<char> calib_cache_;
 };
 

@@ -52,7 +52,7 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
             const char* dir = std::getenv("TRTX_CALIB_DIR");
             const char* table = std::getenv("TRTX_CALIB_TABLE");
             const std::string m0(model);
-            calibrator.reset(new trtx_host::Int8EntropyCalibrator2(1, geti(o, "w", 640), geti(o, "h", 640), dir ? dir : "./coco_calib/",
+            calibrator.reset(new trtx_host::Int8EntropyCalibrator2(geti(o, "calib_batch", 1), geti(o, "w", 640), geti(o, "h", 640), dir ? dir : "./coco_calib/",
                                                                    table ? table : "int8calib.table", m0 == "yolov8n" ? "images" : "data"));
         }
         config->setInt8Calibrator(calibrator.get());

@@ -457,3 +457,80 @@ def test_conv_chain_plans_for_the_yolov8n_chains():
     assert capi.conv_chain_plan(1, 20, 20, 64, [3, 3], [96, 96], None) is None      # Cout not instantiated
     assert capi.conv_chain_plan(1, 20, 20, 32, [3, 3], [64, 64], [0, 1]) is None    # shortcut needs Cin == Cout
     assert capi.conv_chain_plan(1, 20, 20, 64, [5, 3], [64, 64], None) is None
+
+
+def test_int8_tensor_on_a_convolution_without_the_mfma_path_falls_back_to_fp16():
+    """kINT8 promises that layers which cannot run in int8 stay in fp16.  The assignment screens by shape only; whether a convolution
+    really takes the implicit-GEMM path is decided later from strides / offsets / K.  Here a 1x1 convolution over 16 channels (K = 16:
+    the direct kernel) produces a 32-channel tensor with a calibrated scale that a 3x3 convolution consumes - the producer cannot write
+    int8, so the tensor must stay fp16 (it used to be marked int8 and the whole build then failed in finalize)."""
+    import struct
+    from tensorrtx_amd import calibrator, capi
+    L = capi.lib()
+
+    class Dims(ctypes.Structure):
+        _fields_ = [("nb", ctypes.c_int32), ("d", ctypes.c_int64 * 8)]
+
+    def dims(*v):
+        d = Dims()
+        d.nb = len(v)
+        for i, x in enumerate(v):
+            d.d[i] = x
+        return d
+
+    rng = np.random.default_rng(0)
+
+    def build(int8, cache=None):
+        b, n, m = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check = lambda st: (_ for _ in ()).throw(AssertionError(st)) if st != 0 else None
+        check(L.trtx_builder_create(ctypes.byref(b)))
+        check(L.trtx_builder_set_max_batch(b, 2))
+        check(L.trtx_builder_set_flag(b, 0, 1))
+        cal = None
+        if int8:
+            check(L.trtx_builder_set_flag(b, 1, 1))
+            cal = calibrator.Calibrator(cache=cache)
+            check(L.trtx_builder_set_int8_calibrator(b, ctypes.byref(cal.vtbl)))
+        check(L.trtx_network_create(b, 0, ctypes.byref(n)))
+        x = L.trtx_add_input(n, b"data", 0, ctypes.byref(dims(3, 32, 32)))
+
+        def conv(x, cin, cout, k):
+            w = np.ascontiguousarray(rng.normal(0, 0.1, (cout, cin, k, k)), dtype=np.float32)
+            bias = np.zeros(cout, dtype=np.float32)
+            l = L.trtx_add_convolution(n, x, cout, k, k, w.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(w.size),
+                                       bias.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cout))
+            assert l >= 0
+            pad = (ctypes.c_int32 * 2)(k // 2, k // 2)
+            check(L.trtx_layer_set_ints(n, l, 2, pad, 2))   # TRTX_PARAM_PADDING
+            r = L.trtx_add_activation(n, L.trtx_layer_output(n, l, 0), 1)
+            return L.trtx_layer_output(n, r, 0)
+
+        x = conv(x, 3, 16, 3)     # the stem
+        x = conv(x, 16, 32, 1)    # K = 16: direct kernel, cannot quantise its output
+        x = conv(x, 32, 32, 3)    # MFMA-eligible consumer
+        x = conv(x, 32, 32, 3)
+        check(L.trtx_tensor_set_name(n, x, b"out"))
+        check(L.trtx_mark_output(n, x))
+        st = L.trtx_build_serialized(b, n, ctypes.byref(m))
+        err = ctypes.string_at(ctypes.c_char_p(L.trtx_network_last_error(n))).decode() if st else ""
+        assert st == 0, err
+        L.trtx_hostmem_data.restype = ctypes.c_void_p
+        L.trtx_hostmem_size.restype = ctypes.c_size_t
+        plan = ctypes.string_at(L.trtx_hostmem_data(m), L.trtx_hostmem_size(m))
+        L.trtx_hostmem_destroy(m)
+        L.trtx_network_destroy(n)
+        L.trtx_builder_destroy(b)
+        return plan
+
+    L.trtx_network_last_error.restype = ctypes.c_void_p
+    rng = np.random.default_rng(0)
+    plan16 = build(False)
+    names = [t["name"] or f"(Unnamed Tensor* {t['id']})" for t in engine.describe_plan(plan16)["tensors"]]
+    cache = b"TRT-8601-EntropyCalibration2\n" + b"".join(f"{nm}: {struct.unpack('<I', struct.pack('<f', 0.05))[0]:08x}\n".encode() for nm in names)
+    rng = np.random.default_rng(0)
+    low = engine.describe_plan(build(True, cache), lowered=True)
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert len(convs) == 4
+    assert convs[1]["i8"] == [0, 0, 0] or convs[1]["i8"][:2] == [0, 0]      # the K = 16 layer reads and writes fp16
+    assert convs[2]["i8"][0] == 0 and convs[2]["i8"][1] == 1                 # its consumer reads fp16 and quantises for the next layer
+    assert convs[3]["i8"][0] == 1
