@@ -78,7 +78,7 @@ def _kernel_duration_from_profile(model):
         return None, None
 
 
-def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0):
+def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0, precision="fp16"):
     """The oracle (PyTorch-CPU fp32 restatement of the reference graph + C decode/NMS) timed on the host cores on a bounded
     sample of the same workload: reported next to the GPU number, never the thing measured.  The same oracle outputs are
     compared with what the GPU produced for the same images -> `parity` (what the fp16 engine is off by)."""
@@ -116,7 +116,7 @@ def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.
             "sample": f"{n} images ({nb}/iter) 640x640 fp32, PyTorch-CPU restatement of the reference graph + C decode/NMS"}
     # parity of the fp16 engine vs the fp32 oracle on those same images: head logits and decoded boxes
     logit_err = max(float((g[:nb] - h.numpy().reshape(g[:nb].shape)).__abs__().max()) for g, h in zip(gpu_heads, keep["heads"]))
-    ious, matched, total = [], 0, 0
+    ious, matched, total, loose = [], 0, 0, []
     for b in range(nb):
         nr, ng = int(keep["dec"][b, 0]), int(gpu_dec[b, 0])
         r = keep["dec"][b, 1:1 + nr * 90].reshape(nr, 90)
@@ -130,13 +130,16 @@ def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.
             iy = np.maximum(0, np.minimum(cand[:, 3], rec[3]) - np.maximum(cand[:, 1], rec[1]))
             inter = ix * iy
             iou = inter / ((cand[:, 2] - cand[:, 0]) * (cand[:, 3] - cand[:, 1]) + (rec[2] - rec[0]) * (rec[3] - rec[1]) - inter)
+            if iou.max() > 0.5:
+                loose.append(float(iou.max()))
             if iou.max() > 0.9:
                 matched += 1
                 ious.append(float(iou.max()))
+    what = "fp16 build (fp16 storage of 63 layers)" if precision == "fp16" else "int8 build (int8 activations and weights behind the first two layers, fp16 elsewhere)"
     parity = {"vs": "fp32 PyTorch-CPU oracle, same weights and images", "images": nb, "head_logit_max_abs_err": logit_err,
-              "oracle_candidates_conf>0.25": total, "matched_same_class_iou>0.9": matched,
-              "min_box_iou": min(ious) if ious else None,
-              "north_star_tolerance": "1e-4 logit / 1e-3 IoU: met by the fp32 build (tests), NOT by this fp16 build (fp16 storage of 63 layers)",
+              "oracle_candidates_conf>0.25": total, "matched_same_class_iou>0.9": matched, "matched_same_class_iou>0.5": len(loose),
+              "min_box_iou": min(ious) if ious else None, "mean_box_iou_of_iou>0.5_matches": float(np.mean(loose)) if loose else None,
+              "north_star_tolerance": "1e-4 logit / 1e-3 IoU: met by the fp32 build (tests), NOT by this " + what,
               "nms_kept_indices": "bit-exact vs the oracle on identical decode buffers (tests/test_gpu_yolo_plugins.py, test_ref_pinning.py)"}
     return base, parity
 
@@ -168,6 +171,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=7,
                     help="the W-warm-up + K-step timed leg is run this many times back to back; `value` is the MEDIAN leg (all legs are printed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of this script's control flow (ranks over gloo, rank 0 builds and broadcasts the plan, legs / barriers / "
+                         "max-over-ranks, JSON assembly) with stand-ins for every GPU object (tensorrtx_amd/dryrun.py); the line is marked dry_run and "
+                         "its numbers mean nothing")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent timing table (JSON) to this path")
     args = ap.parse_args()
 
@@ -177,24 +184,34 @@ def main():
     import numpy as np
     import torch
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run
+    if dry:
+        from tensorrtx_amd import dryrun
+        tc = dryrun.FakeCuda(world)          # stands in for torch.cuda below
+    else:
+        tc = torch.cuda
+    if not tc.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    if torch.cuda.device_count() < (local + 1):
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
+    if tc.device_count() < (local + 1):
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {tc.device_count()} GPU(s) visible")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        tc.set_device(local)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+        tc.set_device(0)
+    dev = torch.device("cpu") if dry else torch.device("cuda", tc.current_device())
+    pin = (lambda t: t) if dry else (lambda t: t.pin_memory())
 
     from tensorrtx_amd import capi, engine, replicas, synth
     from tensorrtx_amd import wts as wts_writer
@@ -226,6 +243,7 @@ def main():
         from util import synth_wts  # seeded synthetic weights through the product-side writer
         path, _ = synth_wts(args.config)
     n_ctx = max(1, args.contexts)
+    calib_cache = {}
 
     def build(aux):
         opts = dict(batch=batch, h=H, w=W, fp16=1)
@@ -234,8 +252,11 @@ def main():
         if args.precision == "int8":
             from tensorrtx_amd import calibrator
             cal_batches = [torch.from_numpy(synth.images(batch, H, W, seed=900 + k) * cfg["scale"]).to(dev) for k in range(2)]
-            with calibrator.Calibrator(batches=cal_batches, batch_size=batch).installed():
-                return engine.build_plan(args.config, path, int8=1, **opts)
+            cal = calibrator.Calibrator(batches=cal_batches, batch_size=batch, cache=calib_cache.get("text"))
+            with cal.installed():
+                plan8 = engine.build_plan(args.config, path, int8=1, **opts)
+            calib_cache.setdefault("text", cal.written_cache)   # later builds (other aux-stream settings, the parity engine) reuse the scales
+            return plan8
         return engine.build_plan(args.config, path, **opts)
 
     # Several execution contexts in flight (each on its own stream, over one set of weights) is how a throughput-oriented caller
@@ -253,34 +274,40 @@ def main():
 
     plan = build_shared(0 if n_ctx > 1 else -1)
     low = engine.describe_plan(plan, lowered=True)
-    eng = engine.Engine(plan)
+    make_engine = (lambda pl: dryrun.DryEngine(pl, engine.describe_plan)) if dry else engine.Engine
+    eng = make_engine(plan)
 
     # bindings: N_INPUT_SETS rotating input batches (resident in HBM), one set of outputs per context
-    rng_imgs = [synth.images(batch, H, W, seed=100 + 17 * rank + k) * cfg["scale"] for k in range(N_INPUT_SETS if args.config == "yolov8n" else 2)]
+    n_sets = N_INPUT_SETS if args.config == "yolov8n" else 2
+    if dry:   # one synthetic batch stands for all of them (generating 8 x 32 images is most of a dry run's time)
+        rng_imgs = [synth.images(batch, H, W, seed=100 + 17 * rank) * cfg["scale"]] * n_sets
+    else:
+        rng_imgs = [synth.images(batch, H, W, seed=100 + 17 * rank + k) * cfg["scale"] for k in range(n_sets)]
     nhwc_input = args.config == "rcnn_r50c4"  # DataPreprocess takes HWC images (rcnn.cpp:80-100)
     inputs = [torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1)) if nhwc_input else x).to(dev) for x in rng_imgs]
     in_idx = [i for i in range(eng.nb_bindings) if eng.is_input[i]][0]
-    L = capi.lib()
-    L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    L = None if dry else capi.lib()
+    if L:
+        L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
 
     class Slot:
         """One batch in flight: an execution context, its stream, its output / NMS / pinned host buffers."""
 
         def __init__(self, e, ctx):
             self.e, self.ctx = e, ctx
-            self.stream = torch.cuda.Stream()
+            self.stream = tc.Stream()
             self.stream_p = ctypes.c_void_p(self.stream.cuda_stream)
-            self.outs = {i: torch.empty(batch * int(np.prod(e.dims[i])), dtype=torch.float32, device=dev)
+            self.outs = {i: (torch.zeros if dry else torch.empty)(batch * int(np.prod(e.dims[i])), dtype=torch.float32, device=dev)
                          for i in range(e.nb_bindings) if not e.is_input[i]}
             if cfg["nms"]:
                 self.out = self.outs[e.names.index("output")].reshape(batch, 1 + 1000 * 90)
                 self.keep_idx = torch.empty((batch, 1000), dtype=torch.int32, device=dev)
                 self.keep_cnt = torch.empty((batch,), dtype=torch.int32, device=dev)
                 self.keep_det = torch.empty((batch, 1000, 6), dtype=torch.float32, device=dev)
-                self.ws_bytes = L.trtx_yolo_nms_workspace(batch)
+                self.ws_bytes = L.trtx_yolo_nms_workspace(batch) if L else 256
                 self.ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
-                self.host_cnt = torch.empty((batch,), dtype=torch.int32).pin_memory()
-                self.host_det = torch.empty((batch, 1000, 6), dtype=torch.float32).pin_memory()
+                self.host_cnt = pin(torch.empty((batch,), dtype=torch.int32))
+                self.host_det = pin(torch.empty((batch, 1000, 6), dtype=torch.float32))
 
         def bindings(self, x):
             return [x if i == in_idx else self.outs[i] for i in range(self.e.nb_bindings)]
@@ -288,12 +315,14 @@ def main():
         def run(self, x, with_d2h=False):
             """enqueue (+ device NMS (+ D2H of the detections)) of one batch, all on this slot's stream"""
             self.ctx.enqueue(batch, self.bindings(x), stream=self.stream.cuda_stream)
-            if cfg["nms"]:
+            if cfg["nms"] and dry:
+                self.keep_cnt.zero_()
+            elif cfg["nms"]:
                 capi.check(L.trtx_yolo_nms(capi._p(self.out), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(self.keep_idx),
                                            capi._p(self.keep_cnt), capi._p(self.keep_det), capi._p(self.ws), ctypes.c_size_t(self.ws_bytes),
                                            self.stream_p), "trtx_yolo_nms")
                 if with_d2h:  # what the reference's timer includes: results back on the host (yolov8_det.cpp:97-104)
-                    with torch.cuda.stream(self.stream):
+                    with tc.stream(self.stream):
                         self.host_cnt.copy_(self.keep_cnt, non_blocking=True)
                         self.host_det.copy_(self.keep_det, non_blocking=True)  # contiguous 768 KB
 
@@ -304,13 +333,13 @@ def main():
         """one timed leg: barrier + synchronize, EXACTLY n_steps steps, synchronize + barrier; max over ranks (seconds).
         trace (a dict): per-step host time at which the enqueue returned and device time at which the step's last kernel ended,
         both in ms from the start of the leg - what lets a reader see WHERE a slow leg lost its time."""
-        torch.cuda.synchronize()
+        tc.synchronize()
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        tc.synchronize()
         evs = None
         if trace is not None:
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+            evs = [tc.Event(enable_timing=True) for _ in range(n_steps + 1)]
             evs[0].record(slots[0].stream)
             host = []
         t0 = time.perf_counter()
@@ -320,10 +349,10 @@ def main():
             if evs:
                 evs[k + 1].record(sl.stream)
                 host.append((time.perf_counter() - t0) * 1e3)
-        torch.cuda.synchronize()                     # all streams: every step's NMS / copies end inside the timed region
+        tc.synchronize()                     # all streams: every step's NMS / copies end inside the timed region
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        tc.synchronize()
         dt = time.perf_counter() - t0
         if evs:
             trace["host_enqueue_returned_ms"] = [round(h, 3) for h in host]
@@ -351,7 +380,7 @@ def main():
     # after seconds of host-only set-up
     eng1 = one = None
     if n_ctx > 1:
-        eng1 = engine.Engine(build_shared(-1))
+        eng1 = make_engine(build_shared(-1))
         one = make_slots(eng1, 1)
     # settle (set-up, untimed, before the W warm-up steps the contract asks for): every slot, stream and input batch has been used
     # and the clocks are up: at least 24 steps AND at least 0.4 s of back-to-back work
@@ -361,13 +390,13 @@ def main():
         slots[k % n_ctx].run(inputs[k % len(inputs)])
         k += 1
         if k % 8 == 0:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
+            tc.synchronize()
+    tc.synchronize()
     settle_steps = k
     dt, value_legs, value_trace = legs(slots, args.repeats)
     detections = None
     if cfg["nms"]:
-        torch.cuda.synchronize()
+        tc.synchronize()
         last = slots[(args.steps - 1) % n_ctx]
         detections = {"decode_candidates_per_image": float(last.out[:, 0].float().mean().item()),
                       "kept_after_nms_per_image": float(last.keep_cnt.float().mean().item()),
@@ -388,45 +417,47 @@ def main():
         from tensorrtx_amd import preproc
         n_up = n_ctx + 1
         # the same synthetic scenes as the resident-input legs, as camera frames: uint8, HWC, BGR
-        frames = [torch.from_numpy(np.ascontiguousarray((np.clip(rng_imgs[s % len(rng_imgs)], 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
-                                                        .transpose(0, 2, 3, 1)[..., ::-1])).pin_memory() for s in range(n_up)]
+        def as_frames(x):
+            return pin(torch.from_numpy(np.ascontiguousarray((np.clip(x, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8).transpose(0, 2, 3, 1)[..., ::-1])))
+        frames = [as_frames(rng_imgs[0])] * n_up if dry else [as_frames(rng_imgs[s % len(rng_imgs)]) for s in range(n_up)]
         raw = [torch.empty((batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n_up)]
         net_in = [torch.empty((batch, 3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
-        copy_stream = torch.cuda.Stream()
-        uploaded = [torch.cuda.Event() for _ in range(n_up)]
-        consumed = [torch.cuda.Event() for _ in range(n_up)]
+        copy_stream = tc.Stream()
+        uploaded = [tc.Event() for _ in range(n_up)]
+        consumed = [tc.Event() for _ in range(n_up)]
 
         def upload(s):
-            with torch.cuda.stream(copy_stream):
+            with tc.stream(copy_stream):
                 copy_stream.wait_event(consumed[s])      # the letterbox kernel of the previous user of this buffer is done
                 raw[s].copy_(frames[s], non_blocking=True)
                 uploaded[s].record(copy_stream)
 
         def host_step(k):
             s, slot = k % n_up, slots[k % n_ctx]
-            with torch.cuda.stream(slot.stream):
+            with tc.stream(slot.stream):
                 slot.stream.wait_event(uploaded[s])
-                preproc.letterbox_batch(list(raw[s]), W, H, out=net_in[k % n_ctx])
+                if not dry:
+                    preproc.letterbox_batch(list(raw[s]), W, H, out=net_in[k % n_ctx])
                 consumed[s].record(slot.stream)
             slot.run(net_in[k % n_ctx], with_d2h=True)
 
         def host_timed(n_steps):
             for s in range(n_up):
-                consumed[s].record(torch.cuda.current_stream())
-            torch.cuda.synchronize()
+                consumed[s].record(tc.current_stream())
+            tc.synchronize()
             if dist:
                 dist.barrier()
-            torch.cuda.synchronize()
+            tc.synchronize()
             t0 = time.perf_counter()
             upload(0)
             for k in range(n_steps):
                 if k + 1 < n_steps:
                     upload((k + 1) % n_up)               # prefetch the next batch while the earlier ones compute
                 host_step(k)
-            torch.cuda.synchronize()
+            tc.synchronize()
             if dist:
                 dist.barrier()
-            torch.cuda.synchronize()
+            tc.synchronize()
             return replicas.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
         host_timed(min(2 * n_ctx, args.steps))           # warm the path (letterbox kernel, pinned copies)
@@ -572,21 +603,29 @@ def main():
         res["suspect_why"] = why
     if max(value_legs) > 1.25 * med_ms:
         res["slowest_leg_trace"] = value_trace   # per step: when the host's enqueue returned / when the device finished it (ms)
+    if dry:
+        res["dry_run"] = True
+        res["data"] = "NONE: --dry-run rehearses the control flow on CPU; every number in this line is meaningless"
     if rank == 0:
-        if args.config == "yolov8n" and not args.no_cpu_baseline and args.precision == "fp16":
+        if args.config == "yolov8n" and not args.no_cpu_baseline and not dry:
             # GPU outputs for the oracle's sample images (a separate small engine run, outside every timed region)
             nb = 4
-            plan_h = engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=1, mark_heads=1)
+            if args.precision == "int8":   # the scales the benchmarked engine was calibrated to
+                from tensorrtx_amd import calibrator
+                with calibrator.Calibrator(cache=calib_cache["text"]).installed():
+                    plan_h = engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=1, int8=1, mark_heads=1)
+            else:
+                plan_h = engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=1, mark_heads=1)
             eh = engine.Engine(plan_h)
             imgs = synth.images(nb, H, W, seed=11)
             bufs = [torch.from_numpy(imgs).to(dev)] + [torch.empty(nb * int(np.prod(eh.dims[i])), dtype=torch.float32, device=dev)
                                                        for i in range(1, eh.nb_bindings)]
             eh.enqueue(nb, bufs)
-            torch.cuda.synchronize()
+            tc.synchronize()
             heads = [bufs[eh.names.index(f"head{i}")].cpu().numpy().reshape(nb, -1) for i in range(3)]
             dec = bufs[eh.names.index("output")].cpu().numpy().reshape(nb, -1)
             eh.close()
-            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(path, heads, dec, imgs)
+            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(path, heads, dec, imgs, precision=args.precision)
         print(json.dumps(res), flush=True)
     eng.close()
     if dist:

@@ -141,6 +141,10 @@ class IInt8EntropyCalibrator : public IInt8Calibrator {
    public:
     CalibrationAlgoType getAlgorithm() override { return CalibrationAlgoType::kENTROPY_CALIBRATION; }
 };
+class IInt8MinMaxCalibrator : public IInt8Calibrator {
+   public:
+    CalibrationAlgoType getAlgorithm() override { return CalibrationAlgoType::kMINMAX_CALIBRATION; }
+};
 class IGpuAllocator;
 
 namespace shim {
@@ -863,6 +867,7 @@ class IBuilderConfig {
             };
             v.read_cache = [](void* s, size_t* len) -> const void* { return static_cast<IInt8Calibrator*>(s)->readCalibrationCache(*len); };
             v.write_cache = [](void* s, const void* p, size_t len) { static_cast<IInt8Calibrator*>(s)->writeCalibrationCache(p, len); };
+            v.get_algorithm = [](void* s) -> int32_t { return (int32_t) static_cast<IInt8Calibrator*>(s)->getAlgorithm(); };
         }
         trtx_builder_set_int8_calibrator(mB, c ? &v : nullptr);
     }

@@ -417,6 +417,10 @@ typedef struct trtx_calibrator_vtbl {
     int32_t (*get_batch)(void* self, void** bindings, const char* const* names, int32_t nb_bindings);
     const void* (*read_cache)(void* self, size_t* length); /* NULL / length 0: no cache */
     void (*write_cache)(void* self, const void* cache, size_t length);
+    /* IInt8Calibrator::getAlgorithm (nvinfer1::CalibrationAlgoType): NULL or 1 / 2 = entropy calibration (the reference's
+     * IInt8EntropyCalibrator2: the threshold that minimises the KL divergence, clipping rare large values); 3 = kMINMAX_CALIBRATION
+     * (IInt8MinMaxCalibrator: the largest |x| seen, nothing clipped). */
+    int32_t (*get_algorithm)(void* self);
 } trtx_calibrator_vtbl;
 /* IBuilderConfig::setMaxAuxStreams (TensorRT >= 8.6): how many streams besides the caller's an execution context may use to run
  * independent branches of the plan concurrently.  -1 (default) = the runtime's choice (3); 0 = strictly the caller's stream, the

@@ -20,11 +20,12 @@ class CalibratorVtbl(ctypes.Structure):
         ("get_batch", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32)),
         ("read_cache", ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t))),
         ("write_cache", ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)),
+        ("get_algorithm", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p)),
     ]
 
 
 class Calibrator:
-    def __init__(self, batches=None, batch_size=1, cache=None):
+    def __init__(self, batches=None, batch_size=1, cache=None, algorithm="entropy2"):
         self.batches = list(batches or [])
         self.batch_size = batch_size
         self.cache = cache
@@ -57,10 +58,16 @@ class Calibrator:
         def write_cache(_, ptr, n):
             self.written_cache = ctypes.string_at(ptr, n)
 
+        algo = {"entropy": 1, "entropy2": 2, "minmax": 3}[algorithm]   # nvinfer1::CalibrationAlgoType
+
+        def get_algorithm(_):
+            return algo
+
         self.vtbl = CalibratorVtbl()
         self._cbs = (CalibratorVtbl._fields_[1][1](get_batch_size), CalibratorVtbl._fields_[2][1](get_batch),
-                     CalibratorVtbl._fields_[3][1](read_cache), CalibratorVtbl._fields_[4][1](write_cache))
-        self.vtbl.get_batch_size, self.vtbl.get_batch, self.vtbl.read_cache, self.vtbl.write_cache = self._cbs
+                     CalibratorVtbl._fields_[3][1](read_cache), CalibratorVtbl._fields_[4][1](write_cache),
+                     CalibratorVtbl._fields_[5][1](get_algorithm))
+        self.vtbl.get_batch_size, self.vtbl.get_batch, self.vtbl.read_cache, self.vtbl.write_cache, self.vtbl.get_algorithm = self._cbs
 
     @contextlib.contextmanager
     def installed(self):

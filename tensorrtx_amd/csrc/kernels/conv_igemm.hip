@@ -95,9 +95,9 @@ __device__ __forceinline__ int swz(int row) {
 // stores) exists ONCE, in a rolled loop with wave-uniform branches, instead of once per accumulator fragment and activation
 // kind.  Unrolled, that code was 80 % of a 45-90 KB kernel against a 64 KB instruction cache shared by two CUs
 // (profiles/r02_code_size.txt).  `pixel_of(t)` maps row t of the tile (0 .. 64 * MI) to the output pixel index, or -1.
-template <int NFRAG, int MI, bool I8, int LDS_BYTES, typename PixelOf>
+template <int NFRAG, int MI, bool I8, int LDS_BYTES, int NWAVES = 4, typename PixelOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[MI][NFRAG], intx4 (&acci)[MI][NFRAG], char* smem, int wave, int lane,
-                                              int n0, PixelOf&& pixel_of) {
+                                              int n0, PixelOf&& pixel_of, int row0 = -1) {
     constexpr int BN = 16 * NFRAG;
     constexpr int WR = 16 * MI;
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
@@ -106,11 +106,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
     const int ch_in = (lane >> 4) * 4;
     const bool second = res || p.act2 != ACT_NONE;
     constexpr int PS = BN * 4 + 16;   // fp32 row stride of the staging tile (padded: 16 consecutive rows start in distinct bank groups)
-    static_assert(4 * 16 * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
+    static_assert(NWAVES * 16 * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
     constexpr int CPR = BN / 8;       // 8-channel items per row
     constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
     __syncthreads();  // every wave is done reading the last stage
     char* mine = smem + wave * 16 * PS;
+    const int rbase = row0 < 0 ? wave * WR : row0;   // first tile row of this wave (waves may also be split along N: WN below)
 #pragma nounroll
     for (int i = 0; i < MI; ++i) {
         // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
@@ -131,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 #pragma nounroll
         for (int q = lane; q < ITEMS; q += 64) {
             const int row = q / CPR, cc = q % CPR;
-            const int m = pixel_of(wave * WR + i * 16 + row);
+            const int m = pixel_of(rbase + i * 16 + row);
             const int co = n0 + cc * 8;
             if (m < 0 || co >= p.Cout) continue;
             const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
@@ -214,25 +215,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 // MI = 16-row MFMA fragments per wave along M: 2 -> a 128-row tile (the default), 1 -> a 64-row tile (twice the workgroups for
 // layers whose 128-row tiling leaves most of the 256 CUs idle), 4 -> a 256-row tile (half the tiles, prologues and weight
 // traffic for the large maps); chosen per layer by the tactic tuner, runtime/tune.cpp.
-template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2>
-__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
+// WN = waves along N: 1 -> the four waves stack along M and each reads ALL of the B tile (fine up to 128 x 128: 40 LDS bytes per
+// wave-cycle at most); 2 -> a 2 x 2 wave grid, each wave owns (BM / 2) x (BN / 2).  The large-GEMM configuration is <NFRAG 8, BKT 64,
+// MI 8, WN 2, three stages>: a 256 x 128 tile of 128 x 64 wave tiles - 12 ds_read_b128 per 32 MFMAs (24 LDS bytes per wave-cycle, 75 %
+// of what the CU's LDS delivers when all four SIMDs keep their MFMA pipe full; the 128 x 128 / WN 1 tile needs 160 B/clk for that and
+// cannot), 43 MACs per operand byte fetched into LDS, accumulators 128 VGPRs.  Its three stages are 144 KB of LDS: one workgroup per
+// CU, which the 64 independent MFMAs per k-step of every wave tolerate.  NSTO overrides the stage count.
+// RS = register-staged operands: global memory -> VGPRs (buffer_load_dwordx4) -> LDS (ds_write_b128, the same lane-linear rows the
+// DMA writes) instead of buffer_load ... lds.  One LDS-DMA piece (1 KiB per wave-instruction) costs the issuing wave 60-185 cycles
+// of issue (MI355X_MICROARCH.md; ablation of this kernel, profiles/r03_gemm_ablation.txt: the k-loop with the MFMAs removed is 72 % of
+// the whole kernel and does not shrink when the loads are range-checked away), against 16 for an MFMA: a 128 x 128 x 64 step is 8
+// pieces = ~800 cycles next to 512 cycles of MFMA per wave - the loop is bound by DMA issue.  A register load issues in a few cycles;
+// the tile for step kt+1 is fetched into registers before the MFMAs of step kt are issued and written to the other LDS stage after them
+// (two LDS stages, one barrier per step).  Same LDS contents, same MFMA order: bit-identical results.
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
     constexpr int BN = 16 * NFRAG;
-    constexpr int BM = 64 * MI;                    // rows per tile: every wave owns 16 * MI of them
+    constexpr int WM = NW / WN;                    // waves along M (NW = waves per workgroup: 4, or 8 for the large-GEMM tile)
+    constexpr int NFW = NFRAG / WN;                // 16-column fragments per wave
+    static_assert(NFRAG % WN == 0 && (WN == 1 || WN == 2), "wave grid");
+    constexpr int BM = WM * 16 * MI;               // rows per tile: every wave owns 16 * MI of them
     constexpr int WR = 16 * MI;                    // rows per wave
     constexpr int ROW_B = BKT * 2;                 // bytes per LDS row
     constexpr int CH = BKT / 8;                    // 16-byte chunks per row
     constexpr int RPI = 64 / CH;                   // rows filled by one wave-instruction (16 / 8)
-    constexpr int A_LOADS = BM / (4 * RPI);        // per wave per k-step (2 / 4)
-    constexpr int B_PASSES = (BN + 4 * RPI - 1) / (4 * RPI);
-    constexpr int B_ROWS = B_PASSES * 4 * RPI;     // rows beyond BN are dummy targets
+    constexpr int A_LOADS = BM / (NW * RPI);       // per wave per k-step (2 / 4)
+    constexpr int B_PASSES = (BN + NW * RPI - 1) / (NW * RPI);
+    constexpr int B_ROWS = B_PASSES * NW * RPI;    // rows beyond BN are dummy targets
     constexpr int A_BYTES = BM * ROW_B;
     constexpr int STAGE_BYTES = A_BYTES + B_ROWS * ROW_B;
     constexpr int LOADS_PER_TILE = A_LOADS + B_PASSES;
     constexpr int KSUB = BKT / 32;                 // MFMA k-slices per k-step
-    constexpr int NST = BKT == 64 ? 2 : 3;         // pipeline stages (64-wide stages are double-buffered to keep occupancy)
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
+    constexpr int NST = RS ? 2 : NSTO ? NSTO : (BKT == 64 ? 2 : 3);  // pipeline stages (64-wide stages are double-buffered to keep occupancy)
+    constexpr int EPI_BYTES = NW * 16 * (16 * NFW * 4 + 16);   // the epilogue's wave-private staging tiles (conv_epilogue)
+    constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // up to 144 KB of the CU's 160 KB (the large-GEMM tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     unsigned a_cols[A_LOADS];   // bit q: filter column q lies inside the image
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int m = m0 + (4 * i + wave) * RPI + lrow;
+        const int m = m0 + (NW * i + wave) * RPI + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         // quotients are small (image index, output row): a float estimate is within +-1, fixed up exactly
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     unsigned b_off[B_PASSES];
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-        const int row = (4 * j + wave) * RPI + lrow;
+        const int row = (NW * j + wave) * RPI + lrow;
         b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;  // weights < 2 GB
     }
 
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     };
     s_r[0] = 0;
     s_q[0] = 0;
-    if (TPS == 2) {
+    if constexpr (TPS == 2) {
         s_r[1] = 0;
         s_q[1] = 0;
         tap_next(s_r[1], s_q[1]);
@@ -341,6 +360,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 #pragma unroll
     for (int t = 0; t < TPS; ++t) s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
 
+    intx4 ra[RS ? A_LOADS : 1], rb[RS ? B_PASSES : 1];   // RS: the operand tile in flight (registers)
     auto issue_tile = [&](int stage) {
         char* sbase = smem + stage * STAGE_BYTES;
         const bool live = s_kt < nk && !(dbg & 1);
@@ -353,7 +373,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             for (int i = 0; i < A_LOADS; ++i) {
                 const bool ok = ((a_taps[i] >> tap) & 1u) && chunk_ok && live;
                 const unsigned voff = ok ? a_base[i] + add : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+                if constexpr (RS) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (NW * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             }
         } else {
             const int r = tsel ? s_r[TPS - 1] : s_r[0];
@@ -363,14 +384,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             for (int i = 0; i < A_LOADS; ++i) {
                 const bool ok = ((a_rows[i] >> r) & (a_cols[i] >> q) & 1u) && s_uc < cmax && live;
                 const unsigned voff = ok ? a_base[i] + add : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+                if constexpr (RS) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (NW * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
             const unsigned voff = (s_kt < nk && !(dbg & 2)) ? b_off[j] : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (4 * j + wave) * RPI * ROW_B), 16, voff, 0, 0,
-                                                     0);
+            if constexpr (RS) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (NW * j + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             b_off[j] += BKT * 2;  // kOOB stays out of range for any K < 2^30
         }
         ++s_kt;
@@ -386,12 +408,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         }
     };
 
-    floatx4 acc[MI][NFRAG];
-    intx4 acci[MI][NFRAG];
+    // RS: the fetched tile -> LDS stage `stage`, lane-linear rows exactly where the DMA would have put them
+    auto commit = [&](int stage) {
+        char* sbase = smem + stage * STAGE_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<intx4*>(sbase + (NW * i + wave) * RPI * ROW_B) = ra[i];
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<intx4*>(sbase + A_BYTES + (NW * j + wave) * RPI * ROW_B) = rb[j];
+    };
+
+    floatx4 acc[MI][NFW];
+    intx4 acci[MI][NFW];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
+        for (int j = 0; j < NFW; ++j) {
             acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
             acci[i][j] = intx4{0, 0, 0, 0};
         }
@@ -402,7 +433,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
     int f_off[KSUB];
 #pragma unroll
     for (int h = 0; h < KSUB; ++h) f_off[h] = frow * ROW_B + ((((lane >> 4) + 4 * h) ^ fswz) * 16);
-    const int a_frag = wave * WR * ROW_B;
+    const int wave_m = WN == 1 ? wave : (wave >> 1), wave_n = WN == 1 ? 0 : (wave & 1);
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    const int a_frag = wave_m * WR * ROW_B;
+    const int b_frag = A_BYTES + wave_n * NFW * 16 * ROW_B;
 
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
@@ -413,22 +447,43 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const intx4*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) {
-                    const intx4 bf = *reinterpret_cast<const intx4*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
+                for (int j = 0; j < NFW; ++j) {
+                    const intx4 bf = *reinterpret_cast<const intx4*>(sb + b_frag + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acci[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf, af[i], acci[i][j], 0, 0, 0);
                 }
-            } else {
+            } else if constexpr (!PRE) {
                 half8 af[MI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) {
-                    const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + j * 16 * ROW_B + f_off[h]);
+                for (int j = 0; j < NFW; ++j) {
+                    const half8 bf = *reinterpret_cast<const half8*>(sb + b_frag + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
                 }
             }
+        }
+        if constexpr (PRE && !I8) {
+            // every fragment read of the k-step is issued before its first MFMA (B fragment 0 first, then the A fragments, then the
+            // rest): the LDS returns in order, so the first MFMA waits for two reads and the later ones find theirs landed - with one
+            // workgroup per CU there is no other wave to cover a read issued right before its use
+            half8 af[KSUB][MI], bf[KSUB][NFW];
+#pragma unroll
+            for (int h = 0; h < KSUB; ++h) {
+                bf[h][0] = *reinterpret_cast<const half8*>(sb + b_frag + f_off[h]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[h][i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
+#pragma unroll
+                for (int j = 1; j < NFW; ++j) bf[h][j] = *reinterpret_cast<const half8*>(sb + b_frag + j * 16 * ROW_B + f_off[h]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks every read next to its MFMA again (two live B fragments)
+#pragma unroll
+            for (int h = 0; h < KSUB; ++h)
+#pragma unroll
+                for (int j = 0; j < NFW; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[h][j], af[h][i], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -447,6 +502,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
         TRTX_STAMP(4, kt);                                                    \
     }
 
+    if constexpr (RS) {
+        // registers <- tile 0; LDS stage 0 <- registers; registers <- tile 1.  Step kt: (writes of tile kt visible) barrier, MFMAs of
+        // stage kt & 1, then tile kt+1 goes from the registers to the other stage - free since every wave passed this step's barrier
+        // after its reads of step kt-1 - and tile kt+2 is fetched.  The compiler places the vmcnt / lgkmcnt waits of the register path.
+        issue_tile(0);
+        commit(0);
+        issue_tile(0);
+        for (int kt = 0; !(dbg & 16);) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!(dbg & 4)) compute(kt & 1);
+            commit((kt + 1) & 1);
+            issue_tile(0);
+            if (++kt == nk) break;
+        }
+    } else {
     issue_tile(0);
     if (NST == 3) issue_tile(1);
     for (int kt = 0; !(dbg & 16);) {
@@ -459,15 +530,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgs p, u
             if (++kt == nk) break;
         }
     }
+    }
 #undef TRTX_KSTEP
     // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (dbg & 8) return;
-    conv_epilogue<NFRAG, MI, I8, NST * STAGE_BYTES>(p, acc, acci, smem, wave, lane, n0, [&](int t) {
+    conv_epilogue<NFW, MI, I8, LDS_BYTES, NW>(p, acc, acci, smem, wave, lane, n0 + wave_n * NFW * 16, [&](int t) {
         const int m = m0 + t;
         return m < p.M ? m : -1;
-    });
+    }, wave_m * WR);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -922,8 +994,36 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
     const int chunk = plain ? 0 : (total + 7) / 8;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
+    static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // A/B switch: 0 / 1 override ConvArgs::t_rs
+    if (rs_env >= 0 ? rs_env != 0 : a.t_rs != 0)
+        TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
+                    w_bytes, tiles_n, total, chunk, dbg);
+    else
     TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
                        w_bytes, tiles_n, total, chunk, dbg);
+}
+
+// the large-GEMM configuration: 256 x 128 tile, 2 x 2 waves of 128 x 64, 64-wide k-steps, three stages = 144 KB of LDS
+int32_t launch_big(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    // TRTX_BIG_VARIANT (experiments): 0 = 256 x 128, fragment reads issued ahead; 1 = the same, reads next to their MFMAs;
+    // 2 / 3 = 128 x 128 with the 2 x 2 wave grid (64 x 64 wave tiles, two workgroups per CU), reads next to / ahead of their MFMAs
+    static const int variant = getenv("TRTX_BIG_VARIANT") ? atoi(getenv("TRTX_BIG_VARIANT")) : 0;
+    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
+    const int bm = (variant >= 2 && variant <= 4) ? 128 : 256;   // 5 / 6 / 7 = 256 x 128 with EIGHT waves (4 x 2 grid of 64 x 64 wave tiles; 3 stages, 3 + reads ahead, 2 stages);   // 4 = the plain 128 x 128 tile (four waves stacked along M) with the reads issued ahead
+    const int tiles_m = (a.M + bm - 1) / bm, tiles_n = a.Cout_pad / 128;
+    const int total = tiles_m * tiles_n;
+    const int chunk = (total + 7) / 8;
+    switch (variant) {
+        case 1: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 8, 2, 3, false>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 2: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, false>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 3: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 5: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 6: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, true, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 7: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        case 4: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 2, 1, 0, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+        default: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 8, 2, 3, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
+    }
+    return TRTX_OK;
 }
 
 template <int BKT, int TPS, bool I8 = false, int MI = 2>
@@ -984,6 +1084,8 @@ int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStr
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 // ... 256-row tiles too, for 32/64/80-wide column tiles
 bool bm256_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16 && (a.bn == 32 || a.bn == 64 || a.bn == 80); }
+// ... and, 128 columns wide with 64-wide k-steps, the large-GEMM configuration (launch_big)
+bool big_possible(const ConvArgs& a) { return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bn == 128 && a.bk == 64 && a.CinK % 64 == 0 && a.Kpad % 64 == 0 && a.Cout_pad % 128 == 0; }
 
 }  // namespace
 
@@ -1026,7 +1128,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
     return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
            a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9 &&
-           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && bm256_possible(a))) &&
+           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && (bm256_possible(a) || big_possible(a)))) &&
            (a.t_r3 == 0 || r3_possible(a));
 }
 
@@ -1074,6 +1176,11 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             push(bn, t.bk, 128, 1, 1);
             if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
             if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
+            // The large-GEMM tile (launch_big) is a candidate only on request (TRTX_BIG_VARIANT set): none of its variants beats the
+            // 128 x 128 tile on MI355X (profiles/r03_gemm_tiles.txt) - all of them stop at ~0.42 of the MFMA peak, bound by instruction
+            // issue (4.2 non-MFMA instructions per 16-cycle MFMA; SQ counters in profiles/r03_sq_counters_res5_3x3.txt).
+            static const bool big_on = getenv("TRTX_BIG_VARIANT") != nullptr;
+            if (big_on && big_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 256) push(bn, t.bk, 256, 1, 1);
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
             // The 3x3 row-reuse kernel is a candidate only on request (TRTX_TACTICS_R3=1).  Round 3 found engines that had chosen it
             // returning results that differ in the last fp16 places between execution contexts running side by side (and only then:
@@ -1129,6 +1236,8 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);
+        } else if (bm256 && big_possible(a)) {
+            st = launch_big(a, in_bytes, w_bytes, s);
         } else if (a.bk == 64) {
             st = bm64 ? launch_bn<64, 1, false, 1>(a, in_bytes, w_bytes, s)
                       : (bm256 ? launch_bn<64, 1, false, 4>(a, in_bytes, w_bytes, s) : launch_bn<64, 1>(a, in_bytes, w_bytes, s));

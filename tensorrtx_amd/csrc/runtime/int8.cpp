@@ -123,6 +123,7 @@ bool read_calibration_cache(const void* data, size_t length, Network* net, std::
 
 int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
     if (!calib.get_batch || !calib.get_batch_size) return TRTX_ERR_INVALID;
+    const bool minmax = calib.get_algorithm && calib.get_algorithm(calib.self) == 3;   // nvinfer1::CalibrationAlgoType::kMINMAX_CALIBRATION
     if (trtx_device_count() < 1) {
         fprintf(stderr, "[trtx_hip] INT8 calibration runs the network on the GPU: no HIP device (provide a calibration cache to build without one)\n");
         return TRTX_ERR_NO_DEVICE;
@@ -258,7 +259,15 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
             if (!(obs.range[s] > 0.f)) continue;
             std::vector<double> h(kCalibBins);
             for (int k = 0; k < kCalibBins; ++k) h[k] = (double)h_hist[s * kCalibBins + k];
-            const float thr = entropy_threshold(h, obs.range[s]);
+            float thr;
+            if (minmax) {   // kMINMAX_CALIBRATION: the upper edge of the last occupied bin = the largest |x| seen (to one bin)
+                int last = 0;
+                for (int k = 0; k < kCalibBins; ++k)
+                    if (h[k] > 0) last = k;
+                thr = obs.range[s] * (float)(last + 1) / (float)kCalibBins;
+            } else {
+                thr = entropy_threshold(h, obs.range[s]);
+            }
             net->tensor_scale[t.net_tensor] = thr / 127.0f;
         }
     }

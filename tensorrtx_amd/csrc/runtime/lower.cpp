@@ -1282,6 +1282,11 @@ struct Lowerer {
                 t.res_i8 = res8 ? 1 : 0;
                 t.out_inv_scale = out8 ? 1.0f / to.scale : 0.f;
                 t.res_scale = res8 ? plan.tensors[op.in[1]].scale : 0.f;
+                // Engines for several execution contexts in flight (setMaxAuxStreams(0)) take the implicit-GEMM operands through
+                // registers instead of LDS-DMA: bit-identical results, and on YOLOv8n b32 with three contexts 34.2-34.5k img/s against
+                // 33.3-33.6k (same box, alternating runs) - a DMA piece costs its wave 60-185 cycles of issue, which co-scheduled
+                // workgroups of other contexts cannot hide for each other; a lone context is 3 % slower with it and keeps the DMA.
+                t.t_rs = net.max_aux_streams == 0 ? 1 : 0;
                 if (conv_igemm_supported(t)) {
                     a = t;
                     op.igemm = true;

@@ -118,9 +118,12 @@ class Int8EntropyCalibrator2 : public nvinfer1::IInt8EntropyCalibrator2 {
     std::vector<char> calib_cache_;
 };
 
-class CallbackCalibrator : public nvinfer1::IInt8EntropyCalibrator2 {
+class CallbackCalibrator : public nvinfer1::IInt8Calibrator {
    public:
     explicit CallbackCalibrator(const trtx_calibrator_vtbl& v) : v_(v) {}
+    nvinfer1::CalibrationAlgoType getAlgorithm() override {
+        return v_.get_algorithm ? static_cast<nvinfer1::CalibrationAlgoType>(v_.get_algorithm(v_.self)) : nvinfer1::CalibrationAlgoType::kENTROPY_CALIBRATION_2;
+    }
     int32_t getBatchSize() const noexcept override { return v_.get_batch_size ? v_.get_batch_size(v_.self) : 1; }
     bool getBatch(void* bindings[], const char* names[], int32_t nb) noexcept override {
         return v_.get_batch && v_.get_batch(v_.self, bindings, names, nb) != 0;

@@ -1,0 +1,54 @@
+"""bench.py's control flow on CPU: the exact launch line the driver uses for N > 1 (python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N --steps K --warmup W), with --dry-run putting stand-ins in place of every GPU object and gloo in place of RCCL.
+What runs for real: RANK / WORLD_SIZE handling, rank 0 building the plan and broadcasting it, the per-rank input seeds, settle / warm-up
+/ K-step legs with their barriers and the max-over-ranks reduce, the host-fed ring, one JSON line from rank 0 only."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(n, extra=()):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if n == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "3", *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port()), os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", str(n), "--steps", "6", "--warmup", "2", "--repeats", "3", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line (rank 0 only), got {len(lines)}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_control_flow_weak_scaling(n):
+    d = _run(n)
+    assert d["dry_run"] is True and d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 2
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["unit"] == "images/sec"
+    assert len(d["legs_ms"]) == 3 and all(x > 0 for x in d["legs_ms"])
+    assert abs(d["value"] - 32 * n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate over all ranks
+    assert d["config"]["workload"] and "roofline" in d and d["roofline"]["launches_per_step"] > 40
+    assert ("cpu_baseline" in d) == False   # noqa: E712  (the oracle needs real GPU outputs to be compared with: not in a dry run)
+
+
+def test_bench_control_flow_strong_scaling_two_ranks():
+    d = _run(2, ("--mode", "strong"))
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the global batch is fixed: 16 + 16

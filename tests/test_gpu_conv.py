@@ -1,6 +1,8 @@
 """GPU numerics: fused implicit-GEMM MFMA convolution vs a plain PyTorch fp32 reference of the same op
 (conv2d on the fp16-rounded operands, fp32 math).  Shapes are taken from the YOLOv8n / ResNet-50
 inventories."""
+import os
+
 import numpy as np
 import pytest
 
@@ -121,6 +123,8 @@ TACTIC_CASES = [
     (3, 7, 5, 64, 128, 3, 1, 1, "none", False, "none"),      # tiny map: padding columns are 2 of 7, tiles straddle rows and images
     (6, 160, 160, 64, 64, 3, 1, 1, "silu", True, "none"),    # 600 tiles of 256 rows: the 256-row tile joins the candidates
     (8, 160, 160, 48, 32, 1, 1, 0, "silu", False, "none"),   # 1x1 over a large map, 32-wide column tiles, Cin 48 in a 64-wide slice
+    (16, 57, 55, 256, 256, 1, 1, 0, "relu", True, "relu"),   # the large-GEMM tile (256 x 128, 2 x 2 waves) joins: 1x1, ragged last tile
+    (9, 56, 56, 128, 384, 3, 1, 1, "relu", False, "none"),   # ... and on a 3x3 (K = 1152), three column tiles
 ]
 
 
@@ -143,6 +147,8 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
     scale = ref.abs().max().item()
     tactics = capi.conv2d_tactics(N, H, W, Cin, Cout, k, s, p, residual=use_res)
     assert len(tactics) >= 2 and len(set(tactics)) == len(tactics)
+    if os.environ.get("TRTX_BIG_VARIANT") and Cout % 128 == 0 and Cin % 64 == 0 and N * Ho * Wo * (Cout // 128) >= 256 * 256:
+        assert (128, 64, 256, 1, 1, 0) in tactics   # the large-GEMM configurations (experiments: tools/gemm_tactics.py)
     exact = None
     try:
         for t in tactics:

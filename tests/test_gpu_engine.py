@@ -43,10 +43,7 @@ def plan_is_explicit(plan):
     return engine.describe_plan(plan)["explicit_batch"]
 
 
-def _metric(name, **kw):
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_metrics.jsonl", "a") as f:
-        f.write(json.dumps(dict(test=name, **kw)) + "\n")
+from tests import parity  # noqa: E402  (the table of bounds; check() records what was measured and asserts)
 
 
 def test_lenet_fp32(gpu):
@@ -56,12 +53,11 @@ def test_lenet_fp32(gpu):
     out = _run(plan, {"data": x.numpy()}, 1, gpu)["prob"]
     ref = mt.lenet(mt.Params(owts.load_wts(path)), x).reshape(-1)
     err = (out - ref).abs().max().item()
-    _metric("lenet_fp32", max_abs_err=err)
-    assert err < 1e-5
+    parity.check("lenet_fp32", max_abs_err=err)
 
 
-@pytest.mark.parametrize("fp16,tol", [(0, 1e-4), (1, 3e-2)])
-def test_resnet50_small(gpu, fp16, tol):
+@pytest.mark.parametrize("fp16", [0, 1])
+def test_resnet50_small(gpu, fp16):
     path, _ = synth_wts("resnet50")
     plan = engine.build_plan("resnet50", path, batch=4, fp16=fp16, h=64, w=64)
     x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(4))  # batch 3 < max_batch 4
@@ -70,8 +66,8 @@ def test_resnet50_small(gpu, fp16, tol):
         ref = mt.resnet50(mt.Params(owts.load_wts(path)), x)
     err = (out - ref).abs().max().item()
     scale = ref.abs().max().item()
-    _metric("resnet50_64", fp16=fp16, max_abs_err=err, ref_max=scale, argmax_equal=bool((out.argmax(1) == ref.argmax(1)).all()))
-    assert err < tol * max(1.0, scale)
+    parity.check("resnet50_64", "fp16" if fp16 else "fp32", max_abs_err=err, ref_max=scale)
+    assert bool((out.argmax(1) == ref.argmax(1)).all())
 
 
 def test_resnet50_fp16_224_batch32_all_ones_and_random(gpu):
@@ -85,8 +81,7 @@ def test_resnet50_fp16_224_batch32_all_ones_and_random(gpu):
         ref = mt.resnet50(mt.Params(owts.load_wts(path)), x[:4])
     err = (out[:4] - ref).abs().max().item()
     scale = ref.abs().max().item()
-    _metric("resnet50_224_b32", max_abs_err=err, ref_max=scale)
-    assert err < 3e-2 * max(1.0, scale)
+    parity.check("resnet50_224_b32", max_abs_err=err, ref_max=scale)
     assert torch.isfinite(out).all()
 
 
@@ -106,8 +101,7 @@ def test_yolov8n_fp32_engine_matches_oracle(gpu):
     for i, h in enumerate(heads):
         got = out[f"head{i}"].reshape(h.shape)
         worst = max(worst, (got - h).abs().max().item())
-    _metric("yolov8n_fp32_128", head_max_abs_err=worst)
-    assert worst < 1e-3  # logits of O(10); 1e-4 relative
+    parity.check("yolov8n_fp32_128", head_max_abs_err=worst)   # logits of O(10): inside the north_star's 1e-4
     dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 128, 128, strides)
     dec = out["output"].reshape(2, -1).numpy()
     assert np.array_equal(dec[:, 0], dec_ref[:, 0])
@@ -155,15 +149,12 @@ def test_yolov8n_fp16_engine_640(gpu):
     dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
     dec = out["output"].reshape(4, -1).numpy()
     st = _match_detections(dec, dec_ref)
-    _metric("yolov8n_fp16_640", cls_logit_max_abs_err=worst_cls, box_ltrb_max_abs_err=worst_box,
-            counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
-    # fp16 storage of 63 layers vs the fp32 oracle: measured 0.065-0.077 on O(10) class logits, 0.015-0.02 cells on the DFL
-    # distances, min IoU 0.9967-0.9975 (profiles/r02_parity_metrics.jsonl; the range is over runs: the tactic timing may pick kernels
-    # that sum K in a different order); asserted at <= 1.5x of the largest.  The north_star's 1e-4 / 1e-3 bar is met by the fp32
-    # build only (test_yolov8n_fp32_engine_matches_oracle).
-    assert worst_cls < 0.115 and worst_box < 0.03
-    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"]
-    assert st["min_iou"] > 0.995
+    # fp16 storage of 63 layers vs the fp32 oracle: 0.065-0.077 on O(10) class logits, 0.015-0.02 cells on the DFL distances, min IoU
+    # 0.9967-0.9975 (profiles/r0*_parity_metrics.jsonl; bounds in tests/parity.py at <= 1.5x the worst run).  The north_star's 1e-4 / 1e-3
+    # bar is met by the fp32 build only (test_yolov8n_fp32_engine_matches_oracle).
+    assert st["ref"] > 50
+    parity.check("yolov8n_fp16_640", cls_logit_max_abs_err=worst_cls, box_ltrb_max_abs_err=worst_box, counts=dec[:, 0].tolist(),
+                 ref_counts=dec_ref[:, 0].tolist(), matched_fraction=st["matched"] / st["ref"], **st)
 
 
 def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
@@ -180,9 +171,8 @@ def test_yolov8n_fp16_fused_head_and_stem_640(gpu):
     dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
     dec = out["output"].reshape(4, -1).numpy()
     st = _match_detections(dec, dec_ref)
-    _metric("yolov8n_fp16_640_fused", counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
-    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"]
-    assert st["min_iou"] > 0.995
+    assert st["ref"] > 50
+    parity.check("yolov8n_fp16_640_fused", counts=dec[:, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), matched_fraction=st["matched"] / st["ref"], **st)
     assert np.abs(dec[:, 0] - dec_ref[:, 0]).max() <= 0.02 * dec_ref[:, 0].max() + 3
 
 
@@ -213,8 +203,8 @@ def test_yolov8n_fp16_engine_640_batch32_the_bench_configuration(gpu):
         heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), x[:4])
     dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
     st = _match_detections(dec[:4], dec_ref)
-    _metric("yolov8n_fp16_640_b32", counts=dec[:4, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), **st)
-    assert st["ref"] > 50 and st["matched"] >= 0.99 * st["ref"] and st["min_iou"] > 0.995
+    assert st["ref"] > 50
+    parity.check("yolov8n_fp16_640_b32", counts=dec[:4, 0].tolist(), ref_counts=dec_ref[:, 0].tolist(), matched_fraction=st["matched"] / st["ref"], **st)
     # (c)
     ki, kc, kd = capi.yolo_nms(outs[0])
     torch.cuda.synchronize()
@@ -289,12 +279,11 @@ def test_retinaface_r50_fp16_engine(gpu, hw, batch):
         heads = mt.retinaface_r50(mt.Params(owts.load_wts(path)), x)
     ref = dp.retina_decode([h.reshape(batch, 32, -1).numpy() for h in heads], H, W)
     st = _retina_match(out, ref)
-    _metric("retinaface_r50_fp16", hw=list(hw), counts=out[:, 0].tolist(), ref_counts=ref[:, 0].tolist(), **st)
-    assert st["ref"] > 100 and st["matched"] >= 0.97 * st["ref"]
-    # boxes are exp()-scaled anchors up to several hundred px wide: judge them by IoU (north_star: 1e-3 box IoU is the
-    # fp32 budget; fp16 storage measures ~5e-3) and bound the absolute error loosely
-    # measured (RetinaFace-R50 fp16 vs fp32 oracle): min IoU 0.9917-0.9925, box error <= 1.25 px
-    assert st["min_iou"] > 0.985 and st["max_box_err"] < 2.0 and st["max_conf_err"] < 0.05   # measured 0.9897-0.9925 / 0.84-1.25 px over runs
+    assert st["ref"] > 100
+    # boxes are exp()-scaled anchors up to several hundred px wide: judged by IoU (north_star: 1e-3 box IoU is the fp32 budget; fp16
+    # storage measures 8e-3 .. 1e-2) and by the absolute error in px; bounds in tests/parity.py
+    parity.check("retinaface_r50_fp16", f"{hw[0]}x{hw[1]}", counts=out[:, 0].tolist(), ref_counts=ref[:, 0].tolist(),
+                 matched_fraction=st["matched"] / st["ref"], **st)
     # device NMS on the engine's own decode buffer == oracle NMS of the same buffer
     from tensorrtx_amd import det_ops
     gi_, gc_, _ = det_ops.retina_nms(torch.from_numpy(out).to(gpu), H, W)

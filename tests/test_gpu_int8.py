@@ -152,9 +152,154 @@ def test_yolov8n_int8_engine_calibrated_on_the_gpu(gpu):
     err8 = max(float(np.abs(outs["int8"][f"head{i}"].reshape(h.shape) - h.numpy()).max()) for i, h in enumerate(heads))
     err16 = max(float(np.abs(outs["fp16"][f"head{i}"].reshape(h.shape) - h.numpy()).max()) for i, h in enumerate(heads))
     rel8 = max(float(np.abs(outs["int8"][f"head{i}"].reshape(h.shape) - h.numpy()).mean() / np.abs(h.numpy()).mean()) for i, h in enumerate(heads))
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_metrics.jsonl", "a") as f:
-        f.write(json.dumps(dict(test="yolov8n_int8_320", head_max_abs_err_int8=err8, head_max_abs_err_fp16=err16, head_mean_rel_err_int8=rel8)) + "\n")
     assert np.isfinite(outs["int8"]["output"]).all()
-    assert err16 < 0.25
-    assert rel8 < 0.25, (err8, rel8)   # int8 activations + weights: a few percent mean error on the head tensors
+    # int8 activations + weights: a few percent MEAN error on the head tensors; single elements can be far off (err8 is recorded, not
+    # bounded).  What that does to detections is test_yolov8n_int8_detections_at_640 below.
+    from tests import parity
+    parity.check("yolov8n_int8_320", head_max_abs_err_int8=err8, head_max_abs_err_fp16=err16, head_mean_rel_err_int8=rel8)
+
+
+def _iou(r, G):
+    ix = np.maximum(0, np.minimum(G[:, 2], r[2]) - np.maximum(G[:, 0], r[0]))
+    iy = np.maximum(0, np.minimum(G[:, 3], r[3]) - np.maximum(G[:, 1], r[1]))
+    inter = ix * iy
+    return inter / ((G[:, 2] - G[:, 0]) * (G[:, 3] - G[:, 1]) + (r[2] - r[0]) * (r[3] - r[1]) - inter + 1e-12)
+
+
+def _yolo_detection_stats(dec, dec_ref, conf_floor=0.25):
+    """Detection-level agreement of two YoloLayer decode buffers: every reference candidate with conf > conf_floor is looked up among the
+    other buffer's candidates of the same class by box IoU."""
+    total, hit50, hit90, ious, conf_err = 0, 0, 0, [], []
+    for b in range(dec_ref.shape[0]):
+        nr, ng = int(dec_ref[b, 0]), int(dec[b, 0])
+        R = dec_ref[b, 1:1 + nr * 90].reshape(nr, 90)
+        G = dec[b, 1:1 + ng * 90].reshape(ng, 90)
+        for r in R[R[:, 4] > conf_floor]:
+            total += 1
+            cand = G[G[:, 5] == r[5]]
+            if not len(cand):
+                continue
+            iou = _iou(r, cand)
+            j = int(iou.argmax())
+            if iou[j] > 0.5:
+                hit50 += 1
+                ious.append(float(iou[j]))
+                conf_err.append(float(abs(cand[j, 4] - r[4])))
+            hit90 += iou[j] > 0.9
+    return dict(candidates=total, matched_iou50=hit50 / max(total, 1), matched_iou90=int(hit90) / max(total, 1),
+                mean_iou=float(np.mean(ious)) if ious else 0.0, mean_conf_err=float(np.mean(conf_err)) if conf_err else 1.0)
+
+
+@pytest.mark.gpu
+def test_yolov8n_int8_detections_at_640(gpu):
+    """INT8 at the benchmark's resolution, judged where it matters: the decoded detections of the int8 engine (production plan: fused
+    stem, fused detect head) against the fp32 oracle's and against the fp16 engine's, on images the calibration did not see."""
+    import torch
+    from oracle import models_torch as mt
+    from oracle import wts as owts
+    from oracle import yolo_post as yp
+    from tests import parity
+    path, _ = synth_wts("yolov8n")
+    B, S = 4, 640
+    batches = [torch.from_numpy(synth.images(B, S, S, seed=60 + k)).to(gpu) for k in range(4)]
+    plans = {}
+    for algo in ("entropy2", "minmax"):   # the reference's IInt8EntropyCalibrator2, and TensorRT's IInt8MinMaxCalibrator (nothing clipped)
+        with calibrator.Calibrator(batches=batches, batch_size=B, algorithm=algo).installed():
+            plans[algo] = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, int8=1)
+        low = engine.describe_plan(plans[algo], lowered=True)
+        assert sum(o["i8"][0] for o in low["ops"] if o["kind"] == "conv") >= 55
+    plan16 = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1)
+    x = synth.images(B, S, S, seed=1)
+    dec = {}
+    for tag, plan in (("int8", plans["entropy2"]), ("int8_minmax", plans["minmax"]), ("fp16", plan16)):
+        e = engine.Engine(plan)
+        bufs = [torch.from_numpy(x).to(gpu)] + [torch.zeros(B * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(1, e.nb_bindings)]
+        e.enqueue(B, bufs)
+        torch.cuda.synchronize()
+        dec[tag] = bufs[e.names.index("output")].cpu().numpy().reshape(B, -1)
+        e.close()
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), torch.from_numpy(x))
+    dec_ref = yp.decode_c([h.numpy() for h in heads], 80, S, S, strides)
+    vs32 = _yolo_detection_stats(dec["int8"], dec_ref)
+    vs16 = _yolo_detection_stats(dec["int8"], dec["fp16"])
+    mm32 = _yolo_detection_stats(dec["int8_minmax"], dec_ref)
+    assert vs32["candidates"] > 50 and np.isfinite(dec["int8"]).all() and np.isfinite(dec["int8_minmax"]).all()
+    # On these seeded RANDOM weights the candidates are the tail of heavy-tailed activations - exactly what entropy calibration clips:
+    # the numbers below are what int8 costs here, not what it costs a trained detector.
+    parity.check("yolov8n_int8_640", "vs_fp32_oracle", **vs32)
+    parity.check("yolov8n_int8_640", "vs_fp16_engine", **vs16)
+    parity.check("yolov8n_int8_640", "minmax_vs_fp32_oracle", **mm32)
+
+
+def _retina_loose_match(dec, ref, conf_floor=0.1):
+    """RetinaFace decode buffers list anchors in one canonical order; an int8 box can be several px off, so anchors are paired by
+    position in the order and box IoU instead of the 2 px test the fp16 comparison uses."""
+    total, hit, ious, conf_err = 0, 0, [], []
+    for b in range(ref.shape[0]):
+        nr, ng = int(ref[b, 0]), int(dec[b, 0])
+        R = ref[b, 1:1 + nr * 15].reshape(nr, 15)
+        G = dec[b, 1:1 + ng * 15].reshape(ng, 15)
+        j = 0
+        for r in R:
+            if r[4] < conf_floor:
+                continue
+            total += 1
+            win = G[j:j + 16]
+            if not len(win):
+                continue
+            iou = _iou(r, win)
+            k = int(iou.argmax())
+            if iou[k] > 0.5:
+                hit += 1
+                ious.append(float(iou[k]))
+                conf_err.append(float(abs(win[k, 4] - r[4])))
+                j += k + 1
+    return dict(candidates=total, matched_iou50=hit / max(total, 1), mean_iou=float(np.mean(ious)) if ious else 0.0,
+                min_iou=float(np.min(ious)) if ious else 0.0, mean_conf_err=float(np.mean(conf_err)) if conf_err else 1.0)
+
+
+@pytest.mark.gpu
+def test_retinaface_r50_int8_engine(gpu):
+    """The reference's DEFAULT RetinaFace build is INT8 (retinaface/retina_r50.cpp:12, :219-225: kINT8 + Int8EntropyCalibrator2): entropy
+    calibration on the GPU, int8 MFMA convolutions through the R50 body / FPN / SSH, Decode_TRT on fp16 heads; decoded faces vs the fp32
+    oracle and vs the fp16 engine."""
+    import torch
+    from oracle import det_post as dp
+    from oracle import models_torch as mt
+    from oracle import wts as owts
+    from tests import parity
+    path, _ = synth_wts("retinaface_r50")
+    B, H, W = 2, 256, 320
+    pre = lambda seed: ((torch.from_numpy(synth.images(B, H, W, seed=seed)) * 255 - 110) / 64)  # noqa: E731
+    batches = [pre(70 + k).to(gpu) for k in range(4)]
+    cal = calibrator.Calibrator(batches=batches, batch_size=B)
+    with cal.installed():
+        plan8 = engine.build_plan("retinaface_r50", path, batch=B, fp16=1, int8=1, h=H, w=W)
+    assert cal.written_cache and cal.written_cache.startswith(b"TRT-")
+    with calibrator.Calibrator(cache=cal.written_cache).installed():      # the cache file rebuilds the same plan without a GPU pass
+        assert engine.build_plan("retinaface_r50", path, batch=B, fp16=1, int8=1, h=H, w=W) == plan8
+    low = engine.describe_plan(plan8, lowered=True)
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert sum(o["i8"][0] for o in convs) >= 0.75 * len(convs)   # 64 of 82: the stem, the heads and the deconv stand-ins stay fp16
+    with calibrator.Calibrator(batches=batches, batch_size=B, algorithm="minmax").installed():   # TensorRT's IInt8MinMaxCalibrator: nothing clipped
+        plan8mm = engine.build_plan("retinaface_r50", path, batch=B, fp16=1, int8=1, h=H, w=W)
+    plan16 = engine.build_plan("retinaface_r50", path, batch=B, fp16=1, h=H, w=W)
+    x = pre(2)
+    out = {}
+    for tag, plan in (("int8", plan8), ("int8_minmax", plan8mm), ("fp16", plan16)):
+        e = engine.Engine(plan)
+        bufs = [x.to(gpu)] + [torch.zeros(B * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(1, e.nb_bindings)]
+        e.enqueue(B, bufs)
+        torch.cuda.synchronize()
+        out[tag] = bufs[e.names.index("prob")].cpu().numpy().reshape(B, -1)
+        e.close()
+    with torch.inference_mode():
+        heads = mt.retinaface_r50(mt.Params(owts.load_wts(path)), x)
+    ref = dp.retina_decode([h.reshape(B, 32, -1).numpy() for h in heads], H, W)
+    vs32 = _retina_loose_match(out["int8"], ref)
+    vs16 = _retina_loose_match(out["int8"], out["fp16"])
+    assert vs32["candidates"] > 100 and np.isfinite(out["int8"]).all()
+    parity.check("retinaface_r50_int8", "vs_fp32_oracle", **vs32)
+    parity.check("retinaface_r50_int8", "vs_fp16_engine", **vs16)
+    parity.check("retinaface_r50_int8", "minmax_vs_fp32_oracle", **_retina_loose_match(out["int8_minmax"], ref))

@@ -13,7 +13,8 @@ import torch
 from oracle import models_torch as mt
 from oracle import wts as owts
 from tensorrtx_amd import engine, synth
-from test_gpu_engine import _metric, _run
+from test_gpu_engine import _run
+from tests import parity
 from util import synth_wts
 
 pytestmark = pytest.mark.gpu
@@ -58,11 +59,8 @@ def test_rcnn_fp32_engine_end_to_end(gpu):
     labels = out["labels"].reshape(B, 20).numpy()
     pm = min(_matched_fraction(props[b], ref["proposals"][b], 0.99) for b in range(B))
     dm = min(_matched_fraction(boxes[b], ref["boxes"][b], 0.95) for b in range(B))
-    _metric("rcnn_fp32", feat_err=err, proposals_matched=pm, detections_matched=dm,
-            score_err=float(np.abs(scores - ref["scores"]).max()))
-    assert err < 1e-3
-    assert pm >= 0.95 and dm >= 0.9
-    assert np.abs(scores - ref["scores"]).max() < 1e-3 and np.array_equal(labels, ref["labels"])
+    parity.check("rcnn_fp32", feat_err=err, proposals_matched=pm, detections_matched=dm, score_err=float(np.abs(scores - ref["scores"]).max()))
+    assert np.array_equal(labels, ref["labels"])
 
 
 @pytest.mark.parametrize("hw,batch,cfg", [((320, 416), 2, dict(pre_nms_topk=2000, post_nms_topk=200, detections=50)),
@@ -87,7 +85,6 @@ def test_rcnn_fp16_engine_stagewise(gpu, hw, batch, cfg):
         full = mt.rcnn_r50c4(params, x, stage="backbone", **ocfg)
         rf = full["features"]
         rel = float((feats - rf).abs().max() / rf.abs().max())
-        assert rel < 2e-2
         feats4 = feats
         # stage 2: RPN + decode + NMS restarted from the engine's own features
         s2 = mt.rcnn_r50c4(params, x, given={"features": feats4}, **ocfg)
@@ -99,12 +96,10 @@ def test_rcnn_fp16_engine_stagewise(gpu, hw, batch, cfg):
     labels = out["labels"].reshape(batch, D).numpy()
     dm = min(_matched_fraction(boxes[b], s3["boxes"][b], 0.85) for b in range(batch))
     top = float(np.abs(scores[:, 0] - s3["scores"][:, 0]).max())
-    _metric("rcnn_fp16", hw=list(hw), feat_rel_err=rel, proposals_matched=pm, detections_matched=dm, top_score_err=top,
-            labels_equal=float((labels == s3["labels"]).mean()))
     assert np.isfinite(scores).all() and scores[:, 0].min() > 0.05
-    # measured over runs: proposals matched 99.3-99.7 %, detections 97-100 %, top-score error < 0.02 -> asserted at ~1.5x the largest miss
-    assert pm >= 0.988
-    assert dm >= 0.95 and top < 0.03
+    # measured over runs: backbone 1.4e-3 .. 1.9e-3 relative, proposals matched 99.3-100 %, detections 97-100 % (tests/parity.py)
+    parity.check("rcnn_fp16", f"{hw[0]}x{hw[1]}", feat_rel_err=rel, proposals_matched=pm, detections_matched=dm, top_score_err=top,
+                 labels_equal=float((labels == s3["labels"]).mean()))
 
 
 def test_mask_rcnn_fp32_engine(gpu):
@@ -128,8 +123,8 @@ def test_mask_rcnn_fp32_engine(gpu):
                                                  "boxes": boxes, "labels": labels})
     masks = out["masks"].reshape(B, 20, 1, 14, 14).numpy()
     err = float(np.abs(masks - ref["masks"]).max())
-    _metric("mask_rcnn_fp32", mask_err=err, mask_mean=float(masks.mean()))
-    assert err < 2e-3 and masks.std() > 0.01
+    parity.check("mask_rcnn_fp32", mask_err=err, mask_mean=float(masks.mean()))
+    assert masks.std() > 0.01
     # the plugin operator by itself
     g = torch.Generator().manual_seed(3)
     lab = torch.randint(-1, 6, (2, 7), generator=g).float()
@@ -159,5 +154,5 @@ def test_mask_rcnn_fp16_engine(gpu):
                                                  "boxes": boxes, "labels": labels})
     masks = out["masks"].reshape(B, 30, 1, 14, 14).numpy()
     err = float(np.abs(masks - ref["masks"]).max())
-    _metric("mask_rcnn_fp16", mask_err=err, mask_mean=float(masks.mean()))
-    assert np.isfinite(masks).all() and err < 3e-2 and masks.std() > 0.01
+    parity.check("mask_rcnn_fp16", mask_err=err, mask_mean=float(masks.mean()))
+    assert np.isfinite(masks).all() and masks.std() > 0.01
