@@ -17,33 +17,67 @@ IoU tolerance is what the fp32 builds are asserted at; the fp16 bounds are the m
 import json
 import os
 
-# (test, case) -> {metric: (kind, bound[, slack])}
-BOUNDS = {
-    ("lenet_fp32", None): {"max_abs_err": ("max", 3.1e-7)},
-    ("resnet50_64", "fp32"): {"max_abs_err": ("max", 1.7e-3)},          # logits up to 720: 2.3e-6 relative
-    ("resnet50_64", "fp16"): {"max_abs_err": ("max", 1.1)},             # 1.5e-3 relative
-    ("resnet50_224_b32", None): {"max_abs_err": ("max", 1.9)},          # logits up to 1787: 1.1e-3 relative
-    ("yolov8n_fp32_128", None): {"head_max_abs_err": ("max", 1.85e-5)},  # north_star: 1e-4 on O(10) logits
-    ("yolov8n_fp16_640", None): {"cls_logit_max_abs_err": ("max", 0.115), "box_ltrb_max_abs_err": ("max", 0.03),
-                                 "matched_fraction": ("min", 0.9979), "min_iou": ("min", 0.995), "max_conf_err": ("max", 0.0155)},
-    ("yolov8n_fp16_640_fused", None): {"matched_fraction": ("min", 0.9979), "min_iou": ("min", 0.9955), "max_conf_err": ("max", 0.0155)},
-    ("yolov8n_fp16_640_b32", None): {"matched_fraction": ("min", 0.9983), "min_iou": ("min", 0.9982), "max_conf_err": ("max", 0.0079)},
-    ("retinaface_r50_fp16", "256x320"): {"matched_fraction": ("min", 0.9997, 1 / 4177), "min_iou": ("min", 0.9845),
-                                         "max_box_err": ("max", 1.27), "max_conf_err": ("max", 0.0087)},
-    ("retinaface_r50_fp16", "1280x1280"): {"matched_fraction": ("min", 0.99997, 1 / 41696), "min_iou": ("min", 0.9868),
-                                           "max_box_err": ("max", 1.69), "max_conf_err": ("max", 0.01145)},
-    ("rcnn_fp32", None): {"feat_err": ("max", 1.15e-5), "score_err": ("max", 4.9e-6), "proposals_matched": ("min", 0.98, 1 / 50),
-                          "detections_matched": ("min", 0.95, 1 / 20)},
-    ("rcnn_fp16", "320x416"): {"feat_rel_err": ("max", 2.66e-3), "proposals_matched": ("min", 0.9925), "detections_matched": ("min", 0.97),
-                               "top_score_err": ("max", 4.0e-4)},
-    ("rcnn_fp16", "800x1067"): {"feat_rel_err": ("max", 2.6e-3), "proposals_matched": ("min", 0.994), "detections_matched": ("min", 0.955),
-                                "top_score_err": ("max", 7.8e-4)},
-    ("rcnn_fp16", "800x1333"): {"feat_rel_err": ("max", 2.84e-3), "proposals_matched": ("min", 0.9895), "detections_matched": ("min", 0.955),
-                                "top_score_err": ("max", 1.04e-3)},
-    ("mask_rcnn_fp32", None): {"mask_err": ("max", 1.9e-6)},
-    ("mask_rcnn_fp16", None): {"mask_err": ("max", 1.3e-3)},
-    ("yolov8n_int8_320", None): {"head_max_abs_err_fp16": ("max", 0.087), "head_mean_rel_err_int8": ("max", 0.094)},
+# (test, case) -> {metric: (kind[, slack])}: WHICH metrics are bounded and how; the numbers live in the table below
+SPEC = {
+    ("lenet_fp32", None): {"max_abs_err": ("max",)},
+    ("resnet50_64", "fp32"): {"max_abs_err": ("max",)},                 # logits up to 720
+    ("resnet50_64", "fp16"): {"max_abs_err": ("max",)},
+    ("resnet50_224_b32", None): {"max_abs_err": ("max",)},              # logits up to 1787
+    ("yolov8n_fp32_128", None): {"head_max_abs_err": ("max",)},         # north_star: 1e-4 on O(10) logits
+    ("yolov8n_fp16_640", None): {"cls_logit_max_abs_err": ("max",), "box_ltrb_max_abs_err": ("max",), "matched_fraction": ("min",),
+                                 "min_iou": ("min",), "max_conf_err": ("max",)},
+    ("yolov8n_fp16_640_fused", None): {"matched_fraction": ("min",), "min_iou": ("min",), "max_conf_err": ("max",)},
+    ("yolov8n_fp16_640_b32", None): {"matched_fraction": ("min", 1 / 881), "min_iou": ("min",), "max_conf_err": ("max",)},
+    ("retinaface_r50_fp16", "256x320"): {"matched_fraction": ("min", 1 / 4177), "min_iou": ("min",), "max_box_err": ("max",), "max_conf_err": ("max",)},
+    ("retinaface_r50_fp16", "1280x1280"): {"matched_fraction": ("min", 1 / 41696), "min_iou": ("min",), "max_box_err": ("max",), "max_conf_err": ("max",)},
+    ("rcnn_fp32", None): {"feat_err": ("max",), "score_err": ("max",), "proposals_matched": ("min", 1 / 50), "detections_matched": ("min", 1 / 20)},
+    ("rcnn_fp16", "320x416"): {"feat_rel_err": ("max",), "proposals_matched": ("min", 1 / 200), "detections_matched": ("min", 1 / 50), "top_score_err": ("max",)},
+    ("rcnn_fp16", "800x1067"): {"feat_rel_err": ("max",), "proposals_matched": ("min", 1 / 1000), "detections_matched": ("min", 1 / 100), "top_score_err": ("max",)},
+    ("rcnn_fp16", "800x1333"): {"feat_rel_err": ("max",), "proposals_matched": ("min", 1 / 1000), "detections_matched": ("min", 1 / 100), "top_score_err": ("max",)},
+    ("mask_rcnn_fp32", None): {"mask_err": ("max",)},
+    ("mask_rcnn_fp16", None): {"mask_err": ("max",)},
+    ("yolov8n_int8_320", None): {"head_max_abs_err_fp16": ("max",), "head_mean_rel_err_int8": ("max",)},
+    # INT8 at detection level (seeded RANDOM weights: the candidates are the tail of heavy-tailed activations, which entropy calibration
+    # clips - min-max calibration shows what the int8 kernels themselves cost)
+    ("yolov8n_int8_640", "vs_fp32_oracle"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("yolov8n_int8_640", "vs_fp16_engine"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("yolov8n_int8_640", "minmax_vs_fp32_oracle"): {"matched_iou50": ("min",), "matched_iou90": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("retinaface_r50_int8", "vs_fp32_oracle"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("retinaface_r50_int8", "vs_fp16_engine"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("retinaface_r50_int8", "minmax_vs_fp32_oracle"): {"matched_iou50": ("min", 1 / 3830), "mean_iou": ("min",), "mean_conf_err": ("max",)},
 }
+
+# The numbers: written by `python tools/parity_bounds_from_record.py --write profiles/rNN_parity_metrics.jsonl` at 1.4x the worst value of the
+# record (shortfall from 1 for "min" metrics, plus the metric's slack), never by hand; tests/test_parity_bounds.py re-checks them.
+# BEGIN GENERATED VALUES
+VALUES = {
+    ('lenet_fp32', None): {'max_abs_err': 2.93e-07},
+    ('resnet50_64', 'fp32'): {'max_abs_err': 0.00159},
+    ('resnet50_64', 'fp16'): {'max_abs_err': 1.22},
+    ('resnet50_224_b32', None): {'max_abs_err': 1.78},
+    ('yolov8n_fp32_128', None): {'head_max_abs_err': 1.74e-05},
+    ('yolov8n_fp16_640', None): {'cls_logit_max_abs_err': 0.0913, 'box_ltrb_max_abs_err': 0.0281, 'matched_fraction': 0.99807, 'min_iou': 0.9956, 'max_conf_err': 0.0142},
+    ('yolov8n_fp16_640_fused', None): {'matched_fraction': 0.99807, 'min_iou': 0.99595, 'max_conf_err': 0.0142},
+    ('yolov8n_fp16_640_b32', None): {'matched_fraction': 0.99886, 'min_iou': 0.99834, 'max_conf_err': 0.00736},
+    ('retinaface_r50_fp16', '256x320'): {'matched_fraction': 0.99976, 'min_iou': 0.9883, 'max_box_err': 1.05, 'max_conf_err': 0.00883},
+    ('retinaface_r50_fp16', '1280x1280'): {'matched_fraction': 0.999976, 'min_iou': 0.9885, 'max_box_err': 1.52, 'max_conf_err': 0.0107},
+    ('rcnn_fp32', None): {'feat_err': 1.07e-05, 'score_err': 4.59e-06, 'proposals_matched': 0.98, 'detections_matched': 0.95},
+    ('rcnn_fp16', '320x416'): {'feat_rel_err': 0.00248, 'proposals_matched': 0.988, 'detections_matched': 0.952, 'top_score_err': 0.000377},
+    ('rcnn_fp16', '800x1067'): {'feat_rel_err': 0.00233, 'proposals_matched': 0.9934, 'detections_matched': 0.948, 'top_score_err': 0.00022},
+    ('rcnn_fp16', '800x1333'): {'feat_rel_err': 0.00264, 'proposals_matched': 0.9892, 'detections_matched': 0.962, 'top_score_err': 0.000969},
+    ('mask_rcnn_fp32', None): {'mask_err': 1.76e-06},
+    ('mask_rcnn_fp16', None): {'mask_err': 0.00121},
+    ('yolov8n_int8_320', None): {'head_max_abs_err_fp16': 0.0813, 'head_mean_rel_err_int8': 0.0876},
+    ('yolov8n_int8_640', 'vs_fp32_oracle'): {'matched_iou50': 0.569, 'mean_iou': 0.761, 'mean_conf_err': 0.486},
+    ('yolov8n_int8_640', 'vs_fp16_engine'): {'matched_iou50': 0.571, 'mean_iou': 0.761, 'mean_conf_err': 0.485},
+    ('yolov8n_int8_640', 'minmax_vs_fp32_oracle'): {'matched_iou50': 0.9722, 'matched_iou90': 0.842, 'mean_iou': 0.9411, 'mean_conf_err': 0.0881},
+    ('retinaface_r50_int8', 'vs_fp32_oracle'): {'matched_iou50': 0.427, 'mean_iou': 0.5, 'mean_conf_err': 0.232},
+    ('retinaface_r50_int8', 'vs_fp16_engine'): {'matched_iou50': 0.426, 'mean_iou': 0.5, 'mean_conf_err': 0.232},
+    ('retinaface_r50_int8', 'minmax_vs_fp32_oracle'): {'matched_iou50': 0.999738, 'mean_iou': 0.889, 'mean_conf_err': 0.0438},
+}
+# END GENERATED VALUES
+
+BOUNDS = {k: {m: (spec[0], VALUES[k][m]) + tuple(spec[1:]) for m, spec in ms.items() if k in VALUES and m in VALUES[k]} for k, ms in SPEC.items()}
 
 RECORD = os.path.join("gpurun_out", "parity_metrics.jsonl")
 

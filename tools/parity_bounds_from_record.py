@@ -1,39 +1,51 @@
-"""Suggest tests/parity.py bounds from a record of GPU runs: for every bounded metric the worst recorded value and a bound at 1.3x the
-worst (shortfall from 1 for "min" metrics), rounded to 3 significant digits.  python tools/parity_bounds_from_record.py profiles/r03_parity_metrics.jsonl"""
+"""tests/parity.py bounds from a record of GPU runs: for every metric of parity.SPEC the worst recorded value and a bound at 1.4x the worst
+(for "min" metrics: 1.4x the shortfall from 1, plus the metric's slack), rounded outward to 3 significant digits.
+    python tools/parity_bounds_from_record.py profiles/r03_parity_metrics.jsonl            # print
+    python tools/parity_bounds_from_record.py --write profiles/r03_parity_metrics.jsonl    # rewrite the VALUES table of tests/parity.py"""
 import json
 import math
 import os
+import re
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from tests import parity  # noqa: E402
 
+FACTOR = 1.4
 
-def sig(x, n=3, up=True):
+
+def sig(x, n=3):
+    """round |x| UP to n significant digits"""
     if x == 0:
         return 0.0
-    e = math.floor(math.log10(abs(x))) - (n - 1)
-    f = 10.0 ** e
-    return (math.ceil(x / f) if up else math.floor(x / f)) * f
+    f = 10.0 ** (math.floor(math.log10(abs(x))) - (n - 1))
+    return float(f"{math.ceil(x / f - 1e-9) * f:.12g}")
 
 
-rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
-for key, metrics in parity.BOUNDS.items():
+write = "--write" in sys.argv
+rows = [json.loads(l) for l in open([a for a in sys.argv[1:] if not a.startswith("--")][0]) if l.strip()]
+values = {}
+for key, metrics in parity.SPEC.items():
     mine = [r for r in rows if r["test"] == key[0] and r.get("case") == key[1]]
     if not mine:
         print(key, "NO RECORD")
         continue
-    out = {}
+    values[key] = {}
     for m, spec in metrics.items():
         vals = [r[m] for r in mine]
+        slack = spec[1] if len(spec) > 1 else 0.0
         if spec[0] == "max":
             worst = max(vals)
-            out[m] = ("max", float(f"{sig(1.3 * worst):.6g}"), f"worst {worst:.6g} now {spec[1]}")
+            values[key][m] = sig(FACTOR * worst)
         else:
             worst = min(vals)
-            slack = spec[2] if len(spec) > 2 else 0.0
-            b = 1 - (1.3 * (1 - worst) + (slack if worst == 1.0 else 0.0))
-            out[m] = ("min", float(f"{1 - sig(1 - b, 3, up=True):.6g}") if b < 1 else 1.0, f"worst {worst:.6g} now {spec[1]}")
-    print(key, len(mine), "runs")
-    for m, v in out.items():
-        print("    ", m, v)
+            values[key][m] = float(f"{1.0 - sig(FACTOR * (1.0 - worst) + slack):.12g}")
+        print(f"{str(key):50s} {m:26s} {spec[0]} worst {worst:<12.6g} bound {values[key][m]:<12.6g} ({len(mine)} runs)")
+if write:
+    path = os.path.join(ROOT, "tests", "parity.py")
+    src = open(path).read()
+    body = "VALUES = {\n" + "".join(f"    {k!r}: {v!r},\n" for k, v in values.items()) + "}\n"
+    src = re.sub(r"# BEGIN GENERATED VALUES\n.*?# END GENERATED VALUES\n", "# BEGIN GENERATED VALUES\n" + body + "# END GENERATED VALUES\n", src, flags=re.S)
+    open(path, "w").write(src)
+    print("wrote", path)
