@@ -523,7 +523,8 @@ def main():
             continue
         i8 = o.get("i8", [0, 0, 0])
         es_in, es_out, es_res = (1.0 if i8[0] else 2.0), (1.0 if i8[1] else 2.0), (1.0 if i8[2] else 2.0)
-        act_b = (es_in * o["hw_in"][0] * o["hw_in"][1] * o["cin"] + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (es_out + (es_res if o["residual"] else 0.0)))
+        up_c = o.get("up_c", 0)   # folded upsample: those input channels are read from a tensor a quarter the size
+        act_b = (es_in * o["hw_in"][0] * o["hw_in"][1] * (o["cin"] - 0.75 * up_c) + o["hw_out"][0] * o["hw_out"][1] * o["cout"] * (es_out + (es_res if o["residual"] else 0.0)))
         alg_bytes += act_b * nb * o.get("nmul", 1) + es_in * o["cout"] * o["cin"] * o["k"][0] * o["k"][1]
         flop_per_step += o["flops"] * nb          # plan flops are per sample and already include nmul
     avg_launch_s = conv_ms * 1e-3 / max(n_conv, 1)

@@ -228,7 +228,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 // pieces = ~800 cycles next to 512 cycles of MFMA per wave - the loop is bound by DMA issue.  A register load issues in a few cycles;
 // the tile for step kt+1 is fetched into registers before the MFMAs of step kt are issued and written to the other LDS stage after them
 // (two LDS stages, one barrier per step).  Same LDS contents, same MFMA order: bit-identical results.
-template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false>
+// UP = folded nearest 2x upsample (ConvArgs::up_in, 1x1 stride-1 layers): k-steps whose channel offset lies below up_C fetch their A rows
+// from the half-resolution tensor at (h >> 1, w >> 1) through a second buffer descriptor; everything after the fetch is unchanged.
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
@@ -266,6 +268,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
+    const unsigned up_bytes = UP ? (unsigned)((((size_t)p.N * p.up_H * p.up_W - 1) * p.up_ld + p.up_C) * 2) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_up = UP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.up_in), 0, up_bytes, 0x00020000) : rs_in;
 
     // ---- per-lane source description.  Instruction i of wave w fills LDS rows (4i + w) * RPI + [0, RPI); lane l
     // writes row + l / CH, physical chunk l % CH, so it fetches LOGICAL chunk (l % CH) ^ swz(row).
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     unsigned a_base[A_LOADS];   // byte offset of (n, hi0, wi0, channel lchunk*8); wraps for border pixels (masked)
     unsigned a_rows[A_LOADS];   // bit r: filter row r of this pixel lies inside the image (0 for pixels >= M)
     unsigned a_cols[A_LOADS];   // bit q: filter column q lies inside the image
+    unsigned a_up[UP ? A_LOADS : 1];   // UP: byte offset of (n, ho >> 1, wo >> 1, channel lchunk*8) in the half-resolution tensor
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int m = m0 + (NW * i + wave) * RPI + lrow;
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
         const int hi0 = ho * p.stride_h - p.pad_h;
         const int wi0 = wo * p.stride_w - p.pad_w;
         a_base[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;  // element index < 2^30 (slice < 2 GB)
+        if constexpr (UP) a_up[i] = (unsigned)(((n * p.up_H + (ho >> 1)) * p.up_W + (wo >> 1)) * p.up_ld + cchunk * 8) * 2u;
         // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
         a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
         a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
@@ -369,12 +375,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
             const unsigned tw = (unsigned)__builtin_amdgcn_readlane((int)t_tap, s_kt & 63);
             const int tap = (int)(tw & 255u), uc = (int)(tw >> 8);
             const bool chunk_ok = full_c || uc < cmax;
+            const bool from_up = UP && uc < p.up_C;          // wave-uniform: this k-step's channels live in the half-resolution tensor
+            const __amdgpu_buffer_rsrc_t rs_a = from_up ? rs_up : rs_in;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
                 const bool ok = ((a_taps[i] >> tap) & 1u) && chunk_ok && live;
-                const unsigned voff = ok ? a_base[i] + add : kOOB;
-                if constexpr (RS) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (NW * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+                unsigned voff = ok ? a_base[i] + add : kOOB;
+                if constexpr (UP) voff = from_up ? (ok ? a_up[i] + (unsigned)uc * 2u : kOOB) : voff;   // 1x1: `add` is the channel offset alone
+                if constexpr (RS) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(sbase + (NW * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             }
         } else {
             const int r = tsel ? s_r[TPS - 1] : s_r[0];
@@ -995,7 +1004,19 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     const int chunk = plain ? 0 : (total + 7) / 8;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
     static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // A/B switch: 0 / 1 override ConvArgs::t_rs
-    if (rs_env >= 0 ? rs_env != 0 : a.t_rs != 0)
+    const bool rs_on = rs_env >= 0 ? rs_env != 0 : a.t_rs != 0;
+    if constexpr (TPS == 1 && !I8) {
+        if (a.up_C > 0) {   // folded upsample (conv_igemm_supported has checked the geometry)
+            if (rs_on)
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
+                            in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            else
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
+                            in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            return;
+        }
+    }
+    if (rs_on)
         TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
                     w_bytes, tiles_n, total, chunk, dbg);
     else
@@ -1052,6 +1073,7 @@ bool valid_bn(int bn) { return bn == 16 || bn == 32 || bn == 64 || bn == 80 || b
 
 // the wave-split-K variant exists for 64- and 80-wide column tiles of fp16 layers with 32-wide k-steps
 bool wsk_possible(const ConvArgs& a) {
+    if (a.up_C) return false;   // the folded upsample exists in the main kernel only
     return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bk == 32 && a.CinK % 32 == 0 && (a.bn == 64 || a.bn == 80) && a.Kpad / 32 >= 4;
 }
 // ... and is what the untuned dispatch picks for few tiles with a long k-chain
@@ -1062,7 +1084,7 @@ bool wsk_default(const ConvArgs& a) {
 }
 // the row-reuse kernel: fp16 3x3 stride 1 pad 1 with 16-byte output stores, 128-row tiles, 32..128-wide column tiles
 bool r3_possible(const ConvArgs& a) {
-    return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
+    return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
            a.dil_h == 1 && a.dil_w == 1 && a.CinK % 32 == 0 && a.CinK != 16 && !a.scalar_out && a.Ho == a.H && a.Wo == a.W &&
            (a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) && (a.bm == 0 || a.bm == 128) && (a.bk == 32 || a.CinK % 64 == 0) &&
            (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
@@ -1121,6 +1143,9 @@ int conv_igemm_pick_cink(int cin, int bk) {
 
 bool conv_igemm_supported(const ConvArgs& a) {
     if (a.in_i8 && (a.bk != 32 || a.CinK % 32 || a.scalar_out)) return false;  // int8: 64-channel k-steps, vector epilogue
+    if (a.up_C != 0 && (a.up_C < 0 || a.in_i8 || a.kh != 1 || a.kw != 1 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h || a.pad_w || a.up_C % 64 || a.up_C >= a.Cin ||
+                        a.H != 2 * a.up_H || a.W != 2 * a.up_W || a.up_ld % 8 || a.CinK == 16 || a.t_r3 != 0))
+        return false;  // folded upsample: 1x1 stride 1, a whole number of k-steps from the half-resolution tensor
     if ((a.out_i8 || a.res_i8) && a.scalar_out) return false;
     const bool out_vec = a.ld_out % 8 == 0 && a.Cout % 8 == 0 && (!a.residual || a.ld_res % 8 == 0);
     const int bk = a.CinK % 64 == 0 && a.bk == 64 ? 64 : 32;
@@ -1221,6 +1246,7 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         a.in = static_cast<const char*>(a0.in) + (size_t)n0 * img_in;
         a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * (a0.out_i8 ? 1 : 2);
         if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * (a0.res_i8 ? 1 : 2);
+        if (a0.up_C) a.up_in = static_cast<const char*>(a0.up_in) + (size_t)n0 * a.up_H * a.up_W * a.up_ld * 2;
         // extent of the addressed slice: last pixel's first byte + the channels this conv reads
         const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 2);
         // few tiles and a long k-chain: the wave-split-K variant (see conv_igemm_wsk_f16_kernel); t_wsk: 0 = that rule, 1 = never,

@@ -484,7 +484,7 @@ WsPlan* ws_plan(const ConvArgs& a) {
 
 bool conv_ws_supported(const ConvArgs& a) {
     static const bool off = getenv("TRTX_CONV_NOWS") != nullptr;  // A/B switch for the micro-benchmarks
-    return !off && ws_plan(a)->ok;
+    return !off && a.up_C == 0 && ws_plan(a)->ok;   // a folded upsample is the implicit-GEMM main kernel's
 }
 
 int32_t conv_ws_f16(const ConvArgs& a0, hipStream_t s) {

@@ -47,6 +47,12 @@ struct ConvArgs {
     int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported)
     int t_rs;   // implicit-GEMM operands through registers (global -> VGPR -> ds_write) instead of LDS-DMA: 0 = no, 1 = yes (same bits)
     int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two
+    // Folded nearest 2x upsample (conv_igemm main kernel, 1x1 stride-1 convolutions only): input channels [0, up_C) are not read from
+    // `in` but from `up_in`, an NHWC fp16 tensor of HALF the resolution ([N][up_H][up_W][up_ld], H = 2 up_H, W = 2 up_W), at pixel
+    // (h >> 1, w >> 1); channels >= up_C come from `in` as usual.  This is Upsample -> Concat -> Conv1x1 (YOLOv8 head, model.cpp:130-160)
+    // without the upsampled tensor ever existing.  up_C = 0: off.
+    const void* up_in;
+    int up_C, up_ld, up_H, up_W;
 };
 
 // One launch configuration of an implicit-GEMM layer.  All tactics of a layer share its packed weights (Cout_pad, CinK, Kpad), so

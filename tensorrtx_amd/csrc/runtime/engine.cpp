@@ -158,6 +158,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 a.in = R.ptr(op.in[0]);
                 a.out = R.ptr(op.out[0]);
                 a.residual = op.in.size() > 1 ? R.ptr(op.in[1]) : nullptr;
+                a.up_in = op.extra_in.empty() ? nullptr : R.ptr(op.extra_in[0]);   // folded upsample: the half-resolution source
                 a.wgt = W + op.w_off;
                 a.bias = reinterpret_cast<const float*>(W + op.b_off);
                 a.cscale = a.in_i8 ? reinterpret_cast<const float*>(W + op.s_off) : nullptr;

@@ -1113,8 +1113,10 @@ struct Lowerer {
         std::vector<int> views_of(plan.tensors.size(), 0);  // tensors (other than itself) that alias an owner's storage
         for (const PTensor& t : plan.tensors)
             if (t.parent >= 0) ++views_of[top_of(t.id)];
-        for (const POp& op : plan.ops)
+        for (const POp& op : plan.ops) {
             for (int t : op.in) ++readers[t];
+            for (int t : op.extra_in) ++readers[t];
+        }
         auto plain = [&](const POp& op, int k) {
             const ConvArgs& a = op.conv;
             return op.kind == OP_CONV && op.igemm && !op.stem && !op.from_deconv && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == k && a.kw == k &&
@@ -1218,6 +1220,57 @@ struct Lowerer {
         }
     }
 
+    // Upsample -> Concat -> Conv1x1 without the upsampled tensor (YOLOv8 head: model.cpp:130-160, twice per network).  The nearest 2x
+    // resize writes the first channel slice of a concat buffer whose only reader is a 1x1 stride-1 convolution: that convolution's
+    // A-gather can fetch those channels from the half-resolution tensor at (h >> 1, w >> 1) itself (ConvArgs::up_in).  The resize launch,
+    // its write of the 4x larger tensor and the convolution's read of it disappear (YOLOv8n b32: 2 launches, 78 MB written + 78 MB read
+    // per step become 19.5 MB read); every product is formed from the same operands in the same order: bit-identical outputs.
+    // TRTX_FOLD_UPSAMPLE=0 keeps the resize (A/B, tests).  Not with kINT8 (the int8 resize requantises between two scales).
+    void fold_upsample() {
+        if (dt != DT_F16 || net.int8) return;
+        if (const char* e = getenv("TRTX_FOLD_UPSAMPLE"))
+            if (atoi(e) == 0) return;
+        auto top = [&](int t) {
+            while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
+            return t;
+        };
+        for (size_t k = 0; k < plan.ops.size(); ++k) {
+            const POp& rz = plan.ops[k];
+            if (rz.kind != OP_RESIZE) continue;
+            const PTensor& src = plan.tensors[rz.in[0]];
+            const PTensor& up = plan.tensors[rz.out[0]];
+            if (up.parent < 0 || up.rcoff != 0 || up.layout != LAY_NHWC || src.layout != LAY_NHWC || up.H != 2 * src.H || up.W != 2 * src.W || up.C != src.C ||
+                up.C % 64 || src.ld % 8 || src.nmul != 1 || up.nmul != 1 || is_binding_tensor(rz.out[0]))
+                continue;
+            const int owner = top(rz.out[0]);
+            // every reader of the buffer: exactly one, a 1x1 stride-1 convolution over the WHOLE buffer; nobody reads the slice itself
+            int reader = -1, n_readers = 0;
+            for (size_t j = 0; j < plan.ops.size(); ++j)
+                for (int t : plan.ops[j].in)
+                    if (top(t) == owner) {
+                        // readers of OTHER channel ranges of the buffer (a skip connection also feeding elsewhere) do not matter
+                        const PTensor& rt = plan.tensors[t];
+                        if (rt.rcoff < up.C) {
+                            reader = (int)j;
+                            ++n_readers;
+                        }
+                    }
+            if (n_readers != 1 || is_binding_tensor(owner)) continue;
+            POp& cv = plan.ops[reader];
+            const ConvArgs& a = cv.conv;
+            if (cv.kind != OP_CONV || cv.stem || cv.from_deconv || cv.in[0] != owner || !cv.extra_in.empty() || a.kh != 1 || a.kw != 1 || a.stride_h != 1 ||
+                a.stride_w != 1 || a.pad_h || a.pad_w || a.groups != 1 || a.Cin != plan.tensors[owner].C || up.C >= a.Cin || reader < (int)k)
+                continue;
+            POp probe = cv;
+            probe.extra_in = {rz.in[0]};
+            if (!choose_conv_kernel(probe) || probe.conv.up_C != up.C) continue;   // the MFMA main kernel must take it
+            cv.extra_in = {rz.in[0]};
+            cv.name += " [+ upsample of " + rz.name + "]";
+            plan.ops.erase(plan.ops.begin() + k);
+            --k;
+        }
+    }
+
     // Which kernel runs a convolution, given the (resolved) strides / offsets and the dtypes of the tensors it touches: fills op.conv
     // and sets op.igemm when the implicit-GEMM MFMA kernel takes it (the direct kernel otherwise).  ONE predicate for finalize() and
     // for the int8 assignment, which may only put a tensor in int8 if every convolution touching it gets the MFMA path.
@@ -1231,6 +1284,14 @@ struct Lowerer {
         a.K = a.kh * a.kw * (a.Cin / a.groups);
         a.Cout_pad = a.Cout;
         a.Kpad = a.K;
+        a.up_C = 0;
+        if (!op.extra_in.empty()) {   // folded upsample: geometry of the half-resolution source
+            const PTensor& tu = plan.tensors[op.extra_in[0]];
+            a.up_C = tu.C;
+            a.up_ld = tu.ld;
+            a.up_H = tu.H;
+            a.up_W = tu.W;
+        }
         op.igemm = false;
         if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
             int cin_eff = a.Cin;
@@ -1310,6 +1371,7 @@ struct Lowerer {
             t.reoff = eoff;
             t.ld = plan.tensors[p].layout == LAY_NHWC ? plan.tensors[p].Calloc : 0;
         }
+        fold_upsample();
         // kINT8: assign, then ask the kernel choice itself whether every convolution that touches an int8 tensor gets the MFMA path
         // (K >= 32, channel / offset / stride alignment, < 2 GB images ... - conditions the assignment's own screen does not repeat).
         // A convolution that does not takes its tensors out of the race and the assignment runs again; candidates only shrink, so
@@ -1371,11 +1433,14 @@ struct Lowerer {
             const PTensor& to = plan.tensors[op.out[0]];
             if (op.stem && (to.ld % 8 || to.rcoff % 8)) return fail(op.name + ": stem convolution output is not 16-byte aligned");
             choose_conv_kernel(op);
+            if (!op.extra_in.empty() && !op.igemm) return fail(op.name + ": folded upsample on a convolution that cannot take the MFMA path");
             if ((ti.dtype == DT_I8 || to.dtype == DT_I8 || (op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8)) && !op.igemm)
                 return fail(op.name + ": int8 tensor on a convolution that cannot take the MFMA path");
             const double es_in = (double)dtype_size(ti.dtype), es_out = (double)dtype_size(to.dtype);
             const double cin_real = ti.dtype == DT_I8 ? 2.0 * a.Cin : (double)a.Cin;
-            op.bytes = to.nmul * ((op.stem ? 4.0 : es_in) * (double)a.H * a.W * cin_real + es_out * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
+            // (a folded upsample reads up_C of its input channels from a tensor a quarter the size)
+            const double in_elems = (double)a.H * a.W * (cin_real - a.up_C) + (double)a.up_H * a.up_W * a.up_C;
+            op.bytes = to.nmul * ((op.stem ? 4.0 : es_in) * in_elems + es_out * (double)a.Ho * a.Wo * a.Cout * (op.in.size() > 1 ? 2 : 1));
         }
         // 4. plugins: configure + workspace
         for (size_t k = 0; k < plan.ops.size(); ++k) {
@@ -1437,6 +1502,7 @@ struct Lowerer {
                 const POp& op = plan.ops[k];
                 std::vector<Access> mine;
                 for (int t : op.in) mine.push_back(access_of(t, k, false));
+                for (int t : op.extra_in) mine.push_back(access_of(t, k, false));
                 for (int t : op.out) mine.push_back(access_of(t, k, true));
                 for (const Access& m : mine)
                     for (const Access& o : log)
@@ -1518,6 +1584,7 @@ struct Lowerer {
                 if (touch[st].empty() || touch[st].back() != k) touch[st].push_back(k);
             };
             for (int t : op.in) mark(t);
+            for (int t : op.extra_in) mark(t);
             for (int t : op.out) mark(t);
         }
         // plugin workspaces are short-lived arena blocks
@@ -1751,7 +1818,7 @@ std::string Plan::describe_json() const {
             o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << (a.in_i8 ? 2 * a.Cin : a.Cin) << ",\"cout\":" << a.Cout
               << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
               << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
-              << ",\"act2\":" << a.act2 << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
+              << ",\"act2\":" << a.act2 << ",\"up_c\":" << a.up_C << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
               << ",\"ld_out\":" << a.ld_out << ",\"i8\":[" << a.in_i8 << "," << a.out_i8 << "," << a.res_i8 << "],\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
               << (op.stem ? 0 : tensors[op.in[0]].nfix);

@@ -85,6 +85,8 @@ struct POp {
     int kind = 0;
     std::string name;
     std::vector<int> in, out;  // plan tensor ids
+    std::vector<int> extra_in; // tensors read besides `in` (conv with a folded upsample: the half-resolution source); they count for
+                               // dependencies and buffer lifetimes like `in`
     int dtype = DT_F32;
     // conv / deconv
     ConvArgs conv{};

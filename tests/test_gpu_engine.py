@@ -371,3 +371,39 @@ def test_yolov8n_fp16_engine_with_fused_chains_matches_the_layer_by_layer_engine
         assert (got[k] - ref[k]).abs().max().item() < 0.08      # logits of O(10): a few fp16 ulps of reorder noise (ws / split-K defaults)
     assert torch.equal(got["output"].reshape(B, -1)[:, 0], ref["output"].reshape(B, -1)[:, 0]) or \
         (got["output"].reshape(B, -1)[:, 0] - ref["output"].reshape(B, -1)[:, 0]).abs().max().item() <= 2
+
+
+def test_yolov8n_fp16_folded_upsample_is_bit_identical_to_the_resize_launches(gpu):
+    """Upsample -> Concat -> Conv1x1 folded into the convolution's A-gather (lower.cpp fold_upsample, ConvArgs::up_in) against the same plan
+    lowered with the two nearest-resize launches (TRTX_FOLD_UPSAMPLE=0).  With every layer on a plain implicit-GEMM tile (those sum K in
+    one order; the weight-stationary and wave-split-K kernels, which the unfolded 1x1s may otherwise take, are switched off for the
+    process) the same operands are multiplied in the same order: every output float is the same.  Own process: the switches are read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import numpy as np, torch
+from tensorrtx_amd import engine, synth
+from util import synth_wts
+from test_gpu_engine import _run
+path, _ = synth_wts('yolov8n')
+B = 5
+plan = engine.build_plan('yolov8n', path, batch=B, h=640, w=640, fp16=1, mark_heads=1)
+x = synth.images(B, 640, 640, seed=21)
+outs = []
+for fold in ('1', '0'):
+    os.environ['TRTX_FOLD_UPSAMPLE'] = fold
+    low = engine.describe_plan(plan, lowered=True)
+    assert [o['kind'] for o in low['ops']].count('resize') == (0 if fold == '1' else 2)
+    outs.append(_run(plan, {{'images': x}}, B, torch.device('cuda:0')))
+for k in outs[0]:
+    a, b = outs[0][k].view(torch.int32), outs[1][k].view(torch.int32)   # bit patterns: unused decode slots keep their NaN fill
+    assert torch.equal(a, b), (k, int((a != b).sum()))
+assert outs[0]['output'].reshape(B, -1)[:, 0].min() > 0
+print('IDENTICAL')
+"""
+    env = dict(os.environ, TRTX_TUNE="0", TRTX_CONV_NOWS="1", TRTX_CONV_NOWSK="1")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -127,13 +127,22 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     # layer by layer (the default): Appendix C.1's 63 convolutions = 1 stem (fp32 NCHW in) + 62 MFMA implicit-GEMM; the DFL
     # 1x1 convs are absorbed by the fused head kernel
     monkeypatch.delenv("TRTX_FUSE_CHAINS", raising=False)
+    monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", "0")
+    unfolded = engine.describe_plan(plan, lowered=True)
+    assert [o["kind"] for o in unfolded["ops"]].count("resize") == 2 and len(unfolded["ops"]) == 67
+    monkeypatch.delenv("TRTX_FOLD_UPSAMPLE")
     low = engine.describe_plan(plan, lowered=True)
     convs = [o for o in low["ops"] if o["kind"] == "conv"]
     assert len(convs) == 63 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == 62
     assert abs(low["flops_per_sample"] / 1e9 - 8.743) < 0.01
     kinds = [o["kind"] for o in low["ops"]]
-    assert sorted(set(kinds)) == ["conv", "pool_chain", "resize", "yolo_head"]  # everything else fused / aliased away
-    assert len(kinds) == 67  # 63 conv + 1 fused SPPF pool chain + 2 resize + 1 fused head
+    assert sorted(set(kinds)) == ["conv", "pool_chain", "yolo_head"]  # everything else fused / aliased away
+    assert len(kinds) == 65  # 63 conv + 1 fused SPPF pool chain + 1 fused head; the two nearest upsamples of the head (model.cpp:130-160)
+    #                          are folded into the A-gather of the 1x1 convolutions that read them (384 -> 128 @40x40, 192 -> 64 @80x80)
+    ups = [o for o in convs if o["up_c"]]
+    assert [(o["cin"], o["cout"], o["up_c"], o["hw_in"]) for o in ups] == [(384, 128, 256, [40, 40]), (192, 64, 128, [80, 80])]
+    assert low["bytes_per_sample"] < unfolded["bytes_per_sample"] - 1.8e6   # the convolutions' own reads: 3/4 of 0.8 + 1.6 MB per image gone
+    #                                                                          (the resize launches' 0.6 MB read + 2.5 MB written were never priced)
     assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
     assert sum(o["residual"] for o in convs) == 6  # bottleneck shortcuts of model.2/4/6/8
     assert low["arena_bytes"] < 450e6
@@ -142,7 +151,7 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
     fused = engine.describe_plan(plan, lowered=True)
     chains = [o for o in fused["ops"] if o["kind"] == "conv_chain"]
-    assert len(fused["ops"]) == 45 and len(chains) == 16
+    assert len(fused["ops"]) == 43 and len(chains) == 16
     assert sorted(len(c["stages"]) for c in chains) == [2] * 10 + [3] * 6
     assert sum(c["stages"][1]["residual"] for c in chains) == 6 and all(not c["stages"][0]["residual"] for c in chains)
     assert sum(len(c["stages"]) for c in chains) + sum(o["kind"] == "conv" for o in fused["ops"]) == 63
