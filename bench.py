@@ -312,9 +312,13 @@ def main():
         def bindings(self, x):
             return [x if i == in_idx else self.outs[i] for i in range(self.e.nb_bindings)]
 
-        def run(self, x, with_d2h=False):
-            """enqueue (+ device NMS (+ D2H of the detections)) of one batch, all on this slot's stream"""
-            self.ctx.enqueue(batch, self.bindings(x), stream=self.stream.cuda_stream)
+        def run(self, x, with_d2h=False, frames=None):
+            """enqueue (+ device NMS (+ D2H of the detections)) of one batch, all on this slot's stream; frames: uint8 HWC camera
+            frames instead of a network-input tensor (the stem samples them: trtx_context_enqueue_frames)"""
+            if frames is not None and not dry:
+                self.ctx.enqueue_frames(batch, frames, self.bindings(None), stream=self.stream.cuda_stream)
+            else:
+                self.ctx.enqueue(batch, self.bindings(x), stream=self.stream.cuda_stream)
             if cfg["nms"] and dry:
                 self.keep_cnt.zero_()
             elif cfg["nms"]:
@@ -433,13 +437,12 @@ def main():
                 uploaded[s].record(copy_stream)
 
         def host_step(k):
+            # letterbox fused into the stem: the engine's first layer samples the uploaded uint8 frames itself (enqueue_frames); the fp32
+            # network input of cuda_batch_preprocess is never written or read
             s, slot = k % n_up, slots[k % n_ctx]
-            with tc.stream(slot.stream):
-                slot.stream.wait_event(uploaded[s])
-                if not dry:
-                    preproc.letterbox_batch(list(raw[s]), W, H, out=net_in[k % n_ctx])
-                consumed[s].record(slot.stream)
-            slot.run(net_in[k % n_ctx], with_d2h=True)
+            slot.stream.wait_event(uploaded[s])
+            slot.run(None if not dry else net_in[k % n_ctx], with_d2h=True, frames=list(raw[s]))
+            consumed[s].record(slot.stream)
 
         def host_timed(n_steps):
             for s in range(n_up):
@@ -587,7 +590,7 @@ def main():
                                 "what": "same steps + async copy of the kept counts and the compacted detection buffer [B,1000,6] to pinned host memory each step (the reference's timer includes D2H, yolov8_det.cpp:97-104)"}
         res["host_fed"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_host, "unit": "images/sec",
                            "ms_per_step": dt_host / args.steps * 1e3, "legs_ms": host_legs,
-                           "what": "PCIe-inclusive: uint8 HWC frames in pinned host memory -> H2D on a copy stream (double-buffered, overlapped) -> letterbox kernel -> enqueue -> NMS -> D2H of the detections; never `value`"}
+                           "what": "PCIe-inclusive: uint8 HWC frames in pinned host memory -> H2D on a copy stream (double-buffered, overlapped) -> enqueue_frames (the letterbox is fused into the stem convolution: no fp32 input tensor) -> NMS -> D2H of the detections; never `value`"}
         res["detections"] = detections
     # internal consistency: a leg that does strictly MORE work per step (the D2H copies) or keeps fewer batches in flight (one
     # context) cannot be faster than `value`, and the legs of `value` should agree with each other; if not, say so in the line

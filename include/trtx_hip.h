@@ -513,6 +513,13 @@ int32_t trtx_context_create(trtx_engine* e, trtx_context** out);
 void trtx_context_destroy(trtx_context* c);
 /* IExecutionContext::enqueue(batch, bindings, stream, nullptr) — implicit batch */
 int32_t trtx_context_enqueue(trtx_context* c, int32_t batch, void* const* bindings, trtx_stream_t stream);
+/* cuda_batch_preprocess + enqueue in one call (yolov8/yolov8_det.cpp:146-160 -> preprocess.cu:119-127): frames[i] is a DEVICE pointer to a
+ * tightly packed uint8 HWC BGR image of frame_w[i] x frame_h[i]; the engine's first layer samples the letterboxed frame itself, the fp32
+ * network input is never materialised (the input binding's pointer is ignored and may be NULL).  Same output bits as
+ * trtx_letterbox_batch followed by trtx_context_enqueue.  Engines whose first layer is a 3-channel stem convolution on the MFMA path
+ * (every YOLO / RetinaFace / ResNet builder of the reference); TRTX_ERR_UNSUPPORTED otherwise - then use the two calls. */
+int32_t trtx_context_enqueue_frames(trtx_context* c, int32_t batch, const void* const* frames, const int32_t* frame_w, const int32_t* frame_h,
+                                    void* const* bindings, trtx_stream_t stream);
 /* setTensorAddress + enqueueV3 — explicit batch */
 int32_t trtx_context_set_tensor_address(trtx_context* c, const char* name, void* ptr);
 int32_t trtx_context_enqueue_v3(trtx_context* c, trtx_stream_t stream);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../common.h"
 #include "kernels.h"
@@ -104,14 +105,104 @@ struct StemGeom {
 //          columns outside the image are range-checked to zero by the buffer descriptor.
 // Stage 2: every lane gathers the 8 taps of its (pixel, k-chunk) from LDS, converts to fp16 and feeds the B operand of
 //          v_mfma_f32_16x16x32_f16; the weights stay in registers as A fragments.
+// FRAMES: stage 1 does not copy an fp32 NCHW tensor but SAMPLES it: the network input is the letterboxed camera frame
+// (yolov8/src/preprocess.cu:7-127: scale-about-the-centre warp-affine, bilinear, grey border, BGR -> RGB, / 255) and each patch pixel is
+// computed from the uint8 HWC source image on the fly - the 4.9 MB fp32 image per 640 x 640 frame is never written or read.  The value
+// of a pixel is formed by the reference's expression in the reference's order (see frame_pixel), so the stem sees the same floats as
+// after the separate letterbox kernel (plugins/letterbox.hip) and the engine output is the same bits.
+struct FramePack {
+    StemFrame img[kStemMaxFrames];
+};
+
+// One letterboxed pixel (dx, dy) of frame `im`, all three network channels (R, G, B).  The map is a pure scale (d2s[1] = d2s[3] = +-0), so
+// the source column depends on dx alone and the source row on dy alone: `cx` / `cy` carry what the reference computes per pixel -
+// src_x = m_x1 * dx + m_y1 * dy + m_z1 + 0.5f evaluated left to right (m_y1 * dy = +-0 adds nothing), its floor and fraction.
+struct AxisSample {
+    float pos;   // src_x (or src_y)
+    int low;     // floor
+    float l;     // pos - low
+};
+__device__ __forceinline__ AxisSample frame_axis(float m, float z, int d) {
+#pragma clang fp contract(off)
+    AxisSample a;
+    a.pos = m * (float)d + z + 0.5f;
+    a.low = (int)floorf(a.pos);
+    a.l = a.pos - (float)a.low;
+    return a;
+}
+__device__ __forceinline__ void frame_pixel(const StemFrame& im, const AxisSample& cx, const AxisSample& cy, float& r, float& g, float& b) {
+#pragma clang fp contract(off)
+    float c0, c1, c2;   // B, G, R of the source
+    if (cx.pos <= -1 || cx.pos >= im.w || cy.pos <= -1 || cy.pos >= im.h) {
+        c0 = c1 = c2 = 128.0f;
+    } else {
+        const int x_low = cx.low, y_low = cy.low, x_high = x_low + 1, y_high = y_low + 1;
+        const float lx = cx.l, ly = cy.l, hx = 1 - lx, hy = 1 - ly;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const uint8_t* base = static_cast<const uint8_t*>(im.src);
+        const size_t line = (size_t)im.w * 3;
+        float v[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = q < 2 ? y_low : y_high, xx = (q & 1) ? x_high : x_low;
+            const bool in = (q < 2 ? y_low >= 0 : y_high < im.h) && ((q & 1) ? x_high < im.w : x_low >= 0);
+            const uint8_t* px = base + (size_t)(in ? yy : 0) * line + (size_t)(in ? xx : 0) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[q][c] = in ? (float)px[c] : 128.0f;
+        }
+        c0 = w1 * v[0][0] + w2 * v[1][0] + w3 * v[2][0] + w4 * v[3][0];
+        c1 = w1 * v[0][1] + w2 * v[1][1] + w3 * v[2][1] + w4 * v[3][1];
+        c2 = w1 * v[0][2] + w2 * v[1][2] + w3 * v[2][2] + w4 * v[3][2];
+    }
+    r = c2 / 255.0f;
+    g = c1 / 255.0f;
+    b = c0 / 255.0f;
+}
+
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g, const float* s_patch, int n, int tx0, int ty0, int shift);
+
+template <int NFRAG, int KS>
+__global__ __launch_bounds__(256) void conv_stem_frames_kernel(const ConvArgs p, const StemGeom g, const FramePack fr) {
+    extern __shared__ __attribute__((aligned(16))) float s_patch[];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) * kStemTW;
+    t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) * kStemTH;
+    const int n = t / g.tiles_y;
+    const int hi_start = ty0 * p.stride_h - p.pad_h;
+    const int wi_start = tx0 * p.stride_w - p.pad_w;
+    const int al_start = (wi_start >= 0 ? wi_start : wi_start - 3) / 4 * 4;  // same patch geometry as the copying kernel
+    const int shift = wi_start - al_start;
+    const StemFrame& im = fr.img[n];
+    // stage 1: every patch pixel = one letterboxed pixel (three planes), or 0 outside the network image (the convolution's padding)
+    const int plane = g.PR * g.PCA;
+    const float inv_pca = 1.0f / (float)g.PCA;
+    for (int e = tid; e < plane; e += 256) {
+        int pr = (int)((float)e * inv_pca);   // within +-1, fixed up exactly
+        int pc = e - pr * g.PCA;
+        if (pc < 0) { --pr; pc += g.PCA; }
+        if (pc >= g.PCA) { ++pr; pc -= g.PCA; }
+        const int hi = hi_start + pr, wi = al_start + pc;
+        float r = 0.f, gg = 0.f, b = 0.f;
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+            const AxisSample cx = frame_axis(im.d2s[0], im.d2s[2], wi), cy = frame_axis(im.d2s[4], im.d2s[5], hi);
+            frame_pixel(im, cx, cy, r, gg, b);
+        }
+        s_patch[e] = r;
+        s_patch[plane + e] = gg;
+        s_patch[2 * plane + e] = b;
+    }
+    __syncthreads();
+    stem_stage2<NFRAG, KS>(p, g, s_patch, n, tx0, ty0, shift);
+}
+
 template <int NFRAG, int KS>
 __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, const StemGeom g, unsigned in_bytes) {
     extern __shared__ __attribute__((aligned(16))) float s_patch[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int khw = p.kh * p.kw;
-    const int K = khw * p.Cin;
     // tile coordinates
     int t = blockIdx.x;
     const int tx0 = (t % g.tiles_x) * kStemTW;
@@ -143,7 +234,20 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(s_patch + (size_t)(base + wave * 64) * 4), 16, off, 0, 0, 0);
         }
     }
-    // ---- weights and tap tables while the patch is in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stem_stage2<NFRAG, KS>(p, g, s_patch, n, tx0, ty0, shift);
+}
+
+// stage 2 of both stem kernels: the patch is in LDS, wave w owns tile row w
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g, const float* s_patch, int n, int tx0, int ty0, int shift) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int khw = p.kh * p.kw;
+    const int K = khw * p.Cin;
+    // ---- weights and tap tables
     const float* __restrict__ w = static_cast<const float*>(p.wgt);  // [tap = (c*kh + r)*kw + q][Cout]
     const int kq = (lane >> 4) * 8;
     half8 wf[NFRAG][KS];
@@ -173,8 +277,6 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
             const int co = j * 16 + ch4 + e;
             bias4[j][e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     // ---- stage 2: wave w owns tile row w (64 pixels = 4 groups)
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
 #pragma unroll
@@ -235,6 +337,27 @@ void launch_lds(const ConvArgs& a, hipStream_t s) {
                        in_bytes);
 }
 
+template <int NFRAG, int KS>
+void launch_frames(const ConvArgs& a0, const StemFrame* frames, hipStream_t s) {
+    StemGeom g;
+    g.PR = (kStemTH - 1) * a0.stride_h + a0.kh;
+    g.PCA = ((kStemTW - 1) * a0.stride_w + a0.kw + 3 + 3) / 4 * 4;
+    g.tiles_x = (a0.Wo + kStemTW - 1) / kStemTW;
+    g.tiles_y = (a0.Ho + kStemTH - 1) / kStemTH;
+    g.chunks = a0.Cin * g.PR * g.PCA / 4;
+    const size_t lds = (size_t)((g.chunks + 255) / 256 * 256) * 16;
+    for (int n0 = 0; n0 < a0.N; n0 += kStemMaxFrames) {   // the frame descriptors travel in the kernel arguments, 64 images at a time
+        ConvArgs a = a0;
+        a.N = a0.N - n0 < kStemMaxFrames ? a0.N - n0 : kStemMaxFrames;
+        a.M = a.N * a.Ho * a.Wo;
+        a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * 2;
+        FramePack fr;
+        memset(&fr, 0, sizeof(fr));
+        for (int i = 0; i < a.N; ++i) fr.img[i] = frames[n0 + i];
+        hipLaunchKernelGGL((conv_stem_frames_kernel<NFRAG, KS>), dim3((unsigned)(a.N * g.tiles_x * g.tiles_y)), dim3(256), lds, s, a, g, fr);
+    }
+}
+
 template <int COUT>
 void launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)a.kh * a.kw * a.Cin * COUT * sizeof(float);
@@ -276,6 +399,24 @@ int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s) {
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return check_launch("conv_stem_nchw_f32");
+}
+
+int32_t conv_stem_frames_f32(const ConvArgs& a, const StemFrame* frames, hipStream_t s) {
+    if (!frames || !conv_stem_supported(a) || a.ld_out % 8 || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.Cin != 3) return TRTX_ERR_UNSUPPORTED;
+    const int K = a.kh * a.kw * a.Cin;
+    const size_t patch = (size_t)a.Cin * ((kStemTH - 1) * a.stride_h + a.kh) * ((kStemTW - 1) * a.stride_w + a.kw + 9) * 4;
+    if (a.Cout % 16 || K > 160 || patch > 60 * 1024) return TRTX_ERR_UNSUPPORTED;
+    for (int i = 0; i < a.N; ++i)
+        if (!frames[i].src || frames[i].w < 1 || frames[i].h < 1) return TRTX_ERR_INVALID;
+    const int ks = K <= 32 ? 1 : 5;
+    if (a.Cout == 16 && ks == 1) launch_frames<1, 1>(a, frames, s);
+    else if (a.Cout == 32 && ks == 1) launch_frames<2, 1>(a, frames, s);
+    else if (a.Cout == 64 && ks == 1) launch_frames<4, 1>(a, frames, s);
+    else if (a.Cout == 16 && ks == 5) launch_frames<1, 5>(a, frames, s);
+    else if (a.Cout == 32 && ks == 5) launch_frames<2, 5>(a, frames, s);
+    else if (a.Cout == 64 && ks == 5) launch_frames<4, 5>(a, frames, s);
+    else return TRTX_ERR_UNSUPPORTED;
+    return check_launch("conv_stem_frames_f32");
 }
 
 }  // namespace trtx

@@ -125,6 +125,17 @@ void conv_chain_pack_weights(const float* w_kcrs, int cout, int cin, int k, cons
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);
+// The stem fed by camera frames instead of the fp32 network input: image n of the batch is the letterbox (yolov8/src/preprocess.cu) of
+// frames[n] - a device-resident uint8 HWC BGR image of w x h pixels with d2s = the inverse affine map trtx_letterbox_matrix computes
+// for (w, h) -> (a.W, a.H) - sampled inside the kernel's patch fill.  a.in is ignored.  3-channel stems on the LDS / MFMA path only
+// (TRTX_ERR_UNSUPPORTED otherwise: the caller then runs the letterbox kernel and the ordinary stem).
+constexpr int kStemMaxFrames = 64;
+struct StemFrame {
+    const void* src;
+    int w, h;
+    float d2s[6];
+};
+int32_t conv_stem_frames_f32(const ConvArgs& a, const StemFrame* frames, hipStream_t s);
 // generic direct convolution (any groups / dilation / channel count), T = activation dtype, fp32 weights
 int32_t conv_direct(const ConvArgs& a, int dtype, hipStream_t s);
 // generic transposed convolution, fp32 weights laid out [Cin][kh][kw][Cout/groups]

@@ -86,7 +86,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         return TRTX_ERR_INVALID;
     }
     for (size_t b = 0; b < plan.binding_tensor.size(); ++b)
-        if (!bindings[b]) {
+        if (!bindings[b] && !(c->frames && plan.binding_is_input[b])) {   // enqueue_frames: the input tensor is never touched
             fprintf(stderr, "[trtx_hip] enqueue: binding %zu is null\n", b);
             return TRTX_ERR_INVALID;
         }
@@ -166,6 +166,8 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 a.M = a.N * a.Ho * a.Wo;
                 if (op.kind == OP_DECONV)
                     st = deconv_direct(a, op.dtype, stream);
+                else if (op.stem && c->frames)
+                    st = conv_stem_frames_f32(a, c->frames, stream);   // letterbox fused into the stem (trtx_context_enqueue_frames)
                 else if (op.stem)
                     st = conv_stem_nchw_f32(a, stream);
                 else if (op.igemm) {
@@ -673,6 +675,39 @@ extern "C" int32_t trtx_context_enqueue(trtx_context* c, int32_t batch, void* co
     }
     if (const int32_t st = check_device(c->engine, "enqueue")) return st;
     return enqueue_maybe_graph(c, b, bindings, stream);
+}
+
+// Camera frames in, detections out: the stem convolution samples the letterboxed frame itself (kernels/conv_stem.hip FRAMES), so the
+// fp32 network-input tensor of cuda_batch_preprocess + enqueue (yolov8_det.cpp:146-160) never exists.  Eager path only (no graph replay:
+// the frame pointers are kernel arguments).
+extern "C" int32_t trtx_context_enqueue_frames(trtx_context* c, int32_t batch, const void* const* frames, const int32_t* frame_w, const int32_t* frame_h,
+                                               void* const* bindings, trtx_stream_t stream) {
+    if (!c || !bindings || !frames || !frame_w || !frame_h) return TRTX_ERR_INVALID;
+    const Plan& plan = c->engine->plan;
+    if (plan.explicit_batch || batch < 1 || batch > plan.max_batch) return TRTX_ERR_INVALID;
+    if (const int32_t st = check_device(c->engine, "enqueue_frames")) return st;
+    // the plan must start with a 3-channel stem convolution reading the (only) input binding
+    int stem = -1, n_in = 0;
+    for (size_t b = 0; b < plan.binding_is_input.size(); ++b) n_in += plan.binding_is_input[b] ? 1 : 0;
+    for (size_t k = 0; k < plan.ops.size() && stem < 0; ++k)
+        if (plan.ops[k].kind == OP_CONV && plan.ops[k].stem) stem = (int)k;
+    if (n_in != 1 || stem < 0 || plan.ops[stem].conv.Cin != 3) return TRTX_ERR_UNSUPPORTED;
+    for (size_t k = 0; k < plan.ops.size(); ++k)   // nothing else may read the input tensor
+        for (int t : plan.ops[k].in)
+            if ((int)k != stem && t == plan.ops[stem].in[0]) return TRTX_ERR_UNSUPPORTED;
+    const ConvArgs& a = plan.ops[stem].conv;
+    std::vector<StemFrame> fr(batch);
+    for (int i = 0; i < batch; ++i) {
+        if (!frames[i] || frame_w[i] < 1 || frame_h[i] < 1) return TRTX_ERR_INVALID;
+        fr[i].src = frames[i];
+        fr[i].w = frame_w[i];
+        fr[i].h = frame_h[i];
+        trtx_letterbox_matrix(frame_w[i], frame_h[i], a.W, a.H, fr[i].d2s);
+    }
+    c->frames = fr.data();
+    const int32_t st = execute_plan(c, batch, bindings, stream, nullptr);
+    c->frames = nullptr;
+    return st;
 }
 
 extern "C" int32_t trtx_context_set_tensor_address(trtx_context* c, const char* name, void* ptr) {

@@ -53,6 +53,8 @@ struct trtx_context {
     std::vector<CapturedGraph> seen;   // combinations enqueued once (eagerly) so far
     uint64_t enqueue_count = 0;
     struct trtx::CalibObserver* observer = nullptr;  // INT8 calibration run: statistics of every NHWC tensor written (int8.h)
+    // trtx_context_enqueue_frames: for the duration of that call, the camera frames the stem samples instead of reading its fp32 input
+    const trtx::StemFrame* frames = nullptr;
     bool tuning = false;   // tactic-timing runs: plugins, the fused detect head and RoIAlign are skipped (runtime/tune.cpp)
     int graph_state = 0;   // 0 undecided, 1 eligible, -1 never (user plugins, capture failed once, disabled)
     ~trtx_context();

@@ -552,6 +552,23 @@ struct Lowerer {
                     pt_of[l.outputs[0]] = out;
                     return true;
                 }
+                // A depthwise transposed convolution with kernel == stride, every weight 1 and no bias copies each input pixel into its
+                // k x k block: a nearest-neighbour upsample (RetinaFace's FPN spells its 2x upsample that way, retina_r50.cpp:156-172:
+                // addDeconvolutionNd(256, DimsHW{2, 2}, ones) with setNbGroups(256)).  Same values, exactly; the resize kernel moves
+                // 16-byte chunks where the direct transposed convolution walked scalars (253 us per launch on the 1280 x 1280 config).
+                {
+                    bool ones = l.groups == ti.C && l.nb_out == ti.C && l.kernel[0] == l.stride[0] && l.kernel[1] == l.stride[1] && l.kernel[0] > 1 &&
+                                l.padding[0] == 0 && l.padding[1] == 0 && l.dilation[0] == 1 && l.dilation[1] == 1 &&
+                                (int64_t)l.w0.size() == (int64_t)ti.C * l.kernel[0] * l.kernel[1];
+                    for (size_t i = 0; ones && i < l.w0.size(); ++i) ones = l.w0[i] == 1.0f;
+                    for (size_t i = 0; ones && i < l.w1.size(); ++i) ones = l.w1[i] == 0.0f;
+                    if (ones) {
+                        const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
+                        add_op(OP_RESIZE, l.name + " [all-ones depthwise deconvolution = nearest upsample]", {in}, {out});
+                        pt_of[l.outputs[0]] = out;
+                        return true;
+                    }
+                }
                 const int out = new_tensor(l.outputs[0], out_dims(), LAY_NHWC, true);
                 POp& op = add_op(OP_DECONV, l.name, {in}, {out});
                 op.src_layer = li;

@@ -75,6 +75,10 @@ class Engine:
         """bindings: list of CUDA tensors in binding order (inputs first). Async on the current stream."""
         _enqueue(self._c, self.nb_bindings, batch, bindings, stream)
 
+    def enqueue_frames(self, batch, frames, bindings, stream=None):
+        """letterbox + enqueue in one call: the stem samples the uint8 HWC BGR frames itself (trtx_context_enqueue_frames)"""
+        _enqueue_frames(self._c, self.nb_bindings, batch, frames, bindings, stream)
+
     def profile(self, batch, bindings):
         arr = (ctypes.c_void_p * self.nb_bindings)(*[t.data_ptr() for t in bindings])
         out = ctypes.c_char_p()
@@ -114,6 +118,16 @@ class Engine:
             pass
 
 
+def _enqueue_frames(ctx, nb, batch, frames, bindings, stream):
+    """frames: list of uint8 HWC BGR CUDA tensors (one per image, any sizes); bindings as for enqueue (the input entry may be None)."""
+    arr = (ctypes.c_void_p * nb)(*[(t.data_ptr() if t is not None else None) for t in bindings])
+    fp = (ctypes.c_void_p * batch)(*[f.data_ptr() for f in frames[:batch]])
+    fw = (ctypes.c_int32 * batch)(*[int(f.shape[1]) for f in frames[:batch]])
+    fh = (ctypes.c_int32 * batch)(*[int(f.shape[0]) for f in frames[:batch]])
+    st = capi._stream() if stream is None else ctypes.c_void_p(stream)
+    check(lib().trtx_context_enqueue_frames(ctx, batch, fp, fw, fh, arr, st), "trtx_context_enqueue_frames")
+
+
 def _enqueue(ctx, nb, batch, bindings, stream):
     arr = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in bindings])
     st = capi._stream() if stream is None else ctypes.c_void_p(stream)
@@ -133,6 +147,9 @@ class ExecutionContext:
 
     def enqueue(self, batch, bindings, stream=None):
         _enqueue(self._c, self.engine.nb_bindings, batch, bindings, stream)
+
+    def enqueue_frames(self, batch, frames, bindings, stream=None):
+        _enqueue_frames(self._c, self.engine.nb_bindings, batch, frames, bindings, stream)
 
     def close(self):
         if self._c:

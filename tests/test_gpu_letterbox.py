@@ -91,3 +91,51 @@ def test_letterbox_equals_the_reference_kernel(gpu):
             np.savez_compressed("gpurun_out/ref_letterbox.npz", img=img, out=want.cpu().numpy())
     finally:
         L.ref_yolov8_preprocess_destroy()
+
+
+@pytest.mark.gpu
+def test_enqueue_frames_is_letterbox_then_enqueue_bit_for_bit(gpu):
+    """f2 as specified: the letterbox fused into the stem (trtx_context_enqueue_frames: the first layer samples the uint8 HWC BGR frames
+    itself, kernels/conv_stem.hip) against the two-step path the reference's demo takes (cuda_batch_preprocess, then enqueue;
+    yolov8_det.cpp:146-160) - frames of mixed sizes and aspect ratios (upscaled, downscaled, portrait, already at network size), every
+    engine output compared as bit patterns."""
+    import torch
+    from tensorrtx_amd import engine, preproc
+    from util import synth_wts
+    path, _ = synth_wts("yolov8n")
+    B, S = 6, 640
+    plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1)
+    rng = np.random.default_rng(5)
+    sizes = [(480, 640), (1080, 1920), (640, 640), (333, 517), (900, 400), (97, 1201)]   # (h, w)
+    frames = []
+    for h, w in sizes:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        img[h // 4: h // 2, w // 4: w // 2] = rng.integers(0, 256, size=3, dtype=np.uint8)   # a flat patch: exact bilinear plateaus
+        frames.append(torch.from_numpy(img).to(gpu))
+    e = engine.Engine(plan)
+    try:
+        def outputs():
+            return [None if e.is_input[i] else torch.full((B * int(np.prod(e.dims[i])),), float("nan"), dtype=torch.float32, device=gpu) for i in range(e.nb_bindings)]
+        two = outputs()
+        x = preproc.letterbox_batch(frames, S, S)
+        e.enqueue(B, [x if t is None else t for t in two])
+        one = outputs()
+        e.enqueue_frames(B, frames, one)
+        torch.cuda.synchronize()
+        for i in range(e.nb_bindings):
+            if e.is_input[i]:
+                continue
+            a, b = one[i].view(torch.int32), two[i].view(torch.int32)
+            assert torch.equal(a, b), (e.names[i], int((a != b).sum()))
+        assert two[e.names.index("output")].reshape(B, -1)[:, 0].sum() > 0      # (noise frames: some images have no candidate at all)
+        # a batch smaller than max_batch, through a second execution context
+        ctx = e.create_context()
+        one3, two3 = outputs(), outputs()
+        ctx.enqueue(3, [preproc.letterbox_batch(frames[3:], S, S) if t is None else t for t in two3])
+        ctx.enqueue_frames(3, frames[3:], one3)
+        torch.cuda.synchronize()
+        k = e.names.index("output")
+        n = 3 * int(np.prod(e.dims[k]))
+        assert torch.equal(one3[k][:n].view(torch.int32), two3[k][:n].view(torch.int32))
+    finally:
+        e.close()

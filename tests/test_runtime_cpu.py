@@ -212,7 +212,8 @@ def test_retinaface_lowering_at_config4_size(monkeypatch):
     assert len(convs) + 2 * len(chains) == 82 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == len(convs) - 1
     assert abs(low["flops_per_sample"] / 1e9 - 354.0) < 1.0          # 354 GFLOP @1280^2
     assert "copy_nhwc" not in kinds and "act_nhwc" not in kinds      # SSH ReLU pushed into the conv epilogues, heads aliased
-    assert kinds.count("deconv") == 2 and kinds.count("plugin") == 1
+    # the FPN's two all-ones depthwise 2x2/2 deconvolutions (retina_r50.cpp:156-172) are what they compute: nearest upsamples
+    assert kinds.count("deconv") == 0 and kinds.count("resize") == 2 and kinds.count("plugin") == 1
     plug = [l for l in engine.describe_plan(plan)["layers"] if l["kind"] == 16][0]
     assert np.frombuffer(bytes.fromhex(plug["plugin_blob"]), dtype=np.int32).tolist() == [1280, 1280]
 
