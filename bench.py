@@ -62,9 +62,11 @@ def _kernel_duration_from_profile(model):
     from HIP events attached to each launch - the same begin / end timestamps - or, failing that, from the stream events around
     each op, which also contain the hand-over between two launches)."""
     import re
-    name = {"yolov8n": "r02_kernel_stats_c3_1ctx_lanes1.txt"}.get(model)
-    if not name:
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_c3_1ctx_lanes1.txt"))) if model == "yolov8n" else []
+    if not cand:
         return None, None
+    name = os.path.basename(cand[-1])   # the latest round's
     try:
         calls, tot = 0, 0.0
         for line in open(os.path.join(ROOT, "profiles", name)):

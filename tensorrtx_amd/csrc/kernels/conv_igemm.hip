@@ -230,7 +230,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 // (two LDS stages, one barrier per step).  Same LDS contents, same MFMA order: bit-identical results.
 // UP = folded nearest 2x upsample (ConvArgs::up_in, 1x1 stride-1 layers): k-steps whose channel offset lies below up_C fetch their A rows
 // from the half-resolution tensor at (h >> 1, w >> 1) through a second buffer descriptor; everything after the fetch is unchanged.
-template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false>
+// ONE = 1x1 stride-1 unpadded convolution over un-padded channels (Cin == CinK): a plain GEMM.  There is no tap to validate and no ragged
+// channel chunk, so the per-step source address of a piece is its pixel's base plus a running byte offset - one VALU add where the general
+// walk spends a shift, a mask, a compare and a select per piece (the loop is issue-bound: 2.4 VALU per MFMA, r03_sq_counters_res5_3x3.txt).
+// Rows beyond M carry an out-of-range base from the start; the run-out steps past K read whatever follows (they are never multiplied).
+// Measured (round 3, same box): the 1x1 layers of YOLOv8n b32 3-10 % faster one at a time (34-layer sum 715 vs 724 us), res5's 1x1
+// 2048 -> 512 GEMM 497 vs 509 us; bench.py within run-to-run noise (35.0-35.2k vs 34.4-35.3k img/s).  Same bits.
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
+          bool ONE = false>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
         const int wi0 = wo * p.stride_w - p.pad_w;
         a_base[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.ld_in + cchunk * 8) * 2u;  // element index < 2^30 (slice < 2 GB)
         if constexpr (UP) a_up[i] = (unsigned)(((n * p.up_H + (ho >> 1)) * p.up_W + (wo >> 1)) * p.up_ld + cchunk * 8) * 2u;
+        if constexpr (ONE) a_base[i] = ok ? a_base[i] : kOOB;   // (kOOB + any k offset < 2^30 stays out of range)
         // taps inside the image form a contiguous range (dilation 1): closed form instead of a loop over taps
         a_rows[i] = ok ? tap_range_mask(hi0, p.kh, p.H) : 0u;
         a_cols[i] = tap_range_mask(wi0, p.kw, p.W);
@@ -370,7 +378,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     auto issue_tile = [&](int stage) {
         char* sbase = smem + stage * STAGE_BYTES;
         const bool live = s_kt < nk && !(dbg & 1);
-        if (TPS == 1) {
+        if constexpr (ONE) {
+            const unsigned koff = (unsigned)s_kt * (unsigned)(BKT * 2);   // scalar
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const unsigned voff = a_base[i] + koff;
+                if constexpr (RS) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (NW * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
+            }
+        } else if (TPS == 1) {
             const unsigned add = (unsigned)__builtin_amdgcn_readlane((int)t_add, s_kt & 63);
             const unsigned tw = (unsigned)__builtin_amdgcn_readlane((int)t_tap, s_kt & 63);
             const int tap = (int)(tw & 255u), uc = (int)(tw >> 8);
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
-            const unsigned voff = (s_kt < nk && !(dbg & 2)) ? b_off[j] : kOOB;
+            const unsigned voff = ONE ? b_off[j] : ((s_kt < nk && !(dbg & 2)) ? b_off[j] : kOOB);
             if constexpr (RS) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (NW * j + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
             b_off[j] += BKT * 2;  // kOOB stays out of range for any K < 2^30
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
                 tap_next(s_r[t], s_q[t]);
                 s_toff[t] = (unsigned)((s_r[t] * p.dil_h * p.W + s_q[t] * p.dil_w) * p.ld_in) * 2u;
             }
-        } else if ((s_kt & 63) == 0) {
+        } else if (!ONE && (s_kt & 63) == 0) {
             build_window(s_kt);  // next 64-step window (uniform, once per 64 steps)
         }
     };
@@ -1012,6 +1028,18 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
                             in_bytes, w_bytes, tiles_n, total, chunk, dbg);
             else
                 TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
+                            in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            return;
+        }
+    }
+    if constexpr (TPS == 1 && !I8) {
+        static const bool one_off = getenv("TRTX_CONV_NOONE") != nullptr;   // A/B switch
+        if (!one_off && a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K) {
+            if (rs_on)
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
+                            in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            else
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, false, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
                             in_bytes, w_bytes, tiles_n, total, chunk, dbg);
             return;
         }

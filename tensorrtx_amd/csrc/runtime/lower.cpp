@@ -1364,7 +1364,14 @@ struct Lowerer {
                 // registers instead of LDS-DMA: bit-identical results, and on YOLOv8n b32 with three contexts 34.2-34.5k img/s against
                 // 33.3-33.6k (same box, alternating runs) - a DMA piece costs its wave 60-185 cycles of issue, which co-scheduled
                 // workgroups of other contexts cannot hide for each other; a lone context is 3 % slower with it and keeps the DMA.
-                t.t_rs = net.max_aux_streams == 0 ? 1 : 0;
+                // ... and only for layers below the MFMA / HBM ridge (312 FLOP per byte): the MFMA-bound GEMMs of res5 lose with it (C5 three
+                // contexts 12.1 vs 11.65 ms; tools/gemm_tactics.py: K = 4608 0.39 vs 0.42 of peak), ResNet-50 gains 2.2 %, RetinaFace is
+                // indifferent (profiles/r03_rs_ab.txt).
+                {
+                    const double flop_px = 2.0 * a.Cout * (double)a.kh * a.kw * a.Cin;
+                    const double byte_px = 2.0 * ((double)a.Cin * a.stride_h * a.stride_w + (double)a.Cout * (op.in.size() > 1 ? 2 : 1));
+                    t.t_rs = (net.max_aux_streams == 0 && flop_px / byte_px < 312.0) ? 1 : 0;
+                }
                 if (conv_igemm_supported(t)) {
                     a = t;
                     op.igemm = true;
