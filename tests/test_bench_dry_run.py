@@ -52,3 +52,19 @@ def test_bench_control_flow_strong_scaling_two_ranks():
     d = _run(2, ("--mode", "strong"))
     assert d["scaling"] == "strong" and d["n_gpus"] == 2
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the global batch is fixed: 16 + 16
+
+
+def test_bench_control_flow_c4_strong_split_builds_small_batch_engines():
+    """C4 (RetinaFace-R50 1280x1280, global batch 8) is strong-scaled by default: with 8 GPUs every rank gets ONE image, so the builders must
+    accept a max batch below the config's.  Two ranks here (4 images each) through the same code; the batch-1 build itself is checked on
+    this process (the shape rank k of 8 would build)."""
+    d = _run(2, ("--config", "retinaface_r50"))
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tensorrtx_amd import engine, replicas
+    from util import synth_wts
+    assert [len(list(replicas.partition(8, 8, r))) for r in range(8)] == [1] * 8
+    path, _ = synth_wts("retinaface_r50")
+    plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280, aux_streams=0)
+    assert engine.describe_plan(plan, lowered=True)["max_batch"] == 1

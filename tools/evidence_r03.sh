@@ -40,32 +40,44 @@ if [ $PART = prof ] || [ $PART = all ]; then
   prof c2 "--config resnet50"
   prof c4 "--config retinaface_r50"
   prof c5 "--config rcnn_r50c4"
-  OUT=$E/pmc
-  (cd /tmp && timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $OUT -o c -- python $R/bench.py --contexts 1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline > $OUT.log 2>&1)
+fi
+if [ $PART = pmc ] || [ $PART = prof ] || [ $PART = all ]; then
+  # HBM traffic of the conv launches from the L2 fabric counters, one pass per configuration (its own run: --pmc with --kernel-trace only)
+  for cfg in yolov8n resnet50 retinaface_r50 rcnn_r50c4; do
+    OUT=$E/pmc_$cfg
+    timeout 300 python bench.py --config $cfg --contexts 1 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline > /dev/null 2>&1      # tactic cache
+    (cd /tmp && timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $OUT -o c -- python $R/bench.py --config $cfg --contexts 1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline > $OUT.log 2>&1)
+  done
   python - <<PY
 import csv, glob, collections, json
-f = glob.glob("$OUT/**/c_counter_collection.csv", recursive=True)[0]
-per = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
-for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"]
-    fam = "conv" if ("conv_igemm" in k or "conv_ws" in k) else ("conv_stem" if "conv_stem" in k else ("yolo" if "yolo" in k else "other"))
-    per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
-    key = (r["Dispatch_Id"], fam)
-    if key not in seen:
-        seen.add(key); n[fam] += 1
-lines = ["# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -- python bench.py --contexts 1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline (round 3, final build)",
-         "# bytes = (2 x RDREQ + WRREQ) x 64 B  (reads doubled: gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section)"]
-res = {}
-for fam, d in per.items():
-    rd, wr = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_WRREQ_sum", 0.0)
-    byts = (2 * rd + wr) * 64
-    res[fam] = byts / max(n[fam], 1)
-    lines.append(f"{fam:12s} launches {n[fam]:6d}  RDREQ {rd:14.0f}  WRREQ {wr:14.0f}  bytes/launch {byts / max(n[fam], 1):14.0f}")
+lines = ["# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -- python bench.py --config X --contexts 1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline (round 3, final build)",
+         "# bytes = (2 x RDREQ + WRREQ) x 64 B  (reads doubled: gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); per launch, mean over the launches of the run"]
+out = {}
+for cfg in ("yolov8n", "resnet50", "retinaface_r50", "rcnn_r50c4"):
+    fs = glob.glob("$E/pmc_%s/**/c_counter_collection.csv" % cfg, recursive=True)
+    if not fs:
+        lines.append(f"{cfg}: no counter file")
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"]
+        fam = "conv" if ("conv_igemm" in k or "conv_ws" in k) else ("conv_stem" if "conv_stem" in k else ("yolo" if "yolo" in k else "other"))
+        per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (r["Dispatch_Id"], fam)
+        if key not in seen:
+            seen.add(key); n[fam] += 1
+    lines.append(f"== {cfg}")
+    for fam, d in per.items():
+        rd, wr = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_WRREQ_sum", 0.0)
+        byts = (2 * rd + wr) * 64
+        lines.append(f"{fam:12s} launches {n[fam]:6d}  RDREQ {rd:14.0f}  WRREQ {wr:14.0f}  bytes/launch {byts / max(n[fam], 1):14.0f}")
+        if fam == "conv":
+            out[cfg] = {"bytes_per_launch": byts / max(n[fam], 1), "source": "profiles/r03_pmc_conv_traffic.txt (separate rocprofv3 --pmc pass over bench.py --config %s, fused MFMA conv kernels: conv_igemm* + conv_ws*)" % cfg}
 open("$E/pmc_conv_traffic.txt", "w").write("\n".join(lines) + "\n")
-json.dump({"yolov8n": {"bytes_per_launch": res.get("conv"), "source": "profiles/r03_pmc_conv_traffic.txt (separate rocprofv3 --pmc pass over bench.py, fused MFMA conv kernels: conv_igemm* + conv_ws*)"}}, open("$E/pmc_conv_traffic.json", "w"), indent=1)
+json.dump(out, open("$E/pmc_conv_traffic.json", "w"), indent=1)
 print("\n".join(lines))
 PY
-  rm -rf $OUT
+  rm -rf $E/pmc_*/
 fi
 if [ $PART = suite ] || [ $PART = all ]; then
   unset TRTX_TACTIC_CACHE
