@@ -158,6 +158,125 @@ def _spawn_self(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def run_in_process(args):
+    """--replicas in-process: ONE process drives --gpus N devices through replicas.DeviceReplicas - the reference's own recipe for one
+    host with several GPUs (tutorials/multi_GPU_processing.md:13-30: cudaSetDevice(i), one {engine, context, stream, buffers} per device).
+    Same plan on every device, --contexts execution contexts per device, images resident per device, no cross-device traffic; a "step"
+    enqueues one batch on EVERY device.  The driver's contract is one process per GPU (the default path); this is the alternative for
+    callers that own all GPUs from one address space.  YOLOv8n (C3) only."""
+    import numpy as np
+    import torch
+
+    dry = args.dry_run
+    n_dev = args.gpus
+    if dry:
+        from tensorrtx_amd import dryrun
+        tc = dryrun.FakeCuda(n_dev)
+    else:
+        tc = torch.cuda
+        if not tc.is_available() or tc.device_count() < n_dev:
+            raise SystemExit(f"--replicas in-process --gpus {n_dev}: {tc.device_count() if tc.is_available() else 0} GPU(s) visible")
+    from tensorrtx_amd import capi, engine, replicas, synth
+    from tensorrtx_amd import wts as wts_writer
+
+    if args.config != "yolov8n" or args.precision != "fp16":
+        raise SystemExit("--replicas in-process: yolov8n fp16 only")
+    cfg = CONFIGS["yolov8n"]
+    batch, H, W = cfg["batch"], cfg["h"], cfg["w"]
+    cache = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
+    os.makedirs(cache, exist_ok=True)
+    path = os.path.join(cache, "bench_yolov8n_seed0.wts")
+    if not os.path.exists(path):
+        tmp = path + f".{os.getpid()}.tmp"
+        wts_writer.write_wts(tmp, synth.yolov8n_state(seed=0), dialect="double")
+        os.replace(tmp, path)
+    n_ctx = max(1, args.contexts)
+    if not dry:
+        tc.set_device(0)
+    plan = engine.build_plan("yolov8n", path, batch=batch, h=H, w=W, fp16=1, aux_streams=0 if n_ctx > 1 else -1)   # built (tactics timed) next to device 0
+    low = engine.describe_plan(plan, lowered=True)
+    make_engine = (lambda d: dryrun.DeviceEngine(plan, engine.describe_plan)) if dry else (lambda d: engine.Engine(plan))
+    if dry:
+        reps = dryrun.Replicas(range(n_dev), make_engine)
+    else:
+        reps = replicas.DeviceReplicas(range(n_dev), make_engine)
+    L = None if dry else capi.lib()
+    if L:
+        L.trtx_yolo_nms_workspace.restype = ctypes.c_size_t
+    imgs = synth.images(batch, H, W, seed=100)
+
+    class Slot:
+        def __init__(self, d, e, ctx):
+            dev = torch.device("cpu") if dry else torch.device("cuda", d)
+            self.d, self.ctx = d, ctx
+            self.stream = tc.Stream() if dry else tc.Stream(device=d)
+            self.x = torch.from_numpy(imgs).to(dev)
+            self.out = (torch.zeros if dry else torch.empty)((batch, 1 + 1000 * 90), dtype=torch.float32, device=dev)
+            self.keep_idx = torch.empty((batch, 1000), dtype=torch.int32, device=dev)
+            self.keep_cnt = torch.zeros((batch,), dtype=torch.int32, device=dev)
+            self.keep_det = torch.empty((batch, 1000, 6), dtype=torch.float32, device=dev)
+            self.ws_bytes = L.trtx_yolo_nms_workspace(batch) if L else 256
+            self.ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+
+        def run(self):
+            self.ctx.enqueue(batch, [self.x, self.out], stream=self.stream.cuda_stream)
+            if L:
+                capi.check(L.trtx_yolo_nms(capi._p(self.out), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(self.keep_idx), capi._p(self.keep_cnt),
+                                           capi._p(self.keep_det), capi._p(self.ws), ctypes.c_size_t(self.ws_bytes), ctypes.c_void_p(self.stream.cuda_stream)), "trtx_yolo_nms")
+
+    slots = []   # slots[d][j]
+    for d, e in zip(reps.devices, reps.engines):
+        if not dry:
+            tc.set_device(d)
+        slots.append([Slot(d, e, e if j == 0 else e.create_context()) for j in range(n_ctx)])
+
+    def sync_all():
+        for d in reps.devices:
+            if not dry:
+                tc.set_device(d)
+            tc.synchronize()
+
+    def step(k):
+        for d in range(n_dev):     # engines are bound to their device: make it current for the launches
+            if not dry:
+                tc.set_device(reps.devices[d])
+            slots[d][k % n_ctx].run()
+
+    for k in range(max(24, 8 * n_ctx)):   # settle
+        step(k)
+    sync_all()
+    legs = []
+    for _ in range(max(1, args.repeats)):
+        for k in range(args.warmup):
+            step(k)
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        sync_all()
+        legs.append(time.perf_counter() - t0)
+    dt = sorted(legs)[len(legs) // 2]
+    if not dry:
+        tc.set_device(reps.devices[0])
+    kept = float(slots[0][0].keep_cnt.float().mean().item())
+    res = {
+        "metric": f"images/sec @ batch={batch} {W}x{H} fp16 (yolov8n conv backbone + YoloLayer decode + NMS)", "value": n_dev * batch * args.steps / dt, "unit": "images/sec",
+        "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "legs_ms": [round(x / args.steps * 1e3, 4) for x in legs], "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"yolov8n fp16 {W}x{H}, C3 (BASELINE configs[2]): per-GPU batch {batch}, enqueue + GPU NMS, {n_ctx} execution contexts per device",
+                   "contexts": n_ctx, "global_batch": n_dev * batch,
+                   "parallelism": f"ONE process driving {n_dev} device(s) through DeviceReplicas (tutorials/multi_GPU_processing.md:13-30); image-sharded, no cross-device traffic"},
+        "roofline": None, "cpu_baseline": None,
+        "note": "in-process replicas is a secondary mode: roofline / cpu_baseline / parity are printed by the default one-process-per-GPU path",
+        "detections": {"kept_after_nms_per_image": kept},
+    }
+    if dry:
+        res["dry_run"] = True
+        res["data"] = "NONE: --dry-run rehearses the control flow on CPU; every number in this line is meaningless"
+    print(json.dumps(res), flush=True)
+    reps.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +291,8 @@ def main():
                     help="execution contexts kept in flight per GPU (each on its own stream; 1 = the reference's serial loop)")
     ap.add_argument("--repeats", type=int, default=7,
                     help="the W-warm-up + K-step timed leg is run this many times back to back; `value` is the MEDIAN leg (all legs are printed)")
+    ap.add_argument("--replicas", default="processes", choices=["processes", "in-process"],
+                    help="processes (default, the driver's contract): one rank per GPU; in-process: this one process drives --gpus devices through DeviceReplicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of this script's control flow (ranks over gloo, rank 0 builds and broadcasts the plan, legs / barriers / "
@@ -180,6 +301,8 @@ def main():
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent timing table (JSON) to this path")
     args = ap.parse_args()
 
+    if args.replicas == "in-process":
+        return run_in_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_self(args)
 

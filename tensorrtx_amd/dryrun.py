@@ -91,3 +91,19 @@ class DryEngine:
 
     def close(self):
         pass
+
+
+class DeviceEngine(DryEngine):
+    """DryEngine with the [input, output] binding order bench.py's in-process path uses"""
+
+
+class Replicas:
+    """replicas.DeviceReplicas without devices: one stand-in engine per index"""
+
+    def __init__(self, devices, make_engine):
+        self.devices = list(devices)
+        self.engines = [make_engine(d) for d in self.devices]
+        self.streams = [Stream() for _ in self.devices]
+
+    def close(self):
+        self.engines = []

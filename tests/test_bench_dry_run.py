@@ -68,3 +68,17 @@ def test_bench_control_flow_c4_strong_split_builds_small_batch_engines():
     path, _ = synth_wts("retinaface_r50")
     plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280, aux_streams=0)
     assert engine.describe_plan(plan, lowered=True)["max_batch"] == 1
+
+
+def test_bench_in_process_replicas_control_flow():
+    """--replicas in-process: one process, N devices through DeviceReplicas (the reference's tutorials/multi_GPU_processing.md recipe); dry run
+    with three stand-in devices: every device gets a batch per step, value = all devices' images over the host clock."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--replicas", "in-process", "--gpus", "3", "--steps", "6", "--warmup", "2",
+                        "--repeats", "3"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dry_run"] is True and d["n_gpus"] == 3 and d["config"]["global_batch"] == 96 and len(d["legs_ms"]) == 3
+    assert abs(d["value"] - 96 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
