@@ -71,6 +71,9 @@ BUILDERS = {
     "lenet": (["lenet/lenet.cpp"], ["lenet"], "build_lenet.cpp", []),
     "resnet50": (["resnet/resnet50.cpp"], ["resnet"], "build_resnet50.cpp", []),
     "retinaface": (["retinaface/retina_r50.cpp", "retinaface/decode.cu"], ["retinaface"], "build_retinaface.cpp", []),
+    # the reference's DEFAULT RetinaFace build (USE_INT8, its own calibrator reading a calibration table); no precision patch for this one
+    "retinaface_int8": (["retinaface/retina_r50.cpp", "retinaface/decode.cu", "retinaface/calibrator.cpp"], ["retinaface"], "build_retinaface_int8.cpp",
+                        ["REF_COMPAT_HOST_MALLOC_FALLBACK"]),
     "rcnn": (["rcnn/rcnn.cpp", "rcnn/RpnDecode.cu", "rcnn/RpnNms.cu", "rcnn/RoiAlign.cu", "rcnn/PredictorDecode.cu", "rcnn/BatchedNms.cu",
               "rcnn/MaskRcnnInference.cu"], ["rcnn"], "build_rcnn.cpp", []),
 }
@@ -78,10 +81,10 @@ BUILDERS = {
 INCLUDED_BY_HARNESS = {"lenet/lenet.cpp", "resnet/resnet50.cpp", "retinaface/retina_r50.cpp", "rcnn/rcnn.cpp"}
 
 
-def _patched(rel):
+def _patched(rel, only_generic=False):
     with open(os.path.join(REF, rel)) as f:
         text = f.read()
-    for pat, rep in PATCHES["*"] + PATCHES.get(rel, []):
+    for pat, rep in PATCHES["*"] + ([] if only_generic else PATCHES.get(rel, [])):
         text = re.sub(pat, rep, text)
     return text
 
@@ -158,7 +161,8 @@ def build_builder(name):
     gen_srcs = []
     for rel in srcs:
         dst = os.path.join(gdir, os.path.basename(rel))
-        _write_if_changed(dst, "// generated from %s by oracle/ref_build.py (lexical patches only; not tracked)\n" % rel + _patched(rel))
+        # (the precision switch of retina_r50.cpp is NOT applied to the builder that pins the reference's default INT8 configuration)
+        _write_if_changed(dst, "// generated from %s by oracle/ref_build.py (lexical patches only; not tracked)\n" % rel + _patched(rel, only_generic=name.endswith("_int8")))
         if rel not in INCLUDED_BY_HARNESS:
             gen_srcs.append(dst)
     hsrc = os.path.join(HERE, "ref_harness", harness)

@@ -35,6 +35,11 @@ CASES = {
     # blob still means 480 x 640).  `decode_state` = the state the product must have written; it is cut out before comparing.
     "retinaface_r50": dict(lib="retinaface", wts="retinaface_r50", model="retinaface_r50", opts=dict(batch=1, fp16=1, h=480, w=640),
                            decode_state=(480, 640)),
+    # The reference's DEFAULT RetinaFace build: `#define USE_INT8` (retina_r50.cpp:12, :219-225) = BuilderFlag::kINT8 alone + ITS Int8EntropyCalibrator2
+    # (retinaface/calibrator.cpp) reading "r50_int8calib.table"; the table (TensorRT's text format) is written by the test with one scale per
+    # tensor of the network, so no image and no GPU is needed.  The product builds the same network with the same table through its calibrator.
+    "retinaface_r50_int8": dict(lib="retinaface_int8", wts="retinaface_r50", model="retinaface_r50", opts=dict(batch=1, fp16=0, int8=1, h=480, w=640),
+                                decode_state=(480, 640), calib_table="r50_int8calib.table"),
     # rcnn/rcnn.cpp:310 BuildRcnnModel -> createEngine_rcnn :250 after calculateSize :349 (480 x 640 image -> 800 x 1067 input), "fp16"
     "faster_rcnn_r50c4": dict(lib="rcnn", wts="rcnn_r50c4", model="rcnn_r50c4", opts=dict(batch=1, fp16=1, h=800, w=1067), mask=0),
     # the same with MASK_ON (rcnn.cpp:41, :277-296: mask head + MaskRcnnInference plugin, second output)
@@ -51,6 +56,20 @@ def lib_path(case):
     return os.path.join(REF_DIR, f"libref_build_{CASES[case]['lib']}.so")
 
 
+def calibration_table(case: str) -> bytes:
+    """A TensorRT-format calibration cache with one (seeded, distinct) scale per tensor of the case's network: names from the fp16 plan."""
+    import numpy as np
+    from tensorrtx_amd import engine
+
+    c = CASES[case]
+    wts, _ = synth_wts(c["wts"])
+    opts = dict(c["opts"], fp16=1)
+    opts.pop("int8", None)
+    names = [t["name"] or f"(Unnamed Tensor* {t['id']})" for t in engine.describe_plan(engine.build_plan(c["model"], wts, **opts))["tensors"]]
+    scales = np.random.default_rng(7).uniform(0.01, 0.2, len(names)).astype(np.float32)
+    return b"TRT-8601-EntropyCalibration2\n" + b"".join(f"{n}: {struct.unpack('<I', struct.pack('<f', float(s)))[0]:08x}\n".encode() for n, s in zip(names, scales))
+
+
 def _load(case):
     from tensorrtx_amd import capi
 
@@ -64,6 +83,8 @@ def reference_plan(case: str) -> bytes:
     In a child process: the reference libraries register THEIR plugin creators (REGISTER_TENSORRT_PLUGIN at load time) in the process-wide
     registry and change the working directory; neither may leak into the process that builds and lowers the product's plans."""
     synth_wts(CASES[case]["wts"])  # create the cached weights here, once, not in the child
+    if "calib_table" in CASES[case]:
+        calibration_table(case)
     fd, path = tempfile.mkstemp(prefix="trtx_refplan_", suffix=".plan")
     os.close(fd)
     try:
@@ -83,14 +104,17 @@ def _reference_plan_here(case: str) -> bytes:
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp(prefix="trtx_refbuild_")
     try:
-        if c["lib"] in ("lenet", "resnet50", "retinaface"):
+        if c["lib"] in ("lenet", "resnet50", "retinaface", "retinaface_int8"):
             # these programs open a fixed relative path from their working directory
-            rel = {"lenet": "../models/lenet.wts", "resnet50": "../resnet50.wts", "retinaface": "../retinaface.wts"}[c["lib"]]
+            rel = {"lenet": "../models/lenet.wts", "resnet50": "../resnet50.wts", "retinaface": "../retinaface.wts", "retinaface_int8": "../retinaface.wts"}[c["lib"]]
             run = os.path.join(tmp, "build")
             os.makedirs(run)
             dst = os.path.normpath(os.path.join(run, rel))
             os.makedirs(os.path.dirname(dst), exist_ok=True)
             shutil.copy(wts, dst)
+            if "calib_table" in c:   # the table the reference's calibrator will find in its working directory
+                with open(os.path.join(run, c["calib_table"]), "wb") as f:
+                    f.write(calibration_table(case))
             rc = getattr(L, f"ref_build_{c['lib']}")(run.encode(), 1, ctypes.byref(out), ctypes.byref(n))
         elif c["lib"] == "rcnn":
             rc = L.ref_build_rcnn(wts.encode(), 1, b"fp16", c["mask"], ctypes.byref(out), ctypes.byref(n))
@@ -112,7 +136,12 @@ def product_plan(case: str) -> bytes:
 
     c = CASES[case]
     wts, _ = synth_wts(c["wts"])
-    plan = engine.build_plan(c["model"], wts, **c["opts"])
+    if "calib_table" in c:
+        from tensorrtx_amd import calibrator
+        with calibrator.Calibrator(cache=calibration_table(case)).installed():
+            plan = engine.build_plan(c["model"], wts, **c["opts"])
+    else:
+        plan = engine.build_plan(c["model"], wts, **c["opts"])
     if "decode_state" in c:
         marker = struct.pack("<i", 10) + b"Decode_TRT" + struct.pack("<i", 1) + b"1"
         at = plan.rfind(marker) + len(marker)
