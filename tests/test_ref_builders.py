@@ -8,6 +8,7 @@ Two legs per case, both CPU:
 """
 import hashlib
 import os
+import sys
 
 import pytest
 
@@ -48,3 +49,31 @@ def test_host_builder_plan_matches_committed_reference_builder_digest(case):
     plan = rb.product_plan(case)
     assert len(plan) == gold["plan_bytes"]
     assert hashlib.sha256(plan).hexdigest() == gold["plan_sha256"]
+
+
+@pytest.mark.gpu
+def test_a_plan_serialized_by_the_reference_builder_runs_on_the_gpu(gpu, monkeypatch):
+    """The plan the REFERENCE'S buildEngineYolov8Det serialized through the shim (here, next to a GPU, with TRTX_TUNE=0 so that no timing
+    noise enters either build) is the host builder's plan byte for byte, deserializes, and detects what the fp32 oracle detects."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import models_torch as mt
+    from oracle import wts as owts
+    from oracle import yolo_post as yp
+    from tensorrtx_amd import synth
+    from test_gpu_engine import _match_detections, _run
+    from util import synth_wts
+    if not os.path.exists(rb.lib_path("yolov8n_det")):
+        pytest.skip("oracle/_ref builder library not present")
+    monkeypatch.setenv("TRTX_TUNE", "0")
+    ref, mine = rb.reference_plan("yolov8n_det"), rb.product_plan("yolov8n_det")
+    assert ref == mine
+    x = synth.images(1, 640, 640, seed=1)
+    out = _run(ref, {"images": x}, 1, gpu)["output"].reshape(1, -1).numpy()
+    path, _ = synth_wts("yolov8n")
+    with torch.inference_mode():
+        heads, strides = mt.yolov8_det(mt.Params(owts.load_wts(path)), torch.from_numpy(x))
+    dec_ref = yp.decode_c([h.numpy() for h in heads], 80, 640, 640, strides)
+    st = _match_detections(out, dec_ref)
+    assert st["ref"] > 20 and st["matched"] >= 0.99 * st["ref"] and st["min_iou"] > 0.99
