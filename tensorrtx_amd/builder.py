@@ -83,6 +83,13 @@ class Network:
     def elementwise(self, a, b, op=0):
         return self._layer(self.L.trtx_add_elementwise(self.n, a, b, op), "add_elementwise")
 
+    def resize_nearest(self, x, scale=2):
+        """IResizeLayer, nearest, integer scale on H and W (setScales({1, s, s}))"""
+        l = self._layer(self.L.trtx_add_resize(self.n, x), "add_resize")
+        sc = (ctypes.c_float * 3)(1.0, float(scale), float(scale))
+        check(self.L.trtx_layer_set_floats(self.n, l, 12, sc, 3), "trtx_layer_set_floats(resize scales)")   # TRTX_P_RESIZE_SCALES
+        return l
+
     def concat(self, tensors):
         arr = (ctypes.c_int32 * len(tensors))(*tensors)
         return self._layer(self.L.trtx_add_concatenation(self.n, arr, len(tensors)), "add_concatenation")

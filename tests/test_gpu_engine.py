@@ -9,6 +9,7 @@ Tolerances (north_star: 1e-4 logit / 1e-3 box IoU vs the fp32 reference):
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -407,3 +408,25 @@ print('IDENTICAL')
     env = dict(os.environ, TRTX_TUNE="0", TRTX_CONV_NOWS="1", TRTX_CONV_NOWSK="1")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_folded_upsample_small_network_matches_torch(gpu, monkeypatch):
+    """The Upsample -> Concat -> Conv1x1 pattern on an ad-hoc network (ragged map 16 x 24 -> 8 x 12, batch below max_batch): folded and unfolded
+    lowering against a plain PyTorch fp32 evaluation of the same layers."""
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_runtime_cpu import _upsample_concat_net
+    plan, w = _upsample_concat_net()
+    x = torch.randn(2, 3, 16, 24, generator=torch.Generator().manual_seed(1))
+    t = {k: torch.from_numpy(v) for k, v in w.items()}
+    low = F.relu(F.conv2d(x, t["a"], stride=2, padding=1))
+    skip = F.relu(F.conv2d(x, t["b"], stride=1, padding=1))
+    ref = F.relu(F.conv2d(torch.cat([F.interpolate(low, scale_factor=2, mode="nearest"), skip], 1), t["c"]))
+    scale = ref.abs().max().item()
+    for fold in ("1", "0"):
+        monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", fold)
+        kinds = [o["kind"] for o in engine.describe_plan(plan, lowered=True)["ops"]]
+        assert ("resize" in kinds) == (fold == "0")
+        got = _run(plan, {"data": x.numpy()}, 2, gpu)["y"].reshape(ref.shape)
+        err = (got - ref).abs().max().item()
+        assert err < 4e-3 * max(scale, 1.0), (fold, err, scale)

@@ -544,3 +544,45 @@ def test_int8_tensor_on_a_convolution_without_the_mfma_path_falls_back_to_fp16()
     assert convs[1]["i8"] == [0, 0, 0] or convs[1]["i8"][:2] == [0, 0]      # the K = 16 layer reads and writes fp16
     assert convs[2]["i8"][0] == 0 and convs[2]["i8"][1] == 1                 # its consumer reads fp16 and quantises for the next layer
     assert convs[3]["i8"][0] == 1
+
+
+def _upsample_concat_net(extra_reader=False, cin_up=64, cin_skip=32, k=1, fp16=True):
+    """Upsample(2x nearest) -> Concat([up, skip]) -> Conv k x k, the YOLOv8 head shape (model.cpp:130-160), optionally with a second reader of the
+    upsampled tensor.  Returns (plan, weights) - seeded."""
+    from tensorrtx_amd import builder
+    rng = np.random.default_rng(3)
+    net = builder.Network(max_batch=2, fp16=fp16)
+    x = net.input("data", (3, 16, 24))
+    w = {}
+    w["a"] = rng.normal(0, 0.2, (cin_up, 3, 3, 3)).astype(np.float32)       # low-resolution branch: stride 2
+    w["b"] = rng.normal(0, 0.2, (cin_skip, 3, 3, 3)).astype(np.float32)     # skip branch at full resolution
+    w["c"] = rng.normal(0, 0.1, (48, cin_up + cin_skip, k, k)).astype(np.float32)
+    low = net.out(net.activation(net.out(net.conv(x, w["a"], stride=2, padding=1)), "relu"))
+    skip = net.out(net.activation(net.out(net.conv(x, w["b"], stride=1, padding=1)), "relu"))
+    up = net.out(net.resize_nearest(low, 2))
+    cat = net.out(net.concat([up, skip]))
+    y = net.out(net.activation(net.out(net.conv(cat, w["c"], padding=k // 2)), "relu"))
+    net.mark_output(y, "y")
+    if extra_reader:
+        w["d"] = rng.normal(0, 0.1, (16, cin_up, 1, 1)).astype(np.float32)
+        net.mark_output(net.out(net.conv(up, w["d"])), "z")
+    plan = net.build()
+    net.close()
+    return plan, w
+
+
+def test_upsample_is_folded_only_where_it_is_safe(monkeypatch):
+    """lower.cpp fold_upsample: the resize disappears into the 1x1 convolution that reads the concat buffer - but not when something else
+    reads the upsampled tensor, not into a 3x3, not when the slice is not a whole number of 64-channel k-steps, not in fp32, and not
+    with TRTX_FOLD_UPSAMPLE=0."""
+    def kinds(plan):
+        low = engine.describe_plan(plan, lowered=True)
+        return [o["kind"] for o in low["ops"]], [o for o in low["ops"] if o["kind"] == "conv"]
+    k, convs = kinds(_upsample_concat_net()[0])
+    assert "resize" not in k and [o["up_c"] for o in convs if o["up_c"]] == [64]
+    assert "resize" in kinds(_upsample_concat_net(extra_reader=True)[0])[0]
+    assert "resize" in kinds(_upsample_concat_net(k=3)[0])[0]
+    assert "resize" in kinds(_upsample_concat_net(cin_up=32)[0])[0]
+    assert "resize" in kinds(_upsample_concat_net(fp16=False)[0])[0]
+    monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", "0")
+    assert "resize" in kinds(_upsample_concat_net()[0])[0]
