@@ -95,26 +95,44 @@ __device__ __forceinline__ int swz(int row) {
 // stores) exists ONCE, in a rolled loop with wave-uniform branches, instead of once per accumulator fragment and activation
 // kind.  Unrolled, that code was 80 % of a 45-90 KB kernel against a 64 KB instruction cache shared by two CUs
 // (profiles/r02_code_size.txt).  `pixel_of(t)` maps row t of the tile (0 .. 64 * MI) to the output pixel index, or -1.
-template <int NFRAG, int NSLAB, int ROWS, int LDS_BYTES, int NWAVES, typename PixelOf, typename Fill>
-__device__ __forceinline__ void conv_epilogue_core(const ConvArgs& p, char* smem, int wave, int lane, int n0, PixelOf&& pixel_of, int rbase, Fill&& fill) {
+template <int NFRAG, int MI, bool I8, int LDS_BYTES, int NWAVES = 4, typename PixelOf>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[MI][NFRAG], intx4 (&acci)[MI][NFRAG], char* smem, int wave, int lane,
+                                              int n0, PixelOf&& pixel_of, int row0 = -1) {
     constexpr int BN = 16 * NFRAG;
+    constexpr int WR = 16 * MI;
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
     const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
+    const int px_in = lane & 15;
+    const int ch_in = (lane >> 4) * 4;
     const bool second = res || p.act2 != ACT_NONE;
     constexpr int PS = BN * 4 + 16;   // fp32 row stride of the staging tile (padded: 16 consecutive rows start in distinct bank groups)
-    static_assert(NWAVES * ROWS * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
-    constexpr int CPR = BN / 8;         // 8-channel items per row
-    constexpr int ITEMS = ROWS * CPR;   // items of one ROWS-row slab of this wave
+    static_assert(NWAVES * 16 * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
+    constexpr int CPR = BN / 8;       // 8-channel items per row
+    constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
     __syncthreads();  // every wave is done reading the last stage
-    char* mine = smem + wave * ROWS * PS;
+    char* mine = smem + wave * 16 * PS;
+    const int rbase = row0 < 0 ? wave * WR : row0;   // first tile row of this wave (waves may also be split along N: WN below)
 #pragma nounroll
-    for (int i = 0; i < NSLAB; ++i) {
-        fill(i, mine);   // accumulators of row slab i -> the wave's fp32 LDS tile [ROWS][BN]
+    for (int i = 0; i < MI; ++i) {
+        // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
+#pragma unroll
+        for (int ii = 0; ii < MI; ++ii) {
+            if (ii != i) continue;
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) {
+                floatx4 v = acc[ii][j];
+                if constexpr (I8) {
+                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
+                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
+                }
+                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
+            }
+        }
         // wave-private tile: the LDS accesses of one wave are ordered, no barrier needed
 #pragma nounroll
         for (int q = lane; q < ITEMS; q += 64) {
             const int row = q / CPR, cc = q % CPR;
-            const int m = pixel_of(rbase + i * ROWS + row);
+            const int m = pixel_of(rbase + i * 16 + row);
             const int co = n0 + cc * 8;
             if (m < 0 || co >= p.Cout) continue;
             const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
@@ -189,31 +207,6 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvArgs& p, char* smem
     }
 }
 
-// the 16x16x32 accumulator layout (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel 16i + (lane&15)) in front of the core
-template <int NFRAG, int MI, bool I8, int LDS_BYTES, int NWAVES = 4, typename PixelOf>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[MI][NFRAG], intx4 (&acci)[MI][NFRAG], char* smem, int wave, int lane,
-                                              int n0, PixelOf&& pixel_of, int row0 = -1) {
-    constexpr int PS = 16 * NFRAG * 4 + 16;
-    const int px_in = lane & 15;
-    const int ch_in = (lane >> 4) * 4;
-    conv_epilogue_core<NFRAG, MI, 16, LDS_BYTES, NWAVES>(p, smem, wave, lane, n0, pixel_of, row0 < 0 ? wave * 16 * MI : row0, [&](int i, char* mine) {
-        // (int8: dequantised by input scale * weight scale of the channel)
-#pragma unroll
-        for (int ii = 0; ii < MI; ++ii) {
-            if (ii != i) continue;
-#pragma unroll
-            for (int j = 0; j < NFRAG; ++j) {
-                floatx4 v = acc[ii][j];
-                if constexpr (I8) {
-                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
-                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
-                }
-                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
-            }
-        }
-    });
-}
-
 // TPS = filter taps per k-step: 1 normally; 2 for Cin <= 16 (CinK = 16), where one 32-wide step covers taps 2kt and 2kt+1
 // and the tap a lane fetches depends on which half of the row it fills.
 // I8: int8 activations / weights on v_mfma_i32_16x16x64_i8 (kINT8 engines).  A 64-byte LDS row then holds 64 int8 channels
@@ -243,12 +236,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 // Rows beyond M carry an out-of-range base from the start; the run-out steps past K read whatever follows (they are never multiplied).
 // Measured (round 3, same box): the 1x1 layers of YOLOv8n b32 3-10 % faster one at a time (34-layer sum 715 vs 724 us), res5's 1x1
 // 2048 -> 512 GEMM 497 vs 509 us; bench.py within run-to-run noise (35.0-35.2k vs 34.4-35.3k img/s).  Same bits.
-// M32 = v_mfma_f32_32x32x16_f16 instead of 16x16x32: a wave's tile is made of 32 x 32 fragments (MI / 2 by NFRAG / 2 of them), half
-// as many MFMA instructions for the same FLOPs and 32 cycles of shadow behind each; operands: lane l holds row (l & 31), k-chunk (l >> 5)
-// of a 16-wide k-slice; results: column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5) of its 16 registers.  Experiment
-// (TRTX_BIG_VARIANT=8), fp16, WN = 1 only.
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
-          bool ONE = false, bool M32 = false>
+          bool ONE = false>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     const int dbg = TRTX_DBG(dbg_flags);
@@ -269,8 +258,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     constexpr int LOADS_PER_TILE = A_LOADS + B_PASSES;
     constexpr int KSUB = BKT / 32;                 // MFMA k-slices per k-step
     constexpr int NST = RS ? 2 : NSTO ? NSTO : (BKT == 64 ? 2 : 3);  // pipeline stages (64-wide stages are double-buffered to keep occupancy)
-    static_assert(!M32 || (!I8 && WN == 1 && MI % 2 == 0 && NFRAG % 2 == 0), "32x32x16 variant: fp16, waves stacked along M, even fragment counts");
-    constexpr int EPI_BYTES = NW * (M32 ? 32 : 16) * (16 * NFW * 4 + 16);   // the epilogue's wave-private staging tiles (conv_epilogue)
+    constexpr int EPI_BYTES = NW * 16 * (16 * NFW * 4 + 16);   // the epilogue's wave-private staging tiles (conv_epilogue)
     constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // up to 144 KB of the CU's 160 KB (the large-GEMM tile)
 
@@ -475,38 +463,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     const int a_frag = wave_m * WR * ROW_B;
     const int b_frag = A_BYTES + wave_n * NFW * 16 * ROW_B;
 
-    typedef float floatx16 __attribute__((ext_vector_type(16)));
-    constexpr int MI2 = M32 ? MI / 2 : 1, NF2 = M32 ? NFW / 2 : 1, KS16 = BKT / 16;
-    floatx16 acc32[MI2][NF2];
-    int f_off32[KS16];
-    if constexpr (M32) {
-#pragma unroll
-        for (int i = 0; i < MI2; ++i)
-#pragma unroll
-            for (int j = 0; j < NF2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
-        const int r32 = lane & 31;
-#pragma unroll
-        for (int s2 = 0; s2 < KS16; ++s2) f_off32[s2] = r32 * ROW_B + (((2 * s2 + (lane >> 5)) ^ swz<BKT>(r32)) * 16);
-    }
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
-        if constexpr (M32) {
-#pragma unroll
-            for (int s2 = 0; s2 < KS16; ++s2) {
-                half8 af[MI2];
-#pragma unroll
-                for (int i = 0; i < MI2; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 32 * ROW_B + f_off32[s2]);
-#pragma unroll
-                for (int j = 0; j < NF2; ++j) {
-                    const half8 bf = *reinterpret_cast<const half8*>(sb + b_frag + j * 32 * ROW_B + f_off32[s2]);
-#pragma unroll
-                    for (int i = 0; i < MI2; ++i) acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af[i], acc32[i][j], 0, 0, 0);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int h = 0; h < KSUB; ++h) {
             if constexpr (I8) {
@@ -603,25 +561,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (dbg & 8) return;
-    if constexpr (M32) {
-        constexpr int PS = 16 * NFW * 4 + 16;
-        conv_epilogue_core<NFW, MI2, 32, LDS_BYTES, NW>(p, smem, wave, lane, n0, [&](int t) {
-            const int m = m0 + t;
-            return m < p.M ? m : -1;
-        }, wave_m * WR, [&](int i, char* mine) {
-#pragma unroll
-            for (int ii = 0; ii < MI2; ++ii) {
-                if (ii != i) continue;
-#pragma unroll
-                for (int j = 0; j < NF2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)   // registers 4g .. 4g+3 = channels 32j + 8g + 4 (lane >> 5) + [0, 4) of pixel lane & 31
-                        *reinterpret_cast<floatx4*>(mine + (lane & 31) * PS + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
-                            floatx4{acc32[ii][j][4 * g], acc32[ii][j][4 * g + 1], acc32[ii][j][4 * g + 2], acc32[ii][j][4 * g + 3]};
-            }
-        });
-        return;
-    }
     conv_epilogue<NFW, MI, I8, LDS_BYTES, NW>(p, acc, acci, smem, wave, lane, n0 + wave_n * NFW * 16, [&](int t) {
         const int m = m0 + t;
         return m < p.M ? m : -1;
@@ -1119,8 +1058,7 @@ int32_t launch_big(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipSt
     // 2 / 3 = 128 x 128 with the 2 x 2 wave grid (64 x 64 wave tiles, two workgroups per CU), reads next to / ahead of their MFMAs
     static const int variant = getenv("TRTX_BIG_VARIANT") ? atoi(getenv("TRTX_BIG_VARIANT")) : 0;
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    const int bm = ((variant >= 2 && variant <= 4) || variant == 8) ? 128 : 256;   // 8 = 32x32x16 MFMAs on the 128 x 128 tile (waves stacked along M)
-      // 5 / 6 / 7 = 256 x 128 with EIGHT waves (4 x 2 grid of 64 x 64 wave tiles; 3 stages, 3 + reads ahead, 2 stages);   // 4 = the plain 128 x 128 tile (four waves stacked along M) with the reads issued ahead
+    const int bm = (variant >= 2 && variant <= 4) ? 128 : 256;   // 5 / 6 / 7 = 256 x 128 with EIGHT waves (4 x 2 grid of 64 x 64 wave tiles; 3 stages, 3 + reads ahead, 2 stages);   // 4 = the plain 128 x 128 tile (four waves stacked along M) with the reads issued ahead
     const int tiles_m = (a.M + bm - 1) / bm, tiles_n = a.Cout_pad / 128;
     const int total = tiles_m * tiles_n;
     const int chunk = (total + 7) / 8;
@@ -1131,7 +1069,6 @@ int32_t launch_big(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipSt
         case 5: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
         case 6: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, true, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
         case 7: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 8: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 2, 1, 0, false, 4, false, false, false, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
         case 4: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 2, 1, 0, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
         default: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 8, 2, 3, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
     }
