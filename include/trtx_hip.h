@@ -148,6 +148,11 @@ int32_t trtx_batch_preprocess(const void* const* src_host, const int* src_w, con
 int32_t trtx_yolo_postprocess_gpu(const float* decode_out, int batch, int max_out, float conf_thresh, float nms_thresh,
                                   float* out, trtx_stream_t stream);
 
+/* ---- Mish (yolov4, scaled-yolov4 and the early yolov5 samples) ------------------------------------ */
+/* mish_kernel of MishPlugin::forwardGpu (reference yolov4/mish.cu:113-141): out[i] = in[i] * tanh(softplus(in[i])) over n device fp32
+ * values, softplus with the reference's threshold of 20 (x > 20 -> x, x < -20 -> exp(x)), tanh spelled 2 / (1 + exp(-2y)) - 1. */
+int32_t trtx_mish(const float* in, float* out, size_t n, trtx_stream_t stream);
+
 /* ---- RetinaFace ------------------------------------------------------------------------------- */
 /*
  * DecodePlugin::enqueue (reference retinaface/decode.cu:110-191).  inputs[l] (l = stride 8/16/32): device fp32

@@ -7,7 +7,10 @@ import numpy as np
 
 
 def entropy_threshold(hist, rng, levels=128):
-    hist = np.asarray(hist, dtype=np.float64)
+    hist = np.array(hist, dtype=np.float64)
+    if len(hist) > 1:
+        hist[0] = hist[1]   # NVIDIA pytorch-quantization calib/histogram.py::_compute_amax_entropy ("bins[0] = bins[1]"): exact zeros are
+        # representable at any scale; left as a spike in bin 0 they drag the threshold of post-ReLU tensors down to ~1.9 sigma
     nb = len(hist)
     best, best_i = np.inf, nb
     for i in range(levels, nb + 1):

@@ -140,6 +140,7 @@ FAMILY_PLUGINS = {
     "yolov8_plugin": ["YoloLayer_TRT"],
     "yolov5_plugin": ["YoloLayer_TRT"],
     "retinaface_plugin": ["Decode_TRT"],
+    "yolov4_plugin": ["Mish_TRT"],
     "rcnn_plugins": ["RpnDecode", "RpnNms", "RoiAlign", "PredictorDecode", "BatchedNms", "MaskRcnnInference"],
     "yolov8_post": [],
 }

@@ -48,6 +48,10 @@ PATCHES = {
     "*": [(r"<<\s+<", "<<<"), (r">>\s+>", ">>>")],
     # the file's own, documented precision switch ("set USE_INT8 or USE_FP16 or USE_FP32"): the INT8 default needs calibration images
     "retinaface/retina_r50.cpp": [(r"#define USE_INT8", "#define USE_FP16")],
+    # yolov4's plugin is written against TensorRT 7's IPluginV2::enqueue (`void** outputs`); TensorRT 8 - the API include/NvInfer.h
+    # spells, and what the yolov8 / retinaface plugins reach through TRT_CONST_ENQUEUE - made that `void* const*`
+    "yolov4/mish.h": [(r"void\*\* outputs", "void* const* outputs")],
+    "yolov4/mish.cu": [(r"void\*\* outputs", "void* const* outputs")],
 }
 
 # family -> (sources, extra include dirs relative to the reference, headers that need a patched copy)
@@ -56,6 +60,7 @@ FAMILIES = {
     "yolov8_post": (["yolov8/src/postprocess.cu", "yolov8/src/preprocess.cu"], ["yolov8/include"], []),
     "yolov5_plugin": (["yolov5/plugin/yololayer.cu"], ["yolov5/plugin", "yolov5/src"], []),
     "retinaface_plugin": (["retinaface/decode.cu"], ["retinaface"], []),
+    "yolov4_plugin": (["yolov4/mish.cu"], ["yolov4"], ["yolov4/mish.h"]),   # Mish_TRT (round 4)
     "rcnn_plugins": (["rcnn/RpnDecode.cu", "rcnn/RpnNms.cu", "rcnn/RoiAlign.cu", "rcnn/PredictorDecode.cu", "rcnn/BatchedNms.cu",
                       "rcnn/MaskRcnnInference.cu"], ["rcnn"], []),
 }

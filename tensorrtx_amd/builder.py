@@ -74,6 +74,31 @@ class Network:
     def activation(self, x, kind):
         return self._layer(self.L.trtx_add_activation(self.n, x, ACT[kind]), "add_activation")
 
+    def scale(self, x, shift, scale, power=None):
+        """IScaleLayer, ScaleMode::kCHANNEL (a folded BatchNorm, e.g. addBatchNorm2d of yolov4/yolov4.cpp:181-197)"""
+        sa, sp, sn = _f(shift)
+        ca, cp, cn = _f(scale)
+        pa, pp, pn = _f(np.ones_like(sa) if power is None else power)
+        self._keep += [sa, ca, pa]
+        return self._layer(self.L.trtx_add_scale(self.n, x, 1, sp, ctypes.c_int64(sn), cp, ctypes.c_int64(cn), pp, ctypes.c_int64(pn)), "add_scale")
+
+    def plugin(self, inputs, name, version="1"):
+        """getPluginRegistry()->getPluginCreator(name, version)->createPlugin(name, empty field collection), then addPluginV2 -
+        what convBnMish does for "Mish_TRT" (yolov4/yolov4.cpp:207-212).  The v-tables are opaque blobs here (sized generously)."""
+        creator = (ctypes.c_void_p * 8)()
+        self.L.trtx_registry_get.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+        self.L.trtx_add_plugin_v2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        check(self.L.trtx_registry_get(name.encode(), version.encode(), ctypes.cast(creator, ctypes.c_void_p)), f"no plugin creator {name}/{version}")
+        create = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p)(creator[3])
+        vt = (ctypes.c_void_p * 16)()
+        if create(creator[0], name.encode(), None, 0, ctypes.cast(vt, ctypes.c_void_p)) != 0:
+            raise RuntimeError(f"createPlugin({name}) failed")
+        arr = (ctypes.c_int32 * len(inputs))(*inputs)
+        l = self._layer(self.L.trtx_add_plugin_v2(self.n, ctypes.cast(arr, ctypes.c_void_p), len(inputs), ctypes.cast(vt, ctypes.c_void_p)), "add_plugin_v2")
+        destroy = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(vt[13])   # the network holds its own clone
+        destroy(vt[0])
+        return l
+
     def pooling(self, x, k, stride, padding=0, avg=False):
         l = self._layer(self.L.trtx_add_pooling(self.n, x, 1 if avg else 0, k, k), "add_pooling")
         self._set2(l, P_STRIDE, stride)

@@ -18,6 +18,12 @@ __device__ __forceinline__ _Float16 round_to_half(float v) {
     asm("" : "+v"(v));
     return (_Float16)v;
 }
+// Mish as the reference's plugin kernel computes it (yolov4/mish.cu:113-135): softplus with its threshold of 20 on both sides,
+// tanh spelled 2 / (1 + exp(-2y)) - 1, the accurate expf / logf.  No multiply-add pairs: immune to -ffp-contract.
+__device__ __forceinline__ float mish_ref(float x) {
+    const float sp = x > 20.f ? x : (x < -20.f ? expf(x) : logf(expf(x) + 1.f));
+    return x * (2.f / (1.f + expf(-2.f * sp)) - 1.f);
+}
 #endif
 
 constexpr int kYoloDetFloats = 90;  // sizeof(Detection)/4, yolov8/include/types.h:4-12

@@ -63,6 +63,7 @@ __device__ __attribute__((noinline)) float act_slow(float v, int act, float alph
         case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case ACT_LEAKY: return v > 0.f ? v : v * alpha;
         case ACT_TANH: return tanhf(v);
+        case ACT_MISH: return mish_ref(v);
         default: return v;
     }
 }
@@ -581,6 +582,13 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
 // kernel above - and 40 KB instead of 60 KB of LDS (64-wide column tile) lets four workgroups share a CU instead of two
 // (SQ counters of the 64 -> 64 3x3 80x80 layer, profiles/r02_sq_counters_64x64_3x3_80.txt: at two workgroups per CU this kernel
 // already matches the kernel above at four, with half the wave-cycles and a third of the wait cycles).
+// ROUND 4: NOT PART OF THE PRODUCT LIBRARY.  Engines that had chosen this kernel returned results differing in the last fp16 places between
+// execution contexts running side by side (tests/test_gpu_multi_context.py: 4 of 6 runs with it among the tactics, 0 of 12 without); a
+// second reading of the code (round 4: load counts against the vmcnt immediates, the rows fa_off[q] reads beyond a wave's own, the DMA- /
+// read-side swizzle keys, the run-out tiles, the padded-column masks) did not locate the hazard, and a kernel whose bits depend on what
+// else is resident does not ship behind an environment variable.  It is compiled only with -DTRTX_EXPERIMENTAL_R3 (tools / bisecting);
+// without it r3_possible() is false, no tactic names it and ConvArgs::t_r3 != 0 is refused by conv_igemm_supported().
+#ifdef TRTX_EXPERIMENTAL_R3
 template <int NFRAG, int BKT, int MI, int NSTAGES>
 __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int total_tiles,
                                                                 int xcd_chunk) {
@@ -763,6 +771,7 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
         return (wp >= 1 && wp <= p.W) ? (n * p.H + h) * p.W + wp - 1 : -1;
     });
 }
+#endif  // TRTX_EXPERIMENTAL_R3
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small-M variant (20x20 maps at batch 32 give M = 12800: 100 tiles of 128 rows for 256 CUs, and a 3x3 conv over 256
@@ -1112,11 +1121,15 @@ bool wsk_default(const ConvArgs& a) {
 }
 // the row-reuse kernel: fp16 3x3 stride 1 pad 1 with 16-byte output stores, 128-row tiles, 32..128-wide column tiles
 bool r3_possible(const ConvArgs& a) {
+#ifndef TRTX_EXPERIMENTAL_R3
+    return false;   // compiled out of the product (see the kernel's header)
+#endif
     return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
            a.dil_h == 1 && a.dil_w == 1 && a.CinK % 32 == 0 && a.CinK != 16 && !a.scalar_out && a.Ho == a.H && a.Wo == a.W &&
            (a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) && (a.bm == 0 || a.bm == 128) && (a.bk == 32 || a.CinK % 64 == 0) &&
            (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
 }
+#ifdef TRTX_EXPERIMENTAL_R3
 template <int BKT, int NSTAGES>
 int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
@@ -1130,12 +1143,13 @@ int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStr
     }
     return TRTX_OK;
 }
+#endif
 // 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 // ... 256-row tiles too, for 32/64/80-wide column tiles
 bool bm256_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16 && (a.bn == 32 || a.bn == 64 || a.bn == 80); }
 // ... and, 128 columns wide with 64-wide k-steps, the large-GEMM configuration (launch_big)
-bool big_possible(const ConvArgs& a) { return !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bn == 128 && a.bk == 64 && a.CinK % 64 == 0 && a.Kpad % 64 == 0 && a.Cout_pad % 128 == 0; }
+bool big_possible(const ConvArgs& a) { return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bn == 128 && a.bk == 64 && a.CinK % 64 == 0 && a.Kpad % 64 == 0 && a.Cout_pad % 128 == 0; }
 
 }  // namespace
 
@@ -1284,9 +1298,11 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
+#ifdef TRTX_EXPERIMENTAL_R3
         } else if (a.t_r3 != 0 && r3_possible(a)) {
             st = a.bk == 64 ? launch_r3<64, 2>(a, in_bytes, w_bytes, s)
                             : (a.t_r3 == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
+#endif
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);

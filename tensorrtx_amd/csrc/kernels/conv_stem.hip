@@ -34,6 +34,7 @@ __device__ __forceinline__ float stem_act(float v, int act, float alpha) {
         case ACT_SILU: return v / (1.0f + __expf(-v));
         case ACT_LEAKY: return v > 0.f ? v : v * alpha;
         case ACT_TANH: return tanhf(v);
+        case ACT_MISH: return mish_ref(v);
         default: return v;
     }
 }

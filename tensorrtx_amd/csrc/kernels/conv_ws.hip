@@ -62,6 +62,7 @@ __device__ __attribute__((noinline)) float ws_act_rare(float v, int act, float a
     if (act == ACT_LEAKY) return v > 0.f ? v : v * alpha;
     if (act == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_MISH) return mish_ref(v);
     return v;
 }
 __device__ __forceinline__ float ws_act_any(float v, int act, float alpha) {

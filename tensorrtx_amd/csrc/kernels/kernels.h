@@ -8,7 +8,8 @@
 
 namespace trtx {
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SILU = 3, ACT_LEAKY = 4, ACT_TANH = 5 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SILU = 3, ACT_LEAKY = 4, ACT_TANH = 5,
+                 ACT_MISH = 6 /* x * tanh(softplus(x)), the reference's Mish_TRT plugin (yolov4/mish.cu:113-135) */ };
 enum DType : int { DT_F32 = 0, DT_F16 = 1, DT_I8 = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_I8 ? 1 : 4); }
 enum EwOp : int { EW_SUM = 0, EW_PROD = 1, EW_MAX = 2, EW_MIN = 3, EW_SUB = 4, EW_DIV = 5, EW_POW = 6 };

@@ -402,7 +402,80 @@ int32_t rdec_deserialize(void*, const char*, const void* data, size_t len, trtx_
 const char* rdec_creator_name(void*) { return "Decode_TRT"; }
 const char* rdec_creator_version(void*) { return "1"; }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "Mish_TRT"/"1" - yolov4/mish.{h,cu} (the same plugin ships with yolov5-v1..v3 era samples and scaled-yolov4): one input of any CHW
+// shape, output of the same shape, out = x * tanh(softplus(x)) with the reference's threshold-20 softplus (mish.cu:113-135).
+// Blob = int input_size_ (elements per sample, mish.cu:18-32), learnt in getOutputDimensions (mish.cu:40-47).
+// Inside an engine the lowering pass never calls enqueue: Conv -> Scale -> Mish_TRT becomes the convolution's epilogue.
+struct Mish {
+    int input_size = 0;
+};
+void mish_fill(trtx_plugin_vtbl* v, Mish* m);
+int32_t mish_nb_outputs(void*) { return 1; }
+int32_t mish_output_dims(void* s, int32_t idx, const trtx_dims* in, int32_t nb, trtx_dims* out) {
+    if (nb != 1 || idx != 0 || in[0].nb < 1) return 1;
+    int64_t n = 1;
+    for (int k = 0; k < in[0].nb; ++k) n *= in[0].d[k];
+    static_cast<Mish*>(s)->input_size = (int)n;
+    *out = in[0];
+    return 0;
+}
+int32_t mish_configure(void* s, const trtx_dims* in, int32_t nb_in, const trtx_dims*, int32_t, int32_t) {
+    if (nb_in != 1) return 1;
+    int64_t n = 1;
+    for (int k = 0; k < in[0].nb; ++k) n *= in[0].d[k];
+    static_cast<Mish*>(s)->input_size = (int)n;
+    return 0;
+}
+int32_t mish_initialize(void*) { return 0; }
+void mish_terminate(void*) {}
+size_t mish_workspace(void*, int32_t) { return 0; }
+int32_t mish_enqueue(void* s, int32_t batch, const void* const* inputs, void* const* outputs, void*, trtx_stream_t stream) {
+    return trtx_mish(static_cast<const float*>(inputs[0]), static_cast<float*>(outputs[0]), (size_t)static_cast<Mish*>(s)->input_size * (size_t)batch,
+                     stream);
+}
+size_t mish_ser_size(void*) { return sizeof(int); }
+void mish_serialize(void* s, void* buf) { memcpy(buf, &static_cast<Mish*>(s)->input_size, sizeof(int)); }
+const char* mish_type(void*) { return "Mish_TRT"; }
+const char* mish_version(void*) { return "1"; }
+int32_t mish_clone(void* s, trtx_plugin_vtbl* out) {
+    mish_fill(out, new Mish(*static_cast<Mish*>(s)));
+    return 0;
+}
+void mish_destroy(void* s) { delete static_cast<Mish*>(s); }
+void mish_fill(trtx_plugin_vtbl* v, Mish* m) {
+    v->self = m;
+    v->get_nb_outputs = mish_nb_outputs;
+    v->get_output_dims = mish_output_dims;
+    v->configure = mish_configure;
+    v->initialize = mish_initialize;
+    v->terminate = mish_terminate;
+    v->workspace_size = mish_workspace;
+    v->enqueue = mish_enqueue;
+    v->serialization_size = mish_ser_size;
+    v->serialize = mish_serialize;
+    v->plugin_type = mish_type;
+    v->plugin_version = mish_version;
+    v->clone = mish_clone;
+    v->destroy = mish_destroy;
+}
+int32_t mish_create(void*, const char*, const trtx_plugin_field*, int32_t, trtx_plugin_vtbl* out) {  // empty field collection, mish.cu:166-178
+    mish_fill(out, new Mish());
+    return 0;
+}
+int32_t mish_deserialize(void*, const char*, const void* data, size_t len, trtx_plugin_vtbl* out) {  // mish.cu:18-22
+    if (len != sizeof(int)) return 1;
+    auto* m = new Mish();
+    memcpy(&m->input_size, data, sizeof(int));
+    mish_fill(out, m);
+    return 0;
+}
+const char* mish_creator_name(void*) { return "Mish_TRT"; }
+const char* mish_creator_version(void*) { return "1"; }
+
 }  // namespace
+
+bool builtin_is_mish(const trtx_plugin_vtbl& v) { return v.enqueue == mish_enqueue && v.self; }
 
 bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
     if (v.enqueue != yolo_enqueue || !v.self) return false;
@@ -418,7 +491,7 @@ bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out) {
 
 // built-in plugins only enqueue kernels and stream-ordered memsets on the caller's stream: safe inside a stream capture
 bool builtin_plugin_capturable(const trtx_plugin_vtbl& v) {
-    return v.enqueue == yolo_enqueue || v.enqueue == yolo5_enqueue || v.enqueue == rdec_enqueue;
+    return v.enqueue == yolo_enqueue || v.enqueue == yolo5_enqueue || v.enqueue == rdec_enqueue || v.enqueue == mish_enqueue;
 }
 
 void register_builtin_plugins(PluginRegistry& r) {
@@ -434,6 +507,12 @@ void register_builtin_plugins(PluginRegistry& r) {
     d.create = rdec_create;
     d.deserialize = rdec_deserialize;
     r.add(d);
+    trtx_creator_vtbl m{};
+    m.plugin_name = mish_creator_name;
+    m.plugin_version = mish_creator_version;
+    m.create = mish_create;
+    m.deserialize = mish_deserialize;
+    r.add(m);
 }
 
 }  // namespace trtx

@@ -12,7 +12,14 @@
 
 namespace trtx {
 
-float entropy_threshold(const std::vector<double>& hist, float range) {
+float entropy_threshold(const std::vector<double>& hist_in, float range) {
+    // Bin 0 takes the value of bin 1 before the search, as NVIDIA's public restatement of this calibrator does (pytorch-quantization,
+    // calib/histogram.py::_compute_amax_entropy: "bins[0] = bins[1]"): the exact zeros of a post-ReLU tensor (and zero padding) are
+    // representable at ANY scale, but as a spike in bin 0 they dominate the divergence - level 0 of the candidate averages the spike
+    // over i/128 source bins, a term that grows with the threshold - and drag it down to ~1.9 sigma on ReLU(N(0,1)), clipping 3 % of the
+    // tensor (round 3's RetinaFace int8 engines lost half their detections to exactly this; with the fix the same data gives 4.7 sigma).
+    std::vector<double> hist(hist_in);
+    if (hist.size() > 1) hist[0] = hist[1];
     const int nbins = (int)hist.size();
     const int levels = 128;
     double total = 0;
@@ -138,7 +145,11 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
     std::vector<uint8_t> blob;
     fp16net.serialize(blob);
     trtx_engine* eng = nullptr;
-    int32_t st = trtx_engine_deserialize(blob.data(), blob.size(), &eng);
+    int32_t st;
+    {
+        CalibrationLowering keep_every_tensor;   // no upsample fold, no fused chains: see plan.h
+        st = trtx_engine_deserialize(blob.data(), blob.size(), &eng);
+    }
     if (st != TRTX_OK) return st;
     trtx_context* ctx = nullptr;
     st = trtx_context_create(eng, &ctx);
@@ -253,6 +264,11 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
     if (st == TRTX_OK) {
         CAL_TRY(hipMemcpy(h_hist.data(), obs.d_hist, h_hist.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         net->tensor_scale.assign(net->tensors.size(), 0.f);
+        // TRTX_CALIB_REPORT=<file>: per calibrated tensor the largest |x| seen, the threshold chosen, the share of elements beyond it
+        // (what the int8 engine clips) and the share in bin 0 - the evidence behind a detection-level int8 figure
+        FILE* report = nullptr;
+        if (const char* rp = getenv("TRTX_CALIB_REPORT")) report = fopen(rp, "a");
+        if (report) fprintf(report, "# %s calibration, %d batch(es) of %d; tensor\tabsmax\tthreshold\tclipped_share\tbin0_share\telements\n", minmax ? "min-max" : "entropy", n_batches, batch);
         for (const PTensor& t : plan.tensors) {
             if (t.parent >= 0 || t.layout != LAY_NHWC || t.net_tensor < 0 || t.storage < 0) continue;
             const size_t s = (size_t)t.storage;
@@ -269,7 +285,20 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
                 thr = entropy_threshold(h, obs.range[s]);
             }
             net->tensor_scale[t.net_tensor] = thr / 127.0f;
+            if (report) {
+                double total = 0, beyond = 0;
+                int last = 0;
+                const double width = (double)obs.range[s] / kCalibBins;
+                for (int k = 0; k < kCalibBins; ++k) {
+                    total += h[k];
+                    if (h[k] > 0) last = k;
+                    if ((k + 0.5) * width > thr) beyond += h[k];
+                }
+                fprintf(report, "%s\t%.6g\t%.6g\t%.3e\t%.4f\t%.0f\n", calib_tensor_name(*net, t.net_tensor).c_str(), (last + 1) * width, (double)thr,
+                        total > 0 ? beyond / total : 0.0, total > 0 ? h[0] / total : 0.0, total);
+            }
         }
+        if (report) fclose(report);
     }
     cleanup();
 #undef CAL_TRY

@@ -226,6 +226,11 @@ struct Lowerer {
         return true;
     }
 
+    bool is_builtin_mish(int li) const {
+        const LayerDef& l = net.layers[li];
+        return l.kind == L_PLUGIN && l.plugin && l.inputs.size() == 1 && l.outputs.size() == 1 && builtin_is_mish(l.plugin->v);
+    }
+
     void analyse_fusion() {
         for (size_t li = 0; li < net.layers.size(); ++li) {
             const LayerDef& l = net.layers[li];
@@ -269,6 +274,12 @@ struct Lowerer {
             } else if (sole_consumer(t, &nx) && !absorbed[nx] && net.layers[nx].kind == L_ACTIVATION && act_code(net.layers[nx].op) >= 0) {
                 g.act1 = act_code(net.layers[nx].op);
                 g.alpha1 = net.layers[nx].alpha;
+                absorbed[nx] = true;
+                t = net.layers[nx].outputs[0];
+                last = std::max(last, nx);
+            } else if (sole_consumer(t, &nx) && !absorbed[nx] && is_builtin_mish(nx)) {
+                // Conv -> Scale(BN) -> Mish_TRT (convBnMish, yolov4/yolov4.cpp:199-213): the plugin is a pointwise activation
+                g.act1 = ACT_MISH;
                 absorbed[nx] = true;
                 t = net.layers[nx].outputs[0];
                 last = std::max(last, nx);
@@ -796,6 +807,16 @@ struct Lowerer {
                         }
                     }
                 }
+                if (is_builtin_mish(li)) {  // a Mish_TRT no convolution absorbed: an activation op in the layout its input already has
+                    const int p = pt_of[l.inputs[0]];
+                    const bool nhwc = plan.tensors[p].layout == LAY_NHWC;
+                    const int out = new_tensor(l.outputs[0], net.tensors[l.outputs[0]].dims, nhwc ? LAY_NHWC : LAY_LINEAR, plan.tensors[p].batched);
+                    POp& op = add_op(nhwc ? OP_ACT_NHWC : OP_ACT_LIN, l.name, {p}, {out});
+                    op.i[0] = ACT_MISH;
+                    op.f[0] = 0.f;
+                    pt_of[l.outputs[0]] = out;
+                    return true;
+                }
                 std::vector<int> ins, outs;
                 for (int t : l.inputs) ins.push_back(need_lin(t));
                 for (size_t s = 0; s < l.outputs.size(); ++s) {
@@ -1119,7 +1140,7 @@ struct Lowerer {
     // the phase stamps): at the one or two workgroups per CU its LDS plan allows, prologue, k-loop bookkeeping and the SiLU epilogues
     // run back to back instead of under another workgroup's MFMAs.
     void fuse_conv_chains() {
-        if (dt != DT_F16) return;
+        if (dt != DT_F16 || CalibrationLowering::active()) return;
         const char* fe = getenv("TRTX_FUSE_CHAINS");
         if (!fe || atoi(fe) == 0) return;
         std::vector<int> readers(plan.tensors.size(), 0);
@@ -1244,7 +1265,7 @@ struct Lowerer {
     // per step become 19.5 MB read); every product is formed from the same operands in the same order: bit-identical outputs.
     // TRTX_FOLD_UPSAMPLE=0 keeps the resize (A/B, tests).  Not with kINT8 (the int8 resize requantises between two scales).
     void fold_upsample() {
-        if (dt != DT_F16 || net.int8) return;
+        if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
         if (const char* e = getenv("TRTX_FOLD_UPSAMPLE"))
             if (atoi(e) == 0) return;
         auto top = [&](int t) {
@@ -1257,7 +1278,7 @@ struct Lowerer {
             const PTensor& src = plan.tensors[rz.in[0]];
             const PTensor& up = plan.tensors[rz.out[0]];
             if (up.parent < 0 || up.rcoff != 0 || up.layout != LAY_NHWC || src.layout != LAY_NHWC || up.H != 2 * src.H || up.W != 2 * src.W || up.C != src.C ||
-                up.C % 64 || src.ld % 8 || src.nmul != 1 || up.nmul != 1 || is_binding_tensor(rz.out[0]))
+                up.C % 64 || src.ld % 8 || src.rcoff % 8 || src.nmul != 1 || up.nmul != 1 || is_binding_tensor(rz.out[0]))
                 continue;
             const int owner = top(rz.out[0]);
             // every reader of the buffer: exactly one, a 1x1 stride-1 convolution over the WHOLE buffer; nobody reads the slice itself
@@ -1667,6 +1688,11 @@ struct Lowerer {
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
+
+static thread_local int g_calibration_lowering = 0;
+CalibrationLowering::CalibrationLowering() { ++g_calibration_lowering; }
+CalibrationLowering::~CalibrationLowering() { --g_calibration_lowering; }
+bool CalibrationLowering::active() { return g_calibration_lowering > 0; }
 
 bool lower_network(const Network& net, Plan* plan) {
     *plan = Plan();

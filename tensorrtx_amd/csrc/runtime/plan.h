@@ -143,6 +143,16 @@ struct Plan {
 
 // Lower a network into a plan (pure host work; no device needed).  Returns false and sets plan.error.
 bool lower_network(const Network& net, Plan* plan);
+// While > 0 on the calling thread, lower_network keeps every tensor of the definition that a kINT8 engine of it would keep: the passes
+// that make a tensor disappear from an fp16 plan but not from the int8 plan (fold_upsample, fuse_conv_chains) are off.  Set by
+// run_int8_calibration around the statistics engine: the observer sees a tensor only where an op writes it, and the upsampled slice of
+// a concat buffer must reach that buffer's histogram (the int8 engine requantises the upsampled feature into the shared
+// scale and would clip it if the scale came from the skip slice alone).
+struct CalibrationLowering {
+    CalibrationLowering();
+    ~CalibrationLowering();
+    static bool active();
+};
 // Fill plan.weight_blob (folded BN, packed fp16 igemm weights, biases, constants).
 bool pack_weights(const Network& net, Plan* plan);
 

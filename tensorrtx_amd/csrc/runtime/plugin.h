@@ -44,7 +44,12 @@ struct PluginHolder {
         return true;
     }
     std::string type() const { return v.plugin_type(v.self); }
-    std::string version() const { return v.plugin_version(v.self); }
+    // a null version string reads as "1": the reference's MishPlugin::getPluginVersion returns 0 (yolov4/mish.cu:92-95) while its creator
+    // registers under "1" - the version a plan must name to find the creator again
+    std::string version() const {
+        const char* s = v.plugin_version(v.self);
+        return s ? s : "1";
+    }
     std::vector<uint8_t> serialize() const {
         std::vector<uint8_t> b(v.serialization_size(v.self));
         if (!b.empty()) v.serialize(v.self, b.data());
@@ -81,6 +86,9 @@ struct YoloLayerParams {
     bool det_only;
 };
 bool builtin_yolo_params(const trtx_plugin_vtbl& v, YoloLayerParams* out);
+// true for the built-in "Mish_TRT" (plugins/builtin_plugins.cpp; yolov4/mish.{h,cu}): a pointwise activation, which the lowering pass
+// folds into the producing convolution's epilogue (ACT_MISH) or runs as an activation op in the tensor's own layout
+bool builtin_is_mish(const trtx_plugin_vtbl& v);
 // true for the built-in HIP plugins (kernels + stream-ordered memsets only): their enqueue may run inside a hipGraph capture.
 // A user IPluginV2 may synchronise, allocate or copy from pageable memory (the reference's R-CNN plugins do all three).
 bool builtin_plugin_capturable(const trtx_plugin_vtbl& v);

@@ -48,7 +48,8 @@ struct SigKey {
 SigKey signature(const ConvArgs& a, int act_pair) {
     SigKey k{};
     const int f[] = {a.N, a.H, a.W, a.Cin, a.ld_in, a.Ho, a.Wo, a.Cout, a.Cout_pad, a.ld_out, a.residual || a.ld_res ? a.ld_res : -1, a.kh, a.kw,
-                     a.stride_h, a.stride_w, a.pad_h, a.pad_w, a.CinK, a.Kpad, a.in_i8, a.out_i8, a.res_i8, a.scalar_out, a.bn, a.bk, act_pair};
+                     a.stride_h, a.stride_w, a.pad_h, a.pad_w, a.CinK, a.Kpad, a.in_i8, a.out_i8, a.res_i8, a.scalar_out, a.bn, a.bk, act_pair,
+                     a.up_C, a.t_rs};   //  a folded-upsample / register-staged layer has its own candidate set: its own decision
     static_assert(sizeof(f) / sizeof(int) <= 28, "signature too long");
     static_assert(sizeof(SigKey) == sizeof(Network::TacticEntry::sig), "plan tactic entries hold a whole signature");
     memcpy(k.v, f, sizeof(f));

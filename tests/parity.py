@@ -13,8 +13,15 @@ kind "min": value must stay above the bound (fractions, IoU: 1.0 is perfect); wo
 fp16 numbers move a little from run to run (tactics are timed when a plan is BUILT, and kernels that split or reorder K round differently;
 one plan is reproducible - see tests/test_gpu_tactics.py); the record therefore holds several runs.  The north_star's 1e-4 logit / 1e-3
 IoU tolerance is what the fp32 builds are asserted at; the fp16 bounds are the measured cost of fp16 storage through 60+ layers.
+
+Round 4 (VERDICT r3 Weak 2): the fitted table is a DRIFT ALARM, not a tolerance - it would pass at whatever accuracy the product
+had when the record was taken, and re-running the generator absorbs a regression.  The tolerance is `CEILINGS` below: hand-written,
+derived from the north_star and from the arithmetic of the precision (never from a product measurement), never touched by
+tools/parity_bounds_from_record.py, asserted FIRST by check().  tests/test_parity_bounds.py requires a ceiling for every bounded metric
+and that the generator's block is the only part of this file the tool may rewrite.
 """
 import json
+import math
 import os
 
 # (test, case) -> {metric: (kind[, slack])}: WHICH metrics are bounded and how; the numbers live in the table below
@@ -77,6 +84,55 @@ VALUES = {
 }
 # END GENERATED VALUES
 
+# ---- spec-derived ceilings (hard asserts; by hand; see the module docstring) ------------------------------------------------------
+EPS16 = 2.0 ** -11   # relative error of ONE round-to-nearest into fp16 (half an ulp)
+
+
+def fp16_walk(sites, magnitude, safety=1.5):
+    """|error| of a value of size `magnitude` that passed `sites` independent fp16 roundings (weights and activations of kFP16: fp16
+    storage, fp32 accumulate), accumulated as a random walk, times a safety factor: EPS16 * sqrt(sites) * magnitude * safety.
+    YOLOv8n: 133 rounding sites (63 weight tensors + 70 activations), logits up to 16 -> 0.135; tools/fp16_budget.py (a CPU emulation of
+    exactly that arithmetic, independent of the GPU product) measures 0.064 and shows it spread over all sites (profiles/r04_fp16_budget.txt)."""
+    return safety * EPS16 * math.sqrt(sites) * magnitude
+
+
+NS_LOGIT, NS_IOU = 1e-4, 1e-3   # the north_star: 1e-4 on logits of O(10) (= 1e-5 of the largest logit), 1e-3 box IoU; met by fp32 builds
+FP16_IOU, FP16_MATCH = 1e-2, 5e-3   # the fp16 allowance stated in DESIGN 2: 10x the IoU figure, 0.5 % of oracle candidates may flip at a threshold
+CEILINGS = {
+    ("lenet_fp32", None): {"max_abs_err": NS_LOGIT / 10},                       # probabilities <= 1
+    ("resnet50_64", "fp32"): {"max_abs_err": NS_LOGIT / 10 * 720},               # logits up to 720
+    ("resnet50_64", "fp16"): {"max_abs_err": fp16_walk(107, 720)},               # 53 convs + fc: 54 weight + 53 activation sites -> 5.5
+    ("resnet50_224_b32", None): {"max_abs_err": fp16_walk(107, 1787)},           # fp16, logits up to 1787 -> 13.5
+    ("yolov8n_fp32_128", None): {"head_max_abs_err": NS_LOGIT},
+    ("yolov8n_fp16_640", None): {"cls_logit_max_abs_err": fp16_walk(133, 16), "box_ltrb_max_abs_err": fp16_walk(133, 16) / 4,   # DFL: expectation over
+                                 # softmax(16 logits) in cells, d(expectation)/d(logit) <= 1/4 of the bin span per unit logit for a unimodal side
+                                 "matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - FP16_IOU, "max_conf_err": fp16_walk(133, 16) / 4},   # sigmoid' <= 1/4
+    ("yolov8n_fp16_640_fused", None): {"matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - FP16_IOU, "max_conf_err": fp16_walk(133, 16) / 4},
+    ("yolov8n_fp16_640_b32", None): {"matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - FP16_IOU, "max_conf_err": fp16_walk(133, 16) / 4},
+    # RetinaFace: anchors of 16 px at stride 8 - one pixel of box error is IoU 0.88 on the smallest face; boxes = prior + 0.1 * delta * size
+    ("retinaface_r50_fp16", "256x320"): {"matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - 2 * FP16_IOU, "max_box_err": 2.0, "max_conf_err": fp16_walk(140, 16) / 4},
+    ("retinaface_r50_fp16", "1280x1280"): {"matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - 2 * FP16_IOU, "max_box_err": 2.0, "max_conf_err": fp16_walk(140, 16) / 4},
+    ("rcnn_fp32", None): {"feat_err": NS_LOGIT, "score_err": NS_LOGIT, "proposals_matched": 0.98, "detections_matched": 0.95},   # one top-k tie per 50 / 20
+    # R-CNN fp16: judged stage by stage; one flipped top-k / NMS decision upstream legitimately changes what follows
+    ("rcnn_fp16", "320x416"): {"feat_rel_err": EPS16 * math.sqrt(90) * 1.5, "proposals_matched": 0.98, "detections_matched": 0.93, "top_score_err": fp16_walk(110, 16) / 4},
+    ("rcnn_fp16", "800x1067"): {"feat_rel_err": EPS16 * math.sqrt(90) * 1.5, "proposals_matched": 0.98, "detections_matched": 0.93, "top_score_err": fp16_walk(110, 16) / 4},
+    ("rcnn_fp16", "800x1333"): {"feat_rel_err": EPS16 * math.sqrt(90) * 1.5, "proposals_matched": 0.98, "detections_matched": 0.93, "top_score_err": fp16_walk(110, 16) / 4},
+    ("mask_rcnn_fp32", None): {"mask_err": NS_LOGIT / 10},                        # sigmoid outputs <= 1
+    ("mask_rcnn_fp16", None): {"mask_err": fp16_walk(110, 16) / 4},
+    # INT8.  One int8 rounding is 1/254 of the tensor's range (vs 2^-11 of the VALUE for fp16), so no logit-level figure is stated for it;
+    # the tolerance is at DETECTION level: with either calibrator at least 90 % of the fp32 oracle's candidates must be found again at
+    # IoU > 0.5 (VERDICT r3 item 9), the head must stay within 10 % mean relative error, and its worst logit error is bounded by the range
+    # of the logits themselves (an error as large as the logit range would mean a dead head).
+    ("yolov8n_int8_320", None): {"head_max_abs_err_fp16": fp16_walk(133, 16), "head_mean_rel_err_int8": 0.10, "head_max_abs_err_int8": 16.0},
+    ("yolov8n_int8_640", "vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
+    ("yolov8n_int8_640", "vs_fp16_engine"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
+    ("yolov8n_int8_640", "minmax_vs_fp32_oracle"): {"matched_iou50": 0.95, "matched_iou90": 0.80, "mean_iou": 0.90, "mean_conf_err": 0.10},
+    ("retinaface_r50_int8", "vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
+    ("retinaface_r50_int8", "vs_fp16_engine"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
+    ("retinaface_r50_int8", "minmax_vs_fp32_oracle"): {"matched_iou50": 0.95, "mean_iou": 0.85, "mean_conf_err": 0.10},
+}
+SPEC[("yolov8n_int8_320", None)]["head_max_abs_err_int8"] = ("max",)   # ADVICE r3: was reported and unbounded
+
 BOUNDS = {k: {m: (spec[0], VALUES[k][m]) + tuple(spec[1:]) for m, spec in ms.items() if k in VALUES and m in VALUES[k]} for k, ms in SPEC.items()}
 
 RECORD = os.path.join("gpurun_out", "parity_metrics.jsonl")
@@ -95,8 +151,15 @@ def holds(kind, bound, value):
 def check(test, case=None, **values):
     """Record `values`, then assert every one that has a bound (all of them reported on failure)."""
     record(test, case, **values)
-    bounds = BOUNDS.get((test, case), {})
-    missing = [m for m in bounds if m not in values]
+    spec = SPEC.get((test, case), {})
+    missing = [m for m in spec if m not in values]
     assert not missing, f"{test}/{case}: bounded metrics not reported: {missing}"
+    # 1. the tolerance: spec-derived ceilings
+    ceil = CEILINGS.get((test, case), {})
+    over = {m: (values[m], (spec[m][0], ceil[m])) for m in spec if m in ceil and not holds(spec[m][0], ceil[m], values[m])}
+    assert not over, f"{test}/{case}: OUTSIDE THE TOLERANCE (value, (kind, spec-derived ceiling)): {over}"
+    # 2. the drift alarm: bounds fitted to the committed record
+    bounds = BOUNDS.get((test, case), {})
     bad = {m: (values[m], bounds[m][:2]) for m in bounds if not holds(bounds[m][0], bounds[m][1], values[m])}
-    assert not bad, f"{test}/{case}: outside the parity bounds (value, (kind, bound)): {bad}"
+    assert not bad, (f"{test}/{case}: inside the tolerance but outside the bounds fitted to the record (value, (kind, bound)): {bad} - a numeric "
+                     "change; if intended, add the new runs to the record and regenerate (tools/parity_bounds_from_record.py)")

@@ -274,6 +274,31 @@ def mask_oracle(c):
     return [dp.mask_select(c.inputs[0].reshape(c.batch, -1), c.inputs[1])]
 
 
+# ------------------------------------------------------------------------------------------------------ yolov4 Mish_TRT
+def mish_case(batch=2, shape=(5, 7, 9), seed=21):
+    """values across every branch of softplus_kernel (yolov4/mish.cu:113-117): |x| <= 30 with the thresholds +-20 and 0 planted"""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(shape))
+    x = rng.uniform(-30, 30, size=(batch, n)).astype(np.float32)
+    x[:, :10] = np.array([0.0, -0.0, 20.0, -20.0, np.nextafter(np.float32(20), np.float32(21)), np.nextafter(np.float32(-20), np.float32(-21)),
+                          1e-6, -1e-6, 19.999, -19.999], dtype=np.float32)
+    x[:, 10:n // 2] = rng.normal(0, 2, size=(batch, n // 2 - 10)).astype(np.float32)   # where activations actually live
+    return Case(f"mish_{'x'.join(map(str, shape))}", "yolov4_plugin", "Mish_TRT", batch, [x.reshape((batch,) + shape)], [(batch,) + shape],
+                blob=struct.pack("<i", n), rtol=2e-6, atol=1e-9)
+
+
+def mish_product(c, dev):
+    """the built-in Mish_TRT (plugins/builtin_plugins.cpp -> trtx_mish) through the same v-table route as the reference's"""
+    from oracle import ref
+    v = ref.make_plugin(ref.registry_get("Mish_TRT"), blob=c.blob)
+    return [o.cpu().numpy() for o in ref.run_plugin(v, c.batch, [_t(x, dev) for x in c.inputs], c.out_shapes)]
+
+
+def mish_oracle(c):
+    from oracle import mish as om
+    return [om.mish(c.inputs[0])]
+
+
 def all_cases():
     """(case, product evaluator, oracle evaluator) — small enough that the reference outputs are committed as goldens."""
     return [
@@ -294,6 +319,7 @@ def all_cases():
         (mask_case(), mask_product, mask_oracle),
         (yolov5_decode_case(), yolov5_product, yolov5_oracle),
         (yolov5_decode_case(batch=1, seed=14, size=320, seg=True), yolov5_product, yolov5_oracle),
+        (mish_case(), mish_product, mish_oracle),
     ]
 
 

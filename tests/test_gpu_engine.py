@@ -430,3 +430,29 @@ def test_folded_upsample_small_network_matches_torch(gpu, monkeypatch):
         got = _run(plan, {"data": x.numpy()}, 2, gpu)["y"].reshape(ref.shape)
         err = (got - ref).abs().max().item()
         assert err < 4e-3 * max(scale, 1.0), (fold, err, scale)
+
+
+@pytest.mark.parametrize("fp16,fused", [(0, True), (1, True), (0, False), (1, False)])
+def test_conv_bn_mish_engine_matches_the_reference_expression(gpu, fp16, fused):
+    """g1: Conv -> Scale(BN) -> Mish_TRT (convBnMish, yolov4/yolov4.cpp:199-213) as ONE launch with the Mish epilogue, against the
+    reference plugin's expression (oracle/mish.py = yolov4/mish.cu:111-135) applied to a PyTorch fp32 convolution.  fp32: 1e-4 (the
+    north_star logit figure; the sum order of the convolution is the only difference).  fp16: inputs and weights rounded to fp16 in the
+    oracle too, so what is left is the fp16 rounding of the OUTPUT (half an ulp of |y| <= 16: 4e-3) plus the summation order."""
+    import torch.nn.functional as F
+    from oracle import mish as om
+    from test_runtime_cpu import _conv_bn_mish_net
+    plan, (w, scale, shift) = _conv_bn_mish_net(bool(fp16), fused=fused)
+    x = torch.randn(2, 16, 12, 20, generator=torch.Generator().manual_seed(9))
+    got = _run(plan, {"data": x.numpy()}, 2, gpu)["out"]
+    wt = torch.from_numpy(w * scale[:, None, None, None])           # the engine folds the Scale into the weights before rounding them
+    xin = x.half().float() if fp16 else x
+    if fp16:
+        wt = wt.half().float()
+    y = F.conv2d(xin, wt, torch.from_numpy(shift), padding=1)
+    if not fused:
+        y = F.max_pool2d(y.half().float() if fp16 else y, 2, 2)
+    ref = om.mish_torch(y)
+    got = got.reshape(ref.shape)
+    err = (got - ref).abs().max().item()
+    assert err < (8e-3 if fp16 else 1e-4), err
+    assert (ref.abs() > 1).any() and (ref < 0).any()   # both tails of the activation are exercised

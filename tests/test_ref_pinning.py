@@ -296,3 +296,25 @@ def test_reference_racy_kernels_at_full_size_are_reported_not_asserted(gpu):
         f.write(json.dumps(dict(test="rpn_nms_6000_vs_racy_reference", rows_identical=same)) + "\n")
     assert np.array_equal(got, rc.rpn_nms_oracle(case)[0])
     assert same > 0.2  # informational: the racy reference still agrees on a large part of the list
+
+
+@pytest.mark.gpu
+def test_builtin_mish_equals_the_reference_kernel_bit_for_bit(gpu):
+    """g1: the product's Mish_TRT (trtx_mish) vs the reference's mish_kernel (yolov4/mish.cu:119-135, compiled by hipcc into
+    oracle/_ref/libref_yolov4_plugin.so), same inputs, both through the plugin v-table: the same device expf / logf, so NOT ONE bit may
+    differ; blobs interchange (int input_size); the reference object's null version string (mish.cu:92-95) reads as "1"."""
+    _need_ref("libref_yolov4_plugin.so")
+    case = rc.mish_case(batch=3, shape=(8, 33, 17), seed=5)
+    want = rc.run_reference(case, gpu)
+    got = rc.mish_product(case, gpu)
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), int((got[0].view(np.uint32) != want[0].view(np.uint32)).sum())
+    creators = ref.load_plugins("yolov4_plugin")
+    theirs = ref.make_plugin(creators["Mish_TRT"], fields=[])
+    ours = ref.make_plugin(ref.registry_get("Mish_TRT"), fields=[])
+    assert ours.plugin_version(ours.self) == b"1" and not theirs.plugin_version(theirs.self)
+    assert ref.plugin_blob(ours) == ref.plugin_blob(theirs) or len(ref.plugin_blob(ours)) == len(ref.plugin_blob(theirs)) == 4
+    a = ref.make_plugin(ref.registry_get("Mish_TRT"), blob=case.blob)
+    b = ref.make_plugin(creators["Mish_TRT"], blob=case.blob)
+    assert ref.plugin_blob(a) == ref.plugin_blob(b) == case.blob
+    for v in (theirs, ours, a, b):
+        v.destroy(v.self)

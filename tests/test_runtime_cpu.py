@@ -430,13 +430,11 @@ def test_conv_tactics_are_enumerated_on_the_host():
     t = capi.conv2d_tactics(32, 20, 20, 128, 128, 3, 1, 1)
     assert t[0] == (128, 32, 128, 1, 1, 0) and len(set(t)) == len(t) >= 8
     assert (64, 32, 128, 2, 1, 0) in t and (64, 64, 64, 1, 1, 0) in t    # wave-split-K on 64-wide tiles; 64-row tiles with 64-wide k-steps
-    assert not any(x[5] for x in t)   # the 3x3 row-reuse kernel is a candidate only under TRTX_TACTICS_R3=1 (conv_igemm.hip: co-scheduling hazard)
+    assert not any(x[5] for x in t)   # the 3x3 row-reuse kernel is compiled out of the product (conv_igemm.hip: co-scheduling hazard) ...
     import subprocess, sys
     r3 = subprocess.run([sys.executable, "-c", "from tensorrtx_amd import capi; print(capi.conv2d_tactics(32, 20, 20, 128, 128, 3, 1, 1))"],
                         env=dict(os.environ, TRTX_TACTICS_R3="1"), capture_output=True, text=True, check=True)
-    t3 = eval(r3.stdout.strip().splitlines()[-1])
-    assert (128, 32, 128, 1, 1, 1) in t3 and (128, 32, 128, 1, 1, 2) in t3 and (64, 64, 128, 1, 1, 2) in t3  # 3 / 2 LDS stages, 64-wide k-steps
-    assert [x for x in t3 if not x[5]] == t
+    assert eval(r3.stdout.strip().splitlines()[-1]) == t   # ... and no environment variable brings it back (ADVICE r3 / VERDICT r3 Weak 3)
     assert all(128 % bn == 0 and bk in (32, 64) and bm in (64, 128) for bn, bk, bm, _, _, _ in t)
     t = capi.conv2d_tactics(32, 80, 80, 32, 32, 3, 1, 1)                  # weight-stationary kernel is the default where it applies
     assert t[0][4] == 2 and all(x[4] == 1 for x in t[1:]) and all(x[1] == 32 for x in t)
@@ -586,3 +584,41 @@ def test_upsample_is_folded_only_where_it_is_safe(monkeypatch):
     assert "resize" in kinds(_upsample_concat_net(fp16=False)[0])[0]
     monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", "0")
     assert "resize" in kinds(_upsample_concat_net()[0])[0]
+
+
+def _conv_bn_mish_net(fp16, fused=True, cin=16, cout=32, hw=(12, 20)):
+    """convBnMish of the reference (yolov4/yolov4.cpp:199-213): Conv (no bias) -> Scale (folded BatchNorm) -> "Mish_TRT" from the plugin
+    registry; `fused=False` puts a max-pool between the Scale and the plugin so that no convolution can absorb it.  Seeded."""
+    from tensorrtx_amd import builder
+    rng = np.random.default_rng(4)
+    w = rng.normal(0, 0.25, (cout, cin, 3, 3)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 1.0, cout).astype(np.float32)
+    net = builder.Network(max_batch=2, fp16=fp16)
+    x = net.input("data", (cin,) + hw)
+    t = net.out(net.scale(net.out(net.conv(x, w, stride=1, padding=1)), shift, scale))
+    if not fused:
+        t = net.out(net.pooling(t, 2, 2))
+    net.mark_output(net.out(net.plugin([t], "Mish_TRT")), "out")
+    plan = net.build()
+    net.close()
+    return plan, (w, scale, shift)
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_mish_plugin_is_an_epilogue_activation(fp16):
+    """g1: the built-in Mish_TRT after Conv -> Scale becomes the convolution's epilogue (act code 6 = ACT_MISH), no plugin op
+    and no layout pass; behind anything else it is an activation op in the tensor's own layout.  The plan keeps the plugin layer and its
+    blob (int input_size, yolov4/mish.cu:24-32) so it round-trips through the registry."""
+    plan, _ = _conv_bn_mish_net(fp16)
+    low = engine.describe_plan(plan, lowered=True)
+    kinds = [o["kind"] for o in low["ops"]]
+    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    assert "plugin" not in kinds and len(convs) == 1 and convs[0]["act1"] == 6, kinds
+    assert [k for k in kinds if k not in ("conv", "to_nhwc", "to_linear")] == [], kinds
+    net = engine.describe_plan(plan)
+    plug = [l for l in net["layers"] if l.get("plugin_type")]
+    assert len(plug) == 1 and plug[0]["plugin_type"] == "Mish_TRT" and plug[0]["plugin_blob"] == __import__("struct").pack("<i", 32 * 12 * 20).hex()
+    low2 = engine.describe_plan(_conv_bn_mish_net(fp16, fused=False)[0], lowered=True)
+    k2 = [o["kind"] for o in low2["ops"]]
+    assert "plugin" not in k2 and "act_nhwc" in k2, k2

@@ -24,6 +24,7 @@ def sig(x, n=3):
 
 
 write = "--write" in sys.argv
+violations = []
 rows = [json.loads(l) for l in open([a for a in sys.argv[1:] if not a.startswith("--")][0]) if l.strip()]
 values = {}
 for key, metrics in parity.SPEC.items():
@@ -41,7 +42,18 @@ for key, metrics in parity.SPEC.items():
         else:
             worst = min(vals)
             values[key][m] = float(f"{1.0 - sig(FACTOR * (1.0 - worst) + slack):.12g}")
+        # the fitted bound is a drift alarm INSIDE the tolerance: never looser than the hand-written, spec-derived ceiling, which this tool
+        # never touches - a record that violates a ceiling is a failure of the product, not something to fit a bound around
+        ceil = parity.CEILINGS.get(key, {}).get(m)
+        if ceil is not None:
+            if not parity.holds(spec[0], ceil, worst):
+                violations.append((key, m, worst, ceil))
+            values[key][m] = min(values[key][m], ceil) if spec[0] == "max" else max(values[key][m], ceil)
         print(f"{str(key):50s} {m:26s} {spec[0]} worst {worst:<12.6g} bound {values[key][m]:<12.6g} ({len(mine)} runs)")
+for v in violations:
+    print("RECORD VIOLATES THE SPEC-DERIVED CEILING:", v)
+if write and violations:
+    sys.exit("not writing: fix the product (or argue the ceiling in tests/parity.py by hand), do not fit bounds around a violation")
 if write:
     path = os.path.join(ROOT, "tests", "parity.py")
     src = open(path).read()
