@@ -201,6 +201,13 @@ int32_t trtx_roi_align(int batch, const float* boxes, const float* features, int
 int32_t trtx_roi_align_nhwc_f16(int batch, const float* boxes, const void* features, int ld_in, int pooler_resolution,
                                 float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
                                 int feature_w, void* out, int ld_out, trtx_stream_t stream);
+/* ... computing only every bin_step-th bin per axis: out [batch * P][ores][ores][ld_out], ores = (res - 1) / bin_step + 1, bin (oh, ow) of
+ * the output = bin (oh * bin_step, ow * bin_step) of the res x res grid, same arithmetic.  bin_step 2 is what res5.0's two 1x1 STRIDE-2
+ * convolutions read of the 14 x 14 RoI features (rcnn/backbone.hpp:9,110-117 STRIDE_IN_1X1; rcnn/rcnn.cpp:147-163): the engine emits
+ * the 7 x 7 grid and runs those convolutions at stride 1 - three quarters of the RoIAlign samples and writes are gone. */
+int32_t trtx_roi_align_nhwc_f16_strided(int batch, const float* boxes, const void* features, int ld_in, int pooler_resolution,
+                                        float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
+                                        int feature_w, void* out, int ld_out, int bin_step, trtx_stream_t stream);
 /* predictorDecode (rcnn/PredictorDecode.cu:24-110): sort N*C scores, top N (n, cls) pairs, weighted delta decode.
  * The reference clips y2 with image_width (line 99); kept for parity. */
 size_t trtx_predictor_decode_workspace(int batch, int num_boxes, int num_classes);

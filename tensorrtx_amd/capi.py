@@ -265,12 +265,14 @@ def pack_chain_weights_f16(w_kcrs, ch_scale=None):
     return packed
 
 
-def poison_lds():
-    """Test support: fill every CU's LDS with fp16 NaN patterns (LDS is not cleared between kernels)."""
+def poison_lds(sync=True):
+    """Test support: fill every CU's LDS with fp16 NaN patterns (LDS is not cleared between kernels).  sync=False: only enqueued, on the
+    current stream - the poisoning workgroups then run BESIDE whatever the other streams have in flight."""
     import torch
     w = torch.zeros(4, dtype=torch.int32, device="cuda")
     check(lib().trtx_op_poison_lds(_p(w), _stream()), "trtx_op_poison_lds")
-    torch.cuda.synchronize()
+    if sync:
+        torch.cuda.synchronize()
 
 
 def conv_chain_plan(N, H, W, Cin, ks, couts, residuals=None, tile=(0, 0)):

@@ -14,7 +14,7 @@ namespace trtx {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr int kBins = 2048;
+constexpr int kBins = 8192;   // == runtime/int8.h kCalibBins (32 KB of LDS per workgroup)
 
 // max |x| over [pixels][C] (channel stride ld), C % 8 == 0: one atomicMax of the float bits (non-negative floats order as ints)
 __global__ __launch_bounds__(256) void absmax_f16_kernel(const _Float16* __restrict__ x, long pixels, int C, int ld, unsigned* __restrict__ out) {

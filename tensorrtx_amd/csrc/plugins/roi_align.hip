@@ -127,19 +127,23 @@ __global__ __launch_bounds__(256) void roi_align_nchw_f32_kernel(const float* __
 }
 
 // one wave per (RoI, bin); lanes own 8-channel chunks.  features NHWC fp16 [batch][height][width][ld_in], out NHWC fp16
-// [batch * num_proposals][res][res][ld_out]
+// [batch * num_proposals][ores][ores][ld_out] with ores = (res - 1) / step + 1: output bin (oh, ow) is bin (oh * step, ow * step) of the
+// res x res grid.  step = 1 is the operator itself; step = 2 is what a 1x1 STRIDE-2 consumer reads of it (res5.0's conv1 and shortcut,
+// rcnn/backbone.hpp:9,110-117 STRIDE_IN_1X1): the other three quarters of the bins are never computed or written.
 __global__ __launch_bounds__(256) void roi_align_nhwc_f16_kernel(const _Float16* __restrict__ features, int ld_in, const float* __restrict__ rois,
                                                                  float spatial_scale, int channels, int height, int width, int res,
-                                                                 int sampling_ratio, int num_proposals, _Float16* __restrict__ out, int ld_out) {
+                                                                 int sampling_ratio, int num_proposals, _Float16* __restrict__ out, int ld_out, int step) {
     const int n = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bin = blockIdx.x * 4 + wave;
-    if (bin >= res * res) return;  // whole waves
-    const int ph = bin / res, pw = bin - ph * res;
+    const int obin = blockIdx.x * 4 + wave;
+    const int ores = (res - 1) / step + 1;
+    if (obin >= ores * ores) return;  // whole waves
+    const int oh = obin / ores, ow = obin - oh * ores;
+    const int ph = oh * step, pw = ow * step;
     const int b = n / num_proposals;
     const RoiGeom g = roi_geometry(rois + (size_t)n * 4, spatial_scale, res, sampling_ratio);
     const _Float16* img = features + (size_t)b * height * width * ld_in;
-    _Float16* dst = out + (((size_t)n * res + ph) * res + pw) * ld_out;
+    _Float16* dst = out + (((size_t)n * ores + oh) * ores + ow) * ld_out;
     const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
     const int chunks = channels >> 3;
     for (int ck = lane; ck < chunks; ck += 64) {
@@ -184,13 +188,23 @@ extern "C" int32_t trtx_roi_align(int batch, const float* boxes, const float* fe
 extern "C" int32_t trtx_roi_align_nhwc_f16(int batch, const float* boxes, const void* features, int ld_in, int pooler_resolution,
                                            float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
                                            int feature_w, void* out, int ld_out, hipStream_t stream) {
-    if (!boxes || !features || !out || batch < 1 || pooler_resolution < 1 || num_proposals < 1 || channels < 8 || feature_h < 1 || feature_w < 1)
+    return trtx_roi_align_nhwc_f16_strided(batch, boxes, features, ld_in, pooler_resolution, spatial_scale, sampling_ratio, num_proposals, channels,
+                                           feature_h, feature_w, out, ld_out, 1, stream);
+}
+
+// ... every bin_step-th bin per axis only: out NHWC fp16 [batch * P][ores][ores][ld_out], ores = (res - 1) / bin_step + 1
+extern "C" int32_t trtx_roi_align_nhwc_f16_strided(int batch, const float* boxes, const void* features, int ld_in, int pooler_resolution,
+                                                   float spatial_scale, int sampling_ratio, int num_proposals, int channels, int feature_h,
+                                                   int feature_w, void* out, int ld_out, int bin_step, hipStream_t stream) {
+    if (!boxes || !features || !out || batch < 1 || pooler_resolution < 1 || num_proposals < 1 || channels < 8 || feature_h < 1 || feature_w < 1 ||
+        bin_step < 1)
         return TRTX_ERR_INVALID;
     if (channels % 8 || ld_in % 8 || ld_out % 8 || (reinterpret_cast<uintptr_t>(features) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return TRTX_ERR_UNSUPPORTED;
-    const int bins = pooler_resolution * pooler_resolution;
+    const int ores = (pooler_resolution - 1) / bin_step + 1;
+    const int bins = ores * ores;
     const dim3 grid((unsigned)((bins + 3) / 4), (unsigned)(batch * num_proposals));
     hipLaunchKernelGGL(roi_align_nhwc_f16_kernel, grid, dim3(256), 0, stream, static_cast<const _Float16*>(features), ld_in, boxes, spatial_scale,
-                       channels, feature_h, feature_w, pooler_resolution, sampling_ratio, num_proposals, static_cast<_Float16*>(out), ld_out);
+                       channels, feature_h, feature_w, pooler_resolution, sampling_ratio, num_proposals, static_cast<_Float16*>(out), ld_out, bin_step);
     return trtx::check_launch("trtx_roi_align_nhwc_f16");
 }

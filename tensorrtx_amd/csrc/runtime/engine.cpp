@@ -343,8 +343,8 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
             }
             case OP_ROI_ALIGN: {
                 const PTensor& ft = plan.tensors[op.in[1]];
-                st = trtx_roi_align_nhwc_f16(batch, static_cast<const float*>(R.ptr(op.in[0])), R.ptr(op.in[1]), ft.ld, op.i[0], op.f[0], op.i[1],
-                                             op.i[2], ft.C, ft.H, ft.W, R.ptr(op.out[0]), to.ld, stream);
+                st = trtx_roi_align_nhwc_f16_strided(batch, static_cast<const float*>(R.ptr(op.in[0])), R.ptr(op.in[1]), ft.ld, op.i[0], op.f[0], op.i[1],
+                                                     op.i[2], ft.C, ft.H, ft.W, R.ptr(op.out[0]), to.ld, op.i[3] > 0 ? op.i[3] : 1, stream);
                 break;
             }
             case OP_COPY_LIN: {

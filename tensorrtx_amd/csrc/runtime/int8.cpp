@@ -273,28 +273,45 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
             if (t.parent >= 0 || t.layout != LAY_NHWC || t.net_tensor < 0 || t.storage < 0) continue;
             const size_t s = (size_t)t.storage;
             if (!(obs.range[s] > 0.f)) continue;
-            std::vector<double> h(kCalibBins);
-            for (int k = 0; k < kCalibBins; ++k) h[k] = (double)h_hist[s * kCalibBins + k];
+            // the collected fine histogram -> kEntropyBins bins over [0, absmax], absmax = upper edge of the last occupied fine bin; a fine
+            // bin that straddles two coarse ones is split in proportion (>= 2 fine bins per coarse bin: at most half a fine bin of smear)
+            const unsigned long long* hf = h_hist.data() + s * kCalibBins;
+            int last = 0;
+            for (int k = 0; k < kCalibBins; ++k)
+                if (hf[k]) last = k;
+            const double wf = (double)obs.range[s] / kCalibBins;
+            const float absmax = (float)((last + 1) * wf);
+            std::vector<double> h(kEntropyBins, 0.0);
+            const double wc = (double)absmax / kEntropyBins;
+            for (int k = 0; k <= last; ++k) {
+                if (!hf[k]) continue;
+                const double lo = k * wf, hi = (k + 1) * wf;
+                int c0 = (int)(lo / wc), c1 = (int)(hi / wc);
+                c0 = c0 < kEntropyBins ? c0 : kEntropyBins - 1;
+                c1 = c1 < kEntropyBins ? c1 : kEntropyBins - 1;
+                if (c0 == c1) {
+                    h[c0] += (double)hf[k];
+                } else {
+                    for (int c = c0; c <= c1; ++c) {
+                        const double a = std::max(lo, c * wc), b = std::min(hi, (c + 1) * wc);
+                        if (b > a) h[c] += (double)hf[k] * (b - a) / (hi - lo);
+                    }
+                }
+            }
             float thr;
-            if (minmax) {   // kMINMAX_CALIBRATION: the upper edge of the last occupied bin = the largest |x| seen (to one bin)
-                int last = 0;
-                for (int k = 0; k < kCalibBins; ++k)
-                    if (h[k] > 0) last = k;
-                thr = obs.range[s] * (float)(last + 1) / (float)kCalibBins;
+            if (minmax) {   // kMINMAX_CALIBRATION: the largest |x| seen (to one fine bin)
+                thr = absmax;
             } else {
-                thr = entropy_threshold(h, obs.range[s]);
+                thr = entropy_threshold(h, absmax);
             }
             net->tensor_scale[t.net_tensor] = thr / 127.0f;
             if (report) {
                 double total = 0, beyond = 0;
-                int last = 0;
-                const double width = (double)obs.range[s] / kCalibBins;
-                for (int k = 0; k < kCalibBins; ++k) {
+                for (int k = 0; k < kEntropyBins; ++k) {
                     total += h[k];
-                    if (h[k] > 0) last = k;
-                    if ((k + 0.5) * width > thr) beyond += h[k];
+                    if ((k + 0.5) * wc > thr) beyond += h[k];
                 }
-                fprintf(report, "%s\t%.6g\t%.6g\t%.3e\t%.4f\t%.0f\n", calib_tensor_name(*net, t.net_tensor).c_str(), (last + 1) * width, (double)thr,
+                fprintf(report, "%s\t%.6g\t%.6g\t%.3e\t%.4f\t%.0f\n", calib_tensor_name(*net, t.net_tensor).c_str(), (double)absmax, (double)thr,
                         total > 0 ? beyond / total : 0.0, total > 0 ? h[0] / total : 0.0, total);
             }
         }

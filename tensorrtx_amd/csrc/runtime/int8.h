@@ -12,7 +12,10 @@ struct trtx_context;
 
 namespace trtx {
 
-constexpr int kCalibBins = 2048;
+constexpr int kCalibBins = 8192;    // bins COLLECTED per tensor: the range is only known to a power of two while batches arrive (it doubles, bins
+                                    // fold pairwise), so the largest |x| ends up anywhere in the upper half of it - at least 4096 bins cover it
+constexpr int kEntropyBins = 2048;  // bins SEARCHED: the collected histogram resampled onto [0, largest |x| seen] (round 4: searching 2048 bins of
+                                    // a range up to twice the data's put the threshold on a 2x coarser grid than the calibrator is described with)
 
 // statistics collected while a calibration batch runs through the fp16 plan (one slot per plan storage = per owning tensor)
 struct CalibObserver {

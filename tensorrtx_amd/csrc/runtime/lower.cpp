@@ -71,6 +71,7 @@ struct Lowerer {
     std::vector<std::vector<int>> consumers;
     std::vector<int> pt_of, pt_lin, pt_nhwc;
     std::vector<bool> absorbed;
+    std::vector<char> stride_folded;   // per layer: a 1x1 stride-s convolution whose producer emitted only the pixels it reads -> stride 1
     std::vector<int> group_at;
     std::vector<FusedConv> groups;
     std::vector<YoloHeadFuse> yolo_heads;
@@ -87,6 +88,7 @@ struct Lowerer {
         pt_lin.assign(n.tensors.size(), -1);
         pt_nhwc.assign(n.tensors.size(), -1);
         absorbed.assign(n.layers.size(), false);
+        stride_folded.assign(n.layers.size(), 0);
         group_at.assign(n.layers.size(), -1);
         yolo_at.assign(n.layers.size(), -1);
     }
@@ -512,6 +514,7 @@ struct Lowerer {
             a.kw = l.kernel[1];
             a.stride_h = l.stride[0];
             a.stride_w = l.stride[1];
+            if (stride_folded[g.conv_layer]) a.stride_h = a.stride_w = 1;   // its input was emitted at the positions it reads (RoIAlign, below)
             a.pad_h = l.padding[0];
             a.pad_w = l.padding[1];
             a.dil_h = l.dilation[0];
@@ -797,11 +800,37 @@ struct Lowerer {
                         if (iv[0] > 0 && iv[3] > 0 && iv[4] == feat.C && iv[5] == feat.H && iv[6] == feat.W && feat.nmul == 1 && feat.C % 8 == 0 &&
                             od.nb == 4 && od.d[0] == iv[3] && od.d[1] == iv[4] && od.d[2] == iv[0] && od.d[3] == iv[0]) {
                             const int boxes = need_lin(l.inputs[0]);
-                            const int out = new_tensor(l.outputs[0], od, LAY_NHWC, true);
-                            POp& op = add_op(OP_ROI_ALIGN, l.name + " [native NHWC]", {boxes, pt_of[l.inputs[1]]}, {out});
-                            op.i[0] = iv[0]; op.i[1] = iv[2]; op.i[2] = iv[3];
+                            // Every reader a 1x1 stride-2 unpadded convolution (res5.0's conv1 and its shortcut, rcnn/backbone.hpp:9,110-117
+                            // STRIDE_IN_1X1; Faster R-CNN R50-C4): only the even bins are ever read.  Emit exactly those - [P][7][7][C]
+                            // instead of [P][14][14][C] - and run the readers at stride 1 over it: the same samples in the same order
+                            // (bit-identical), a quarter of the RoIAlign work and writes (C5 b4: 1.6 GB -> 0.4 GB per step), and the
+                            // convolutions read contiguous pixels.  Mask R-CNN's mask-head RoIAlign feeds a stride-1 reader and keeps
+                            // the full grid (rcnn/rcnn.cpp:204-233).  TRTX_ROIALIGN_FOLD_STRIDE=0 keeps the full grid (A/B, tests).
+                            int step = 0;
+                            const bool no_fold = getenv("TRTX_ROIALIGN_FOLD_STRIDE") && atoi(getenv("TRTX_ROIALIGN_FOLD_STRIDE")) == 0;   // read at every lowering
+                            if (!no_fold && !net.tensors[l.outputs[0]].is_output && !consumers[l.outputs[0]].empty()) {
+                                step = -1;
+                                for (int c : consumers[l.outputs[0]]) {
+                                    const LayerDef& cl = net.layers[c];
+                                    const bool ok = cl.kind == L_CONV && cl.inputs[0] == l.outputs[0] && cl.kernel[0] == 1 && cl.kernel[1] == 1 &&
+                                                    cl.stride[0] == cl.stride[1] && cl.stride[0] > 1 && cl.padding[0] == 0 && cl.padding[1] == 0 &&
+                                                    cl.groups == 1 && (step < 0 || step == cl.stride[0]);
+                                    if (!ok) { step = 0; break; }
+                                    step = cl.stride[0];
+                                }
+                            }
+                            Dims od_emit = od;
+                            if (step > 1) {
+                                od_emit.d[2] = od_emit.d[3] = (iv[0] - 1) / step + 1;
+                                for (int c : consumers[l.outputs[0]]) stride_folded[c] = 1;
+                            } else {
+                                step = 1;
+                            }
+                            const int out = new_tensor(l.outputs[0], od_emit, LAY_NHWC, true);
+                            POp& op = add_op(OP_ROI_ALIGN, l.name + (step > 1 ? " [native NHWC, every 2nd bin]" : " [native NHWC]"), {boxes, pt_of[l.inputs[1]]}, {out});
+                            op.i[0] = iv[0]; op.i[1] = iv[2]; op.i[2] = iv[3]; op.i[3] = step;
                             op.f[0] = scale;
-                            op.bytes = 2.0 * (double)od.volume() + 2.0 * (double)feat.C * feat.H * feat.W;
+                            op.bytes = 2.0 * (double)od_emit.volume() + 2.0 * (double)feat.C * feat.H * feat.W;
                             pt_of[l.outputs[0]] = out;
                             return true;
                         }

@@ -284,7 +284,7 @@ def mish_case(batch=2, shape=(5, 7, 9), seed=21):
                           1e-6, -1e-6, 19.999, -19.999], dtype=np.float32)
     x[:, 10:n // 2] = rng.normal(0, 2, size=(batch, n // 2 - 10)).astype(np.float32)   # where activations actually live
     return Case(f"mish_{'x'.join(map(str, shape))}", "yolov4_plugin", "Mish_TRT", batch, [x.reshape((batch,) + shape)], [(batch,) + shape],
-                blob=struct.pack("<i", n), rtol=2e-6, atol=1e-9)
+                blob=struct.pack("<i", n), rtol=2e-6, atol=2e-6)   # logf(expf(x) + 1) for x < 0 amplifies one ulp of expf (device vs NumPy) to ~1e-6 absolute
 
 
 def mish_product(c, dev):

@@ -156,7 +156,9 @@ def test_yolov8n_int8_engine_calibrated_on_the_gpu(gpu):
     # int8 activations + weights: a few percent MEAN error on the head tensors; single elements can be far off (err8 is recorded, not
     # bounded).  What that does to detections is test_yolov8n_int8_detections_at_640 below.
     from tests import parity
-    parity.check("yolov8n_int8_320", head_max_abs_err_int8=err8, head_max_abs_err_fp16=err16, head_mean_rel_err_int8=rel8)
+    span = max(float(np.abs(h.numpy()).max()) for h in heads)   # the largest |logit| of the oracle heads (40-55 with these weights)
+    parity.check("yolov8n_int8_320", head_max_abs_err_int8=err8, head_max_abs_err_fp16=err16, head_mean_rel_err_int8=rel8,
+                 head_max_err_over_span_int8=err8 / span)
 
 
 def _iou(r, G):

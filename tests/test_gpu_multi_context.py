@@ -36,7 +36,7 @@ def _check(model, batch, h, w, xs, gpu, rounds=4, rec=0, poison=False, **opts):
         for r in range(rounds):          # keep all contexts busy at the same time, several rounds back to back
             if poison:                   # NaN patterns into every CU's LDS between (and, on its own stream, beside) the rounds
                 with torch.cuda.stream(side):
-                    capi.poison_lds()
+                    capi.poison_lds(sync=False)
             for j in range(n):
                 k = (j + r) % n          # context j sees a different input every round
                 ctxs[j].enqueue(batch, [xs[k] if e.is_input[i] else outs[j][i] for i in range(e.nb_bindings)], stream=streams[j].cuda_stream)

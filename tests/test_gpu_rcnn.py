@@ -156,3 +156,18 @@ def test_mask_rcnn_fp16_engine(gpu):
     err = float(np.abs(masks - ref["masks"]).max())
     parity.check("mask_rcnn_fp16", mask_err=err, mask_mean=float(masks.mean()))
     assert np.isfinite(masks).all() and masks.std() > 0.01
+
+
+def test_roi_align_stride_fold_is_bit_identical(gpu, monkeypatch):
+    """The 7x7 RoIAlign + stride-1 readers against the 14x14 RoIAlign + stride-2 readers: the same samples summed in the same order, the same
+    GEMM rows - every output of the engine equal bit for bit (Faster R-CNN, fp16, two images)."""
+    path, _ = synth_wts("rcnn_r50c4")
+    cfg = dict(pre_nms_topk=2000, post_nms_topk=200, detections=50)
+    x = _images(2, 320, 416, 23)
+    monkeypatch.setenv("TRTX_TUNE", "0")      # one static kernel choice for both plans (a 7x7-pixel GEMM and a strided one get different tactics otherwise)
+    folded = _run(engine.build_plan("rcnn_r50c4", path, batch=2, fp16=1, h=320, w=416, **cfg), {"images": x.numpy()}, 2, gpu)
+    monkeypatch.setenv("TRTX_ROIALIGN_FOLD_STRIDE", "0")
+    full = _run(engine.build_plan("rcnn_r50c4", path, batch=2, fp16=1, h=320, w=416, **cfg), {"images": x.numpy()}, 2, gpu)
+    assert set(folded) == set(full)
+    for k in folded:
+        assert torch.equal(folded[k], full[k]), k

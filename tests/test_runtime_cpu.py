@@ -622,3 +622,23 @@ def test_mish_plugin_is_an_epilogue_activation(fp16):
     low2 = engine.describe_plan(_conv_bn_mish_net(fp16, fused=False)[0], lowered=True)
     k2 = [o["kind"] for o in low2["ops"]]
     assert "plugin" not in k2 and "act_nhwc" in k2, k2
+
+
+def test_roi_align_emits_only_the_bins_its_stride_2_readers_read(monkeypatch):
+    """res5.0's conv1 and shortcut are 1x1 STRIDE-2 convolutions (rcnn/backbone.hpp:9,110-117): the fp16 plan's RoIAlign
+    writes the 7x7 even bins instead of 14x14 and both readers run at stride 1; TRTX_ROIALIGN_FOLD_STRIDE=0 keeps the full grid."""
+    path, _ = synth_wts("rcnn_r50c4")
+
+    def head(env):
+        if env is not None:
+            monkeypatch.setenv("TRTX_ROIALIGN_FOLD_STRIDE", env)
+        ops = engine.describe_plan(engine.build_plan("rcnn_r50c4", path, batch=1, fp16=1, h=320, w=416), lowered=True)["ops"]
+        k = next(i for i, o in enumerate(ops) if o["kind"] == "roi_align")
+        readers = [o for o in ops[k + 1:] if o["kind"] == "conv" and o["in"][0] == ops[k]["out"][0]]
+        return ops[k], readers
+    ra, readers = head(None)
+    assert "every 2nd bin" in ra["name"] and len(readers) == 2
+    assert all(o["k"] == [1, 1] and o["stride"] == [1, 1] and o["hw_in"] == [7, 7] and o["hw_out"] == [7, 7] for o in readers)
+    ra0, readers0 = head("0")
+    assert "every 2nd bin" not in ra0["name"] and all(o["stride"] == [2, 2] and o["hw_in"] == [14, 14] and o["hw_out"] == [7, 7] for o in readers0)
+    assert ra["bytes"] < 0.3 * ra0["bytes"]

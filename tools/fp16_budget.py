@@ -53,7 +53,10 @@ class Emu:
     def site(self, name, t):
         if name not in self.sites:
             self.sites.append(name)
-        return r16(t) if self.on(name) else t
+        r = self.on(name)
+        if callable(r):      # tools/int8_budget.py: a site may carry its own transform (quantise / clip) instead of the fp16 rounding
+            return r(t)
+        return r16(t) if r else t
 
     def conv(self, x, name, cout, k, s, pad, bn=True, act=True, gain=2.0, bias_init=None, res=None):
         p = self.p
