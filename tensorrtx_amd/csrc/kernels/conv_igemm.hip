@@ -237,10 +237,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 // Rows beyond M carry an out-of-range base from the start; the run-out steps past K read whatever follows (they are never multiplied).
 // Measured (round 3, same box): the 1x1 layers of YOLOv8n b32 3-10 % faster one at a time (34-layer sum 715 vs 724 us), res5's 1x1
 // 2048 -> 512 GEMM 497 vs 509 us; bench.py within run-to-run noise (35.0-35.2k vs 34.4-35.3k img/s).  Same bits.
+// LDS bytes of one instantiation (the stage buffers, or the epilogue's staging tiles if those are larger)
+template <int NFRAG, int BKT, int MI, int WN, int NSTO, int NW, bool RS>
+constexpr int igemm_lds_bytes() {
+    constexpr int BN = 16 * NFRAG, WM = NW / WN, NFW = NFRAG / WN, BM = WM * 16 * MI, ROW_B = BKT * 2, CH = BKT / 8, RPI = 64 / CH;
+    constexpr int B_PASSES = (BN + NW * RPI - 1) / (NW * RPI), B_ROWS = B_PASSES * NW * RPI;
+    constexpr int STAGE_BYTES = BM * ROW_B + B_ROWS * ROW_B;
+    constexpr int NST = RS ? 2 : NSTO ? NSTO : (BKT == 64 ? 2 : 3);
+    constexpr int EPI_BYTES = NW * 16 * (16 * NFW * 4 + 16);
+    return NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
+}
+
+// One (BM x BN) output tile at (m0, n0) of the convolution `p`: the whole kernel but for the blockIdx -> tile mapping, which the two
+// entry points below do differently (one problem per launch / several problems per launch, round 4).
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
           bool ONE = false>
-__global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
-                                                             int total_tiles, int xcd_chunk, int dbg_flags) {
+__device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_bytes, unsigned w_bytes, const int m0, const int n0, int dbg_flags,
+                                                char* __restrict__ smem) {
     const int dbg = TRTX_DBG(dbg_flags);
     constexpr int BN = 16 * NFRAG;
     constexpr int WM = NW / WN;                    // waves along M (NW = waves per workgroup: 4, or 8 for the large-GEMM tile)
@@ -261,18 +274,11 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     constexpr int NST = RS ? 2 : NSTO ? NSTO : (BKT == 64 ? 2 : 3);  // pipeline stages (64-wide stages are double-buffered to keep occupancy)
     constexpr int EPI_BYTES = NW * 16 * (16 * NFW * 4 + 16);   // the epilogue's wave-private staging tiles (conv_epilogue)
     constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // up to 144 KB of the CU's 160 KB (the large-GEMM tile)
+    static_assert(LDS_BYTES == igemm_lds_bytes<NFRAG, BKT, MI, WN, NSTO, NW, RS>(), "the entry points allocate what the tile function uses");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
-    if (xcd_chunk) {  // XCD-aware order: id -> (xcd = id % 8, slot = id / 8) -> contiguous tile range per XCD
-        tile = (tile & 7) * xcd_chunk + (tile >> 3);
-        if (tile >= total_tiles) return;
-    }
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
@@ -566,6 +572,51 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
         const int m = m0 + t;
         return m < p.M ? m : -1;
     }, wave_m * WR);
+}
+
+template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
+          bool ONE = false>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
+                                                             int total_tiles, int xcd_chunk, int dbg_flags) {
+    __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<NFRAG, BKT, MI, WN, NSTO, NW, RS>()];   // up to 144 KB of the CU's 160 KB
+    int tile = blockIdx.x;
+    if (xcd_chunk) {  // XCD-aware order: id -> (xcd = id % 8, slot = id / 8) -> contiguous tile range per XCD
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    const int m0 = (tile / tiles_n) * ((NW / WN) * 16 * MI);
+    const int n0 = (tile % tiles_n) * (16 * NFRAG);
+    conv_igemm_tile<NFRAG, BKT, TPS, I8, MI, WN, NSTO, PRE, NW, RS, UP, ONE>(p, in_bytes, w_bytes, m0, n0, dbg_flags, smem);
+}
+
+// Several INDEPENDENT convolutions in one launch (round 4).  The YOLOv8 detect head is six chains of depth three over
+// three pyramid levels (yolov8/src/model.cpp:188-251): at batch 32 the 20x20 level is 100 tiles for 256 CUs and the 40x40 level 400, each
+// paying the per-launch floor on its own.  Here the tile index runs over the tiles of up to kMaxGroup problems of ONE instantiation
+// (same column-tile width, k-step, operand path): a workgroup looks its problem up in a prefix table held in the kernel arguments and then
+// is exactly a workgroup of that problem's own launch - same tile, same K order, same bits.  The small levels' tiles fill the CUs the
+// large level's tail leaves idle, and 18 launches become 6.
+struct ConvGroupArgs {
+    int n;
+    int tile_start[kMaxConvGroup + 1];   // prefix sums of the problems' tile counts (XCD-ordered global tile index -> problem)
+    int tiles_n[kMaxConvGroup];
+    unsigned in_bytes[kMaxConvGroup], w_bytes[kMaxConvGroup];
+    ConvArgs p[kMaxConvGroup];
+};
+template <int NFRAG, int BKT, bool RS, bool ONE>
+__global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGroupArgs g, int xcd_chunk, int dbg_flags) {
+    __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<NFRAG, BKT, 2, 1, 0, 4, RS>()];
+    int tile = blockIdx.x;
+    tile = (tile & 7) * xcd_chunk + (tile >> 3);
+    if (tile >= g.tile_start[g.n]) return;
+    int pid = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxConvGroup; ++k) pid += (k < g.n && tile >= g.tile_start[k]) ? 1 : 0;
+    pid = __builtin_amdgcn_readfirstlane(pid);
+    const int local = tile - g.tile_start[pid];
+    const int tn = g.tiles_n[pid];
+    const int m0 = (local / tn) * 128;
+    const int n0 = (local % tn) * (16 * NFRAG);
+    conv_igemm_tile<NFRAG, BKT, 1, false, 2, 1, 0, false, 4, RS, false, ONE>(g.p[pid], g.in_bytes[pid], g.w_bytes[pid], m0, n0, dbg_flags, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1320,6 +1371,64 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         if (st != TRTX_OK) return st;
     }
     return check_launch("conv_igemm_f16");
+}
+
+// ---- grouped launch ------------------------------------------------------------------------------------------------------
+namespace {
+bool plain_gemm(const ConvArgs& a) {   // the ONE instantiation's condition (launch<> above)
+    return a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K;
+}
+// what the single-problem dispatch would run for this layer must be the plain 128-row / 32-wide-step main kernel
+bool group_member_ok(const ConvArgs& a) {
+    return conv_igemm_supported(a) && !a.in_i8 && !a.out_i8 && !a.res_i8 && !a.up_C && !a.scalar_out && a.CinK != 16 && a.bk == 32 && (a.bn == 64 || a.bn == 80) &&
+           (a.bm == 0 || a.bm == 128) && a.t_r3 == 0 && a.t_wsk != 2 && (double)a.N * a.H * a.W * a.ld_in * 2.0 < 2.0e9;
+}
+template <int NFRAG, bool RS, bool ONE>
+void launch_group(const ConvGroupArgs& g, int total, hipStream_t s) {
+    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
+    const int chunk = (total + 7) / 8;
+    TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE>), dim3(chunk * 8), dim3(256), 0, s, g, chunk, dbg);
+}
+}  // namespace
+
+bool conv_igemm_group_supported(const ConvArgs* a, int n) {
+    if (n < 2 || n > kMaxConvGroup) return false;
+    for (int k = 0; k < n; ++k) {
+        if (!group_member_ok(a[k])) return false;
+        if (a[k].t_ws != 1 && conv_ws_supported(a[k])) return false;   // that layer belongs to the weight-stationary kernel
+        if (a[k].bn != a[0].bn || (a[k].t_rs != 0) != (a[0].t_rs != 0) || plain_gemm(a[k]) != plain_gemm(a[0])) return false;
+    }
+    return true;
+}
+
+int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
+    if (!conv_igemm_group_supported(a, n)) return TRTX_ERR_UNSUPPORTED;
+    ConvGroupArgs g{};
+    g.n = n;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        g.p[k] = a[k];
+        g.p[k].M = a[k].N * a[k].Ho * a[k].Wo;
+        g.tile_start[k] = total;
+        g.tiles_n[k] = a[k].Cout_pad / a[k].bn;
+        total += ((g.p[k].M + 127) / 128) * g.tiles_n[k];
+        g.in_bytes[k] = (unsigned)((((size_t)a[k].N * a[k].H * a[k].W - 1) * a[k].ld_in + a[k].Cin) * 2);
+        g.w_bytes[k] = (unsigned)((size_t)a[k].Cout_pad * a[k].Kpad * 2);
+    }
+    for (int k = n; k <= kMaxConvGroup; ++k) g.tile_start[k] = total;
+    static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // the same A/B switch as the single launches
+    const bool rs = rs_env >= 0 ? rs_env != 0 : a[0].t_rs != 0;
+    static const bool one_off = getenv("TRTX_CONV_NOONE") != nullptr;
+    const bool one = !one_off && plain_gemm(a[0]);
+    const int nf = a[0].bn / 16;
+    if (nf == 4) {
+        if (one) rs ? launch_group<4, true, true>(g, total, s) : launch_group<4, false, true>(g, total, s);
+        else rs ? launch_group<4, true, false>(g, total, s) : launch_group<4, false, false>(g, total, s);
+    } else {
+        if (one) rs ? launch_group<5, true, true>(g, total, s) : launch_group<5, false, true>(g, total, s);
+        else rs ? launch_group<5, true, false>(g, total, s) : launch_group<5, false, false>(g, total, s);
+    }
+    return check_launch("conv_igemm_group_f16");
 }
 
 }  // namespace trtx

@@ -91,6 +91,12 @@ int32_t conv_igemm_f16(const ConvArgs& a, hipStream_t s);
 // activations, 64-row tiles re-read the weights) - what an engine whose contexts run side by side should choose from.
 int conv_tactics(const ConvArgs& a, ConvTactic* out, int max_out, bool work_efficient_only = false);
 void conv_apply_tactic(ConvArgs* a, const ConvTactic& t);
+// Several independent fp16 implicit-GEMM convolutions in ONE launch (conv_igemm.hip conv_igemm_group_f16_kernel): the members share a
+// kernel instantiation - 128-row tiles, one column-tile width (64 or 80), 32-wide k-steps, the same operand path (t_rs) and all or none of
+// them plain 1x1 GEMMs - and each is computed exactly as its own launch would compute it (same tiles, same K order: the same bits).
+constexpr int kMaxConvGroup = 4;
+bool conv_igemm_group_supported(const ConvArgs* a, int n);
+int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);

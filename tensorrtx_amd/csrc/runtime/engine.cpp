@@ -101,7 +101,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
         probes.resize(plan.ops.size());
         if (!no_probe && !c->tuning)  // the tactic timing keeps its own clock (the interval between the stream events)
             for (size_t k = 0; k < plan.ops.size(); ++k)
-                if ((plan.ops[k].kind == OP_CONV && plan.ops[k].igemm) || plan.ops[k].kind == OP_CONV_CHAIN)
+                if ((plan.ops[k].kind == OP_CONV && plan.ops[k].igemm) || plan.ops[k].kind == OP_CONV_CHAIN || plan.ops[k].kind == OP_CONV_GROUP)
                     if (hipEventCreate(&probes[k].start) != hipSuccess || hipEventCreate(&probes[k].stop) != hipSuccess) (void)hipGetLastError();
         TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
     }
@@ -176,6 +176,33 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     conv_set_launch_probe(nullptr);
                 } else
                     st = conv_direct(a, op.dtype, stream);
+                break;
+            }
+            case OP_CONV_GROUP: {   // independent convolutions of one kernel instantiation: one launch (conv_igemm_group_f16_kernel)
+                ConvArgs ga[kMaxConvGroup];
+                const int gn = (int)op.group.size();
+                if (gn < 2 || gn > kMaxConvGroup) { st = TRTX_ERR_STATE; break; }
+                for (int m = 0; m < gn; ++m) {
+                    const POp& mo = op.group[m];
+                    ConvArgs& a = ga[m];
+                    a = mo.conv;
+                    a.in = R.ptr(mo.in[0]);
+                    a.out = R.ptr(mo.out[0]);
+                    a.residual = mo.in.size() > 1 ? R.ptr(mo.in[1]) : nullptr;
+                    a.up_in = nullptr;
+                    a.wgt = W + mo.w_off;
+                    a.bias = reinterpret_cast<const float*>(W + mo.b_off);
+                    a.cscale = nullptr;
+                    a.N = nb(plan.tensors[mo.in[0]]);
+                    a.M = a.N * a.Ho * a.Wo;
+                }
+                if (prof && probes[k].start && probes[k].stop) conv_set_launch_probe(&probes[k]);
+                st = conv_igemm_group_f16(ga, gn, stream);
+                conv_set_launch_probe(nullptr);
+                if (st == TRTX_ERR_UNSUPPORTED) {   // a batch at which the members no longer share an instantiation: one launch each, same bits
+                    st = TRTX_OK;
+                    for (int m = 0; m < gn && st == TRTX_OK; ++m) st = conv_igemm_f16(ga[m], stream);
+                }
                 break;
             }
             case OP_CONV_CHAIN: {

@@ -16,8 +16,8 @@ const char* op_kind_name(int k) {
     static const char* n[] = {"conv",     "deconv",    "pool",      "resize",     "ew_nhwc", "act_nhwc", "scale_nhwc",
                               "copy_nhwc", "reduce_hw", "to_nhwc",   "to_linear",  "gather",  "scatter",  "ew_lin",
                               "act_lin",  "scale_lin", "softmax",   "matmul",     "reduce_lin", "plugin", "copy_lin", "yolo_head",
-                              "pool_chain", "depth_to_space", "roi_align", "conv_chain"};
-    return (k >= 0 && k <= OP_CONV_CHAIN) ? n[k] : "?";
+                              "pool_chain", "depth_to_space", "roi_align", "conv_chain", "conv_group"};
+    return (k >= 0 && k <= OP_CONV_GROUP) ? n[k] : "?";
 }
 
 namespace {
@@ -1287,6 +1287,213 @@ struct Lowerer {
         }
     }
 
+    // Independent convolutions of one kernel instantiation -> one launch (OP_CONV_GROUP; kernels/conv_igemm.hip conv_igemm_group_f16_kernel).
+    // The YOLOv8 detect head is six chains of depth three over three pyramid levels (yolov8/src/model.cpp:188-251): cv2.{0,1,2}.0 are three
+    // independent 3x3 convolutions to 64 channels, cv3.{0,1,2}.0 three to 80, and so on down the chains - 18 launches, of which the 20x20 and
+    // 40x40 levels (100 / 400 tiles at batch 32 for 256 CUs) mostly pay the per-launch floor.  Members must be pairwise independent (no
+    // dependency path either way), have the same filter, stride, Cout, activation and residual-ness and sit at the same height above the
+    // plan's sinks (so that they are the same LAYER of sibling branches, not unrelated work that happens to fit) and pass conv_igemm_group_supported().  The ops are then re-ordered
+    // (a topological order of the dependency graph with each group contracted to one node; a grouping that would close a cycle between
+    // two groups is dropped) and every group's members are replaced by one op whose in / out are the unions.  Each member is computed
+    // exactly as its own launch computes it: bit-identical outputs.  TRTX_GROUP_CONVS=0 keeps one launch per convolution (A/B, tests).
+    void group_convs() {
+        if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
+        if (const char* e = getenv("TRTX_GROUP_CONVS"))
+            if (atoi(e) == 0) return;
+        const int n = (int)plan.ops.size();
+        if (n < 2 || n > 4096) return;
+        // all dependencies (RAW, WAR, WAW at storage / channel-range granularity, as finalize step 5 computes them) in the current order
+        struct Acc { int storage; long lo, hi; int op; bool write; };
+        auto acc_of = [&](int t, int op, bool write) {
+            const PTensor& pt = plan.tensors[t];
+            Acc a{pt.storage, 0, 0, op, write};
+            if (pt.layout == LAY_NHWC) {
+                a.lo = pt.rcoff;
+                a.hi = pt.rcoff + (pt.parent < 0 && pt.Calloc > pt.C ? pt.Calloc : pt.C);
+            } else {
+                a.lo = pt.reoff;
+                a.hi = pt.reoff + pt.dims.volume();
+            }
+            return a;
+        };
+        std::vector<std::vector<int>> deps(n);
+        {
+            std::vector<Acc> log;
+            for (int k = 0; k < n; ++k) {
+                const POp& op = plan.ops[k];
+                std::vector<Acc> mine;
+                for (int t : op.in) mine.push_back(acc_of(t, k, false));
+                for (int t : op.extra_in) mine.push_back(acc_of(t, k, false));
+                for (int t : op.out) mine.push_back(acc_of(t, k, true));
+                for (const Acc& m : mine)
+                    for (const Acc& o : log)
+                        if (o.storage == m.storage && o.lo < m.hi && m.lo < o.hi && (o.write || m.write) && o.op != k) deps[k].push_back(o.op);
+                std::sort(deps[k].begin(), deps[k].end());
+                deps[k].erase(std::unique(deps[k].begin(), deps[k].end()), deps[k].end());
+                log.insert(log.end(), mine.begin(), mine.end());
+            }
+        }
+        // ancestors (transitive), as bit rows
+        const int words = (n + 63) / 64;
+        std::vector<uint64_t> anc((size_t)n * words, 0);
+        auto is_anc = [&](int a, int of) { return (anc[(size_t)of * words + a / 64] >> (a % 64)) & 1ull; };
+        for (int k = 0; k < n; ++k)
+            for (int d : deps[k]) {
+                anc[(size_t)k * words + d / 64] |= 1ull << (d % 64);
+                for (int w = 0; w < words; ++w) anc[(size_t)k * words + w] |= anc[(size_t)d * words + w];
+            }
+        auto args_at_max_batch = [&](const POp& op) {
+            ConvArgs a = op.conv;
+            const PTensor& ti = plan.tensors[op.in[0]];
+            a.N = (ti.nfix ? ti.nfix : plan.max_batch) * ti.nmul;
+            a.M = a.N * a.Ho * a.Wo;
+            a.residual = op.in.size() > 1 ? reinterpret_cast<const void*>(1) : nullptr;   // presence only (alignment rules look at ld_res)
+            return a;
+        };
+        auto candidate = [&](const POp& op) {
+            if (op.kind != OP_CONV || !op.igemm || op.stem || op.from_deconv || !op.extra_in.empty()) return false;
+            ConvArgs two[2] = {args_at_max_batch(op), args_at_max_batch(op)};
+            return conv_igemm_group_supported(two, 2);
+        };
+        auto same_layer_shape = [&](const POp& x, const POp& y) {
+            const ConvArgs &a = x.conv, &b = y.conv;
+            return a.kh == b.kh && a.kw == b.kw && a.stride_h == b.stride_h && a.stride_w == b.stride_w && a.pad_h == b.pad_h && a.pad_w == b.pad_w &&
+                   a.Cout == b.Cout && a.act1 == b.act1 && a.act2 == b.act2 && a.alpha1 == b.alpha1 && a.alpha2 == b.alpha2 && x.in.size() == y.in.size();
+        };
+        // height = longest dependency path from an op down to a sink: sibling branches that end in the same consumer (the three levels'
+        // arms into the fused head op) put their corresponding layers at equal heights; a bottleneck of the neck that merely has the same
+        // shape as an arm's convolution sits higher and stays out of the arm's group
+        std::vector<int> height(n, 0);
+        for (int k = n - 1; k >= 0; --k)
+            for (int d : deps[k]) height[d] = std::max(height[d], height[k] + 1);
+        std::vector<int> group_of(n, -1);
+        std::vector<std::vector<int>> groups;
+        auto acyclic = [&]() {   // the dependency graph with every group contracted to one node
+            std::vector<int> node(n);
+            int nn = 0;
+            std::vector<int> gnode(groups.size(), -1);
+            for (int k = 0; k < n; ++k) {
+                if (group_of[k] >= 0) {
+                    if (gnode[group_of[k]] < 0) gnode[group_of[k]] = nn++;
+                    node[k] = gnode[group_of[k]];
+                } else {
+                    node[k] = nn++;
+                }
+            }
+            std::vector<std::vector<int>> succ(nn);
+            std::vector<int> indeg(nn, 0);
+            for (int k = 0; k < n; ++k)
+                for (int d : deps[k])
+                    if (node[d] != node[k]) {
+                        succ[node[d]].push_back(node[k]);
+                        ++indeg[node[k]];
+                    }
+            std::vector<int> q;
+            for (int v = 0; v < nn; ++v)
+                if (!indeg[v]) q.push_back(v);
+            size_t done = 0;
+            while (done < q.size()) {
+                const int v = q[done++];
+                for (int w : succ[v])
+                    if (--indeg[w] == 0) q.push_back(w);
+            }
+            return (int)q.size() == nn;
+        };
+        for (int k = 0; k < n; ++k) {
+            if (group_of[k] >= 0 || !candidate(plan.ops[k])) continue;
+            std::vector<int> mem = {k};
+            std::vector<ConvArgs> margs = {args_at_max_batch(plan.ops[k])};
+            for (int j = k + 1; j < n && (int)mem.size() < kMaxConvGroup; ++j) {
+                if (group_of[j] >= 0 || height[j] != height[k] || !candidate(plan.ops[j]) || !same_layer_shape(plan.ops[k], plan.ops[j])) continue;
+                bool indep = true;
+                for (int m : mem) indep = indep && !is_anc(m, j) && !is_anc(j, m);
+                if (!indep) continue;
+                margs.push_back(args_at_max_batch(plan.ops[j]));
+                // the operand path (t_rs: registers or LDS-DMA, the same bits either way) is a per-layer heuristic; a group runs on the
+                // path of its member with the most rows
+                int big = 0;
+                for (size_t q = 1; q < margs.size(); ++q)
+                    if (margs[q].M > margs[big].M) big = (int)q;
+                const int rs = margs[big].t_rs;
+                for (ConvArgs& ma : margs) ma.t_rs = rs;
+                if (!conv_igemm_group_supported(margs.data(), (int)margs.size())) {
+                    margs.pop_back();
+                    continue;
+                }
+                mem.push_back(j);
+            }
+            if (mem.size() < 2) continue;
+            const int gi = (int)groups.size();
+            groups.push_back(mem);
+            for (int m : mem) group_of[m] = gi;
+            if (!acyclic()) {   // (two groups each waiting for a member of the other): leave these convolutions alone
+                for (int m : mem) group_of[m] = -1;
+                groups.pop_back();
+            }
+        }
+        if (groups.empty()) return;
+        // new order: Kahn over the contracted graph, ready nodes taken in the order of their first member's old position
+        std::vector<int> node(n);
+        int nn = 0;
+        std::vector<int> gnode(groups.size(), -1), first_op;
+        for (int k = 0; k < n; ++k) {
+            if (group_of[k] >= 0 && gnode[group_of[k]] >= 0) {
+                node[k] = gnode[group_of[k]];
+                continue;
+            }
+            if (group_of[k] >= 0) gnode[group_of[k]] = nn;
+            node[k] = nn++;
+            first_op.push_back(k);
+        }
+        std::vector<std::vector<int>> succ(nn);
+        std::vector<int> indeg(nn, 0);
+        for (int k = 0; k < n; ++k)
+            for (int d : deps[k])
+                if (node[d] != node[k]) {
+                    succ[node[d]].push_back(node[k]);
+                    ++indeg[node[k]];
+                }
+        std::vector<char> emitted(nn, 0);
+        std::vector<POp> out;
+        out.reserve(nn);
+        for (int step = 0; step < nn; ++step) {
+            int pick = -1;
+            for (int v = 0; v < nn; ++v)
+                if (!emitted[v] && indeg[v] == 0) { pick = v; break; }   // nodes are numbered by first member: the lowest ready one
+            if (pick < 0) return;   // cannot happen (acyclic() held); keep the plan as it was
+            emitted[pick] = 1;
+            for (int w : succ[pick]) --indeg[w];
+            const int k0 = first_op[pick];
+            if (group_of[k0] < 0) {
+                out.push_back(plan.ops[k0]);
+                continue;
+            }
+            POp g;
+            g.kind = OP_CONV_GROUP;
+            g.dtype = plan.ops[k0].dtype;
+            g.conv = plan.ops[k0].conv;
+            int big = groups[group_of[k0]][0];
+            for (int m : groups[group_of[k0]])
+                if ((long)plan.ops[m].conv.Ho * plan.ops[m].conv.Wo * plan.tensors[plan.ops[m].in[0]].nmul >
+                    (long)plan.ops[big].conv.Ho * plan.ops[big].conv.Wo * plan.tensors[plan.ops[big].in[0]].nmul)
+                    big = m;
+            for (int m : groups[group_of[k0]]) {
+                POp mo = plan.ops[m];
+                mo.conv.t_rs = plan.ops[big].conv.t_rs;
+                g.group.push_back(mo);
+                g.name += (g.name.empty() ? "" : " + ") + mo.name;
+                for (int t : mo.in)
+                    if (std::find(g.in.begin(), g.in.end(), t) == g.in.end()) g.in.push_back(t);
+                g.out.push_back(mo.out[0]);
+                g.flops += mo.flops;
+                g.bytes += mo.bytes;
+            }
+            g.name = "[group of " + std::to_string(g.group.size()) + "] " + g.name;
+            out.push_back(std::move(g));
+        }
+        plan.ops = std::move(out);
+    }
+
     // Upsample -> Concat -> Conv1x1 without the upsampled tensor (YOLOv8 head: model.cpp:130-160, twice per network).  The nearest 2x
     // resize writes the first channel slice of a concat buffer whose only reader is a 1x1 stride-1 convolution: that convolution's
     // A-gather can fetch those channels from the half-resolution tensor at (h >> 1, w >> 1) itself (ConvArgs::up_in).  The resize launch,
@@ -1554,6 +1761,7 @@ struct Lowerer {
             plan.ops.erase(plan.ops.begin() + k + 1, plan.ops.begin() + k + 3);
         }
         fuse_conv_chains();
+        group_convs();
         // 5. op dependencies at (storage, channel/element range) granularity: RAW, WAR and WAW
         const int nops = (int)plan.ops.size();
         struct Access { int storage; long lo, hi; int op; bool write; };
@@ -1749,7 +1957,13 @@ bool pack_weights(const Network& net, Plan* plan) {
         memcpy(blob.data() + off, l.w0.data(), l.w0.size() * 4);
         plan->storages[t.storage].offset = off;
     }
+    std::vector<POp*> every;   // the members of a conv group are packed like the convolutions they are
     for (auto& op : plan->ops) {
+        for (auto& m : op.group) every.push_back(&m);
+        every.push_back(&op);
+    }
+    for (POp* pop : every) {
+        POp& op = *pop;
         if (op.kind == OP_CONV || op.kind == OP_DECONV) {
             const LayerDef& l = net.layers[op.src_layer];
             const ConvArgs& a = op.conv;
@@ -1843,6 +2057,9 @@ bool pack_weights(const Network& net, Plan* plan) {
                 memcpy(blob.data() + st.b_off, bias.data(), bias.size() * 4);
                 op.bytes += (double)halfs * 2;
             }
+        } else if (op.kind == OP_CONV_GROUP) {   // members were packed just before (they precede their group in `every`)
+            op.bytes = 0;
+            for (const POp& m : op.group) op.bytes += m.bytes;
         } else if (op.kind == OP_YOLO_HEAD) {
             const LayerDef& l = net.layers[op.src_layer];
             op.w_off = reserve(16 * 4);
@@ -1882,6 +2099,8 @@ std::string Plan::describe_json() const {
             ++n_conv;
             n_igemm += op.igemm ? 1 : 0;
         }
+        n_conv += (int)op.group.size();
+        n_igemm += (int)op.group.size();
     }
     o << "{\"fp16\":" << (fp16 ? "true" : "false") << ",\"max_batch\":" << max_batch << ",\"arena_bytes\":" << arena_bytes
       << ",\"weight_bytes\":" << weight_bytes << ",\"n_lanes\":" << num_lanes << ",\"n_ops\":" << ops.size() << ",\"n_conv\":" << n_conv
@@ -1892,7 +2111,7 @@ std::string Plan::describe_json() const {
         o << (k ? "," : "") << "{\"kind\":\"" << op_kind_name(op.kind) << "\",\"name\":\"";
         for (char c : op.name) o << ((c == '"' || c == '\\' || (unsigned char)c < 0x20) ? ' ' : c);
         o << "\",\"flops\":" << op.flops << ",\"bytes\":" << op.bytes;
-        if (op.kind == OP_CONV || op.kind == OP_DECONV) {
+        auto conv_fields = [&](const POp& op) {
             const ConvArgs& a = op.conv;
             o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << (a.in_i8 ? 2 * a.Cin : a.Cin) << ",\"cout\":" << a.Cout
               << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
@@ -1901,6 +2120,21 @@ std::string Plan::describe_json() const {
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
               << ",\"ld_out\":" << a.ld_out << ",\"i8\":[" << a.in_i8 << "," << a.out_i8 << "," << a.res_i8 << "],\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
               << (op.stem ? 0 : tensors[op.in[0]].nfix);
+        };
+        if (op.kind == OP_CONV || op.kind == OP_DECONV) conv_fields(op);
+        if (op.kind == OP_CONV_GROUP) {
+            o << ",\"members\":[";
+            for (size_t j = 0; j < op.group.size(); ++j) {
+                const POp& m = op.group[j];
+                o << (j ? "," : "") << "{\"name\":\"";
+                for (char c : m.name) o << ((c == '"' || c == '\\' || (unsigned char)c < 0x20) ? ' ' : c);
+                o << "\",\"flops\":" << m.flops << ",\"bytes\":" << m.bytes;
+                conv_fields(m);
+                o << ",\"in\":[";
+                for (size_t q = 0; q < m.in.size(); ++q) o << (q ? "," : "") << m.in[q];
+                o << "],\"out\":[" << m.out[0] << "]}";
+            }
+            o << "]";
         }
         if (op.kind == OP_CONV_CHAIN) {
             const ConvArgs& a = op.conv;

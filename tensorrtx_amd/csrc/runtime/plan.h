@@ -45,6 +45,7 @@ enum OpKind : int {
     OP_D2S,           // depth-to-space: [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c] (second half of a kernel == stride deconvolution)
     OP_ROI_ALIGN,     // detectron2 ROIAlign on the NHWC feature map, NHWC [P][res][res][C] out (fused form of the "RoiAlign" plugin)
     OP_CONV_CHAIN,    // two or three stride-1 convolutions in one launch, intermediates in LDS (kernels/conv_chain.hip)
+    OP_CONV_GROUP,    // 2..4 INDEPENDENT implicit-GEMM convolutions of one kernel instantiation in one launch (POp::group; round 4)
 };
 const char* op_kind_name(int k);
 
@@ -102,6 +103,9 @@ struct POp {
         size_t w_off = 0, b_off = 0;
     };
     std::vector<ChainStage> chain;
+    // OP_CONV_GROUP: the member convolutions, each a complete OP_CONV record (its own in / out tensors, ConvArgs, weights); the group's
+    // in / out are the unions, so dependencies, lanes and buffer lifetimes see one op
+    std::vector<POp> group;
     int src_layer = -1;        // network layer holding the kernel weights
     int scale_layer = -1;      // folded IScaleLayer (BatchNorm) or -1
     size_t w_off = 0, b_off = 0, s_off = 0;  // byte offsets into the device weight blob

@@ -456,3 +456,47 @@ def test_conv_bn_mish_engine_matches_the_reference_expression(gpu, fp16, fused):
     err = (got - ref).abs().max().item()
     assert err < (8e-3 if fp16 else 1e-4), err
     assert (ref.abs() > 1).any() and (ref < 0).any()   # both tails of the activation are exercised
+
+
+def test_grouped_sibling_convolutions_return_the_bits_of_one_launch_each(gpu):
+    """lower.cpp group_convs / conv_igemm_group_f16_kernel: the detect head's 18 convolutions in 6 launches of 3 sibling layers each - every
+    member computed exactly as its own launch computes it.  Both engines on the static kernel choice without the wave-split-K variant (a
+    different summation order; TRTX_CONV_NOWSK is read once per process, hence the subprocess), same input: every head tensor and the
+    decode buffer equal bit for bit; and the grouped plan really has the 6 groups."""
+    import subprocess
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from tensorrtx_amd import engine, synth
+from util import synth_wts
+import os
+path, _ = synth_wts("yolov8n")
+B, S = 8, 640
+x = torch.from_numpy(synth.images(B, S, S, seed=31)).cuda()
+outs = []
+for grp in ("1", "0"):
+    os.environ["TRTX_GROUP_CONVS"] = grp
+    plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1, aux_streams=0)
+    kinds = [o["kind"] for o in engine.describe_plan(plan, lowered=True)["ops"]]
+    assert kinds.count("conv_group") == (6 if grp == "1" else 0), kinds
+    e = engine.Engine(plan)
+    bufs = [x] + [torch.zeros(B * int(np.prod(e.dims[i])), dtype=torch.float32, device="cuda") for i in range(1, e.nb_bindings)]
+    e.enqueue(B, bufs)
+    torch.cuda.synchronize()
+    outs.append({e.names[i]: bufs[i].cpu() for i in range(1, e.nb_bindings)})
+    e.close()
+for k in outs[0]:
+    a, b = outs[0][k], outs[1][k]
+    if k == "output":
+        a, b = a.reshape(B, -1), b.reshape(B, -1)
+        assert torch.equal(a[:, 0], b[:, 0])
+        for i in range(B):
+            m = 1 + int(a[i, 0]) * 90
+            assert torch.equal(a[i, :m], b[i, :m]), k
+    else:
+        assert torch.equal(a, b), k
+print("GROUPED_EQUALS_SINGLE", sorted(outs[0]))
+'''
+    env = dict(os.environ, TRTX_TUNE="0", TRTX_CONV_NOWSK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "GROUPED_EQUALS_SINGLE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -127,6 +127,18 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     # layer by layer (the default): Appendix C.1's 63 convolutions = 1 stem (fp32 NCHW in) + 62 MFMA implicit-GEMM; the DFL
     # 1x1 convs are absorbed by the fused head kernel
     monkeypatch.delenv("TRTX_FUSE_CHAINS", raising=False)
+    # round 4: the detect head's 18 convolutions - six chains of depth three over three levels (model.cpp:188-251) - go out as 6 grouped
+    # launches of 3 sibling layers each (lower.cpp group_convs): 65 -> 53 ops, 62 -> 50 MFMA conv launches
+    grouped = engine.describe_plan(plan, lowered=True)
+    groups = [o for o in grouped["ops"] if o["kind"] == "conv_group"]
+    assert len(grouped["ops"]) == 53 and len(groups) == 6 and all(len(g["members"]) == 3 for g in groups)
+    assert sorted((m["cout"], m["k"][0]) for g in groups for m in g["members"]) == sorted([(64, 3)] * 6 + [(64, 1)] * 3 + [(80, 3)] * 6 + [(80, 1)] * 3)
+    assert all(sorted(m["hw_in"][0] for m in g["members"]) == [20, 40, 80] for g in groups)                 # one member per pyramid level
+    assert all(len({(m["cout"], m["k"][0], m["act1"]) for m in g["members"]}) == 1 for g in groups)         # the same layer of sibling branches
+    assert sum(o["kind"] == "conv" for o in grouped["ops"]) + 18 == 63 and grouped["n_conv"] == 63 and grouped["n_igemm"] == 62
+    monkeypatch.setenv("TRTX_GROUP_CONVS", "0")    # the rest of this test looks at the plan one launch per convolution
+    assert abs(engine.describe_plan(plan, lowered=True)["flops_per_sample"] - grouped["flops_per_sample"]) < 1.0
+    assert abs(engine.describe_plan(plan, lowered=True)["bytes_per_sample"] - grouped["bytes_per_sample"]) < 1.0
     monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", "0")
     unfolded = engine.describe_plan(plan, lowered=True)
     assert [o["kind"] for o in unfolded["ops"]].count("resize") == 2 and len(unfolded["ops"]) == 67
@@ -202,6 +214,7 @@ def test_retinaface_builder_matches_pytorch_restatement():
 
 def test_retinaface_lowering_at_config4_size(monkeypatch):
     monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
+    monkeypatch.setenv("TRTX_GROUP_CONVS", "0")
     path, _ = synth_wts("retinaface_r50")
     plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280)
     low = engine.describe_plan(plan, lowered=True)
@@ -410,10 +423,14 @@ def test_yolov8_task_graphs_build_and_lower_on_the_host(task, name, nc, extra):
         engine.build_plan("yolov8n", path, batch=1, h=128, w=128, task=7)
 
 
-def test_max_aux_streams_travels_in_the_plan_and_bounds_the_lanes():
+def test_max_aux_streams_travels_in_the_plan_and_bounds_the_lanes(monkeypatch):
     """IBuilderConfig::setMaxAuxStreams (TensorRT >= 8.6): stored in the plan (format 3), lanes = 1 + aux streams."""
     from util import synth_wts
     path, _ = synth_wts("yolov8n")
+    for aux, lanes in ((None, 2), (0, 1), (1, 2), (3, 2)):   # grouped sibling layers (round 4) leave two independent branches: the cv2 and cv3 arms
+        kw = {} if aux is None else dict(aux_streams=aux)
+        assert engine.describe_plan(engine.build_plan("yolov8n", path, batch=2, h=128, w=128, fp16=1, **kw), lowered=True)["n_lanes"] == lanes
+    monkeypatch.setenv("TRTX_GROUP_CONVS", "0")
     for aux, lanes in ((None, 4), (0, 1), (1, 2), (3, 4)):
         kw = {} if aux is None else dict(aux_streams=aux)
         plan = engine.build_plan("yolov8n", path, batch=2, h=128, w=128, fp16=1, **kw)
