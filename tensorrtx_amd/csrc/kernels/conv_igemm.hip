@@ -595,24 +595,29 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
 // (same column-tile width, k-step, operand path): a workgroup looks its problem up in a prefix table held in the kernel arguments and then
 // is exactly a workgroup of that problem's own launch - same tile, same K order, same bits.  The small levels' tiles fill the CUs the
 // large level's tail leaves idle, and 18 launches become 6.
+// Tile order (measured, round 4: one XCD-contiguous range over the concatenated tiles gave the last XCD all of the small levels' tiles -
+// the ones with the 4x longer K - and the cv2.x.0 group ran 108 us against 78 for its three members one after the other): EVERY problem is
+// split into eight XCD chunks of its own (its tiles keep their L2 locality), an XCD walks its chunk of problem 0, then of problem 1, ...,
+// and the host orders the problems by falling k-steps per tile, so that the long tiles start first and the short ones fill the tail.
 struct ConvGroupArgs {
     int n;
-    int tile_start[kMaxConvGroup + 1];   // prefix sums of the problems' tile counts (XCD-ordered global tile index -> problem)
+    int slot_start[kMaxConvGroup + 1];   // per XCD: prefix sums of the problems' chunk sizes (slot -> problem)
+    int chunk[kMaxConvGroup];            // tiles of problem p per XCD: ceil(tiles[p] / 8)
+    int tiles[kMaxConvGroup];
     int tiles_n[kMaxConvGroup];
     unsigned in_bytes[kMaxConvGroup], w_bytes[kMaxConvGroup];
     ConvArgs p[kMaxConvGroup];
 };
 template <int NFRAG, int BKT, bool RS, bool ONE>
-__global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGroupArgs g, int xcd_chunk, int dbg_flags) {
+__global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGroupArgs g, int dbg_flags) {
     __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<NFRAG, BKT, 2, 1, 0, 4, RS>()];
-    int tile = blockIdx.x;
-    tile = (tile & 7) * xcd_chunk + (tile >> 3);
-    if (tile >= g.tile_start[g.n]) return;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int pid = 0;
 #pragma unroll
-    for (int k = 1; k < kMaxConvGroup; ++k) pid += (k < g.n && tile >= g.tile_start[k]) ? 1 : 0;
+    for (int k = 1; k < kMaxConvGroup; ++k) pid += (k < g.n && slot >= g.slot_start[k]) ? 1 : 0;
     pid = __builtin_amdgcn_readfirstlane(pid);
-    const int local = tile - g.tile_start[pid];
+    const int local = xcd * g.chunk[pid] + (slot - g.slot_start[pid]);
+    if (local >= g.tiles[pid]) return;
     const int tn = g.tiles_n[pid];
     const int m0 = (local / tn) * 128;
     const int n0 = (local % tn) * (16 * NFRAG);
@@ -1384,10 +1389,9 @@ bool group_member_ok(const ConvArgs& a) {
            (a.bm == 0 || a.bm == 128) && a.t_r3 == 0 && a.t_wsk != 2 && (double)a.N * a.H * a.W * a.ld_in * 2.0 < 2.0e9;
 }
 template <int NFRAG, bool RS, bool ONE>
-void launch_group(const ConvGroupArgs& g, int total, hipStream_t s) {
+void launch_group(const ConvGroupArgs& g, hipStream_t s) {
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
-    const int chunk = (total + 7) / 8;
-    TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE>), dim3(chunk * 8), dim3(256), 0, s, g, chunk, dbg);
+    TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g, dbg);
 }
 }  // namespace
 
@@ -1405,28 +1409,38 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     if (!conv_igemm_group_supported(a, n)) return TRTX_ERR_UNSUPPORTED;
     ConvGroupArgs g{};
     g.n = n;
-    int total = 0;
+    int order[kMaxConvGroup];   // falling k-steps per tile (ties: more rows first)
+    for (int k = 0; k < n; ++k) order[k] = k;
+    std::sort(order, order + n, [&](int x, int y) {
+        if (a[x].Kpad != a[y].Kpad) return a[x].Kpad > a[y].Kpad;
+        const long mx = (long)a[x].N * a[x].Ho * a[x].Wo, my = (long)a[y].N * a[y].Ho * a[y].Wo;
+        return mx != my ? mx > my : x < y;
+    });
+    int slots = 0;
     for (int k = 0; k < n; ++k) {
-        g.p[k] = a[k];
-        g.p[k].M = a[k].N * a[k].Ho * a[k].Wo;
-        g.tile_start[k] = total;
-        g.tiles_n[k] = a[k].Cout_pad / a[k].bn;
-        total += ((g.p[k].M + 127) / 128) * g.tiles_n[k];
-        g.in_bytes[k] = (unsigned)((((size_t)a[k].N * a[k].H * a[k].W - 1) * a[k].ld_in + a[k].Cin) * 2);
-        g.w_bytes[k] = (unsigned)((size_t)a[k].Cout_pad * a[k].Kpad * 2);
+        const ConvArgs& ak = a[order[k]];
+        g.p[k] = ak;
+        g.p[k].M = ak.N * ak.Ho * ak.Wo;
+        g.tiles_n[k] = ak.Cout_pad / ak.bn;
+        g.tiles[k] = ((g.p[k].M + 127) / 128) * g.tiles_n[k];
+        g.chunk[k] = (g.tiles[k] + 7) / 8;
+        g.slot_start[k] = slots;
+        slots += g.chunk[k];
+        g.in_bytes[k] = (unsigned)((((size_t)ak.N * ak.H * ak.W - 1) * ak.ld_in + ak.Cin) * 2);
+        g.w_bytes[k] = (unsigned)((size_t)ak.Cout_pad * ak.Kpad * 2);
     }
-    for (int k = n; k <= kMaxConvGroup; ++k) g.tile_start[k] = total;
+    for (int k = n; k <= kMaxConvGroup; ++k) g.slot_start[k] = slots;
     static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // the same A/B switch as the single launches
     const bool rs = rs_env >= 0 ? rs_env != 0 : a[0].t_rs != 0;
     static const bool one_off = getenv("TRTX_CONV_NOONE") != nullptr;
     const bool one = !one_off && plain_gemm(a[0]);
     const int nf = a[0].bn / 16;
     if (nf == 4) {
-        if (one) rs ? launch_group<4, true, true>(g, total, s) : launch_group<4, false, true>(g, total, s);
-        else rs ? launch_group<4, true, false>(g, total, s) : launch_group<4, false, false>(g, total, s);
+        if (one) rs ? launch_group<4, true, true>(g, s) : launch_group<4, false, true>(g, s);
+        else rs ? launch_group<4, true, false>(g, s) : launch_group<4, false, false>(g, s);
     } else {
-        if (one) rs ? launch_group<5, true, true>(g, total, s) : launch_group<5, false, true>(g, total, s);
-        else rs ? launch_group<5, true, false>(g, total, s) : launch_group<5, false, false>(g, total, s);
+        if (one) rs ? launch_group<5, true, true>(g, s) : launch_group<5, false, true>(g, s);
+        else rs ? launch_group<5, true, false>(g, s) : launch_group<5, false, false>(g, s);
     }
     return check_launch("conv_igemm_group_f16");
 }

@@ -252,8 +252,3 @@ extern "C" int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream) {
     return conv_chain_poison_lds(static_cast<unsigned*>(device_word), static_cast<hipStream_t>(stream));
 }
 
-// mish_kernel of the reference's Mish_TRT plugin (yolov4/mish.cu:113-141) over n fp32 values
-extern "C" int32_t trtx_mish(const float* in, float* out, size_t n, trtx_stream_t stream) {
-    if ((!in || !out) && n) return TRTX_ERR_INVALID;
-    return trtx::lin_activation(in, out, trtx::ACT_MISH, 0.f, (long)n, static_cast<hipStream_t>(stream));
-}
