@@ -160,8 +160,23 @@ __device__ __forceinline__ void frame_pixel(const StemFrame& im, const AxisSampl
     b = c0 / 255.0f;
 }
 
+// what a workgroup keeps in registers for all of its tiles: the weights as MFMA A fragments, the patch offsets of its taps, its bias
 template <int NFRAG, int KS>
-__device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g, const float* s_patch, int n, int tx0, int ty0, int shift);
+struct StemRegs {
+    half8 wf[NFRAG][KS];
+    int l_off[KS][8];   // float index inside the patch of tap (c, r, q) relative to the pixel's top-left corner
+    float bias4[NFRAG][4];
+};
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_setup(const ConvArgs& p, const StemGeom& g, StemRegs<NFRAG, KS>& R);
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_compute(const ConvArgs& p, const StemGeom& g, const StemRegs<NFRAG, KS>& R, const float* s_patch, int n, int tx0, int ty0, int shift);
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g, const float* s_patch, int n, int tx0, int ty0, int shift) {
+    StemRegs<NFRAG, KS> R;
+    stem_setup<NFRAG, KS>(p, g, R);
+    stem_compute<NFRAG, KS>(p, g, R, s_patch, n, tx0, ty0, shift);
+}
 
 template <int NFRAG, int KS>
 __global__ __launch_bounds__(256) void conv_stem_frames_kernel(const ConvArgs p, const StemGeom g, const FramePack fr) {
@@ -199,13 +214,18 @@ __global__ __launch_bounds__(256) void conv_stem_frames_kernel(const ConvArgs p,
     stem_stage2<NFRAG, KS>(p, g, s_patch, n, tx0, ty0, shift);
 }
 
+// PERSISTENT (round 4): a workgroup sets its weights / tap tables up once and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the grid is
+// what fits on the chip at once (launch_lds).  RetinaFace's 1280 x 1280 batch 8 is 12 800 tiles: the 160-load set-up is paid 512 times, not 12 800.
 template <int NFRAG, int KS>
-__global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, const StemGeom g, unsigned in_bytes) {
+__global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, const StemGeom g, unsigned in_bytes, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float s_patch[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
+    StemRegs<NFRAG, KS> R;
+    stem_setup<NFRAG, KS>(p, g, R);
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     // tile coordinates
-    int t = blockIdx.x;
+    int t = tile;
     const int tx0 = (t % g.tiles_x) * kStemTW;
     t /= g.tiles_x;
     const int ty0 = (t % g.tiles_y) * kStemTH;
@@ -237,22 +257,42 @@ __global__ __launch_bounds__(256) void conv_stem_lds_kernel(const ConvArgs p, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stem_stage2<NFRAG, KS>(p, g, s_patch, n, tx0, ty0, shift);
+    if (p.W & 3) {
+        // Ragged width (Faster R-CNN's 1333): the 16-byte chunk that straddles the end of an image row was range-checked away whole
+        // above; its 1..3 real pixels are fetched here, one patch row per thread (right-edge tiles only have any)
+        const int cpr = g.PCA / 4, rows = p.Cin * g.PR, wtail = p.W & ~3;
+        const int cq = (wtail - al_start) >> 2;
+        if (cq >= 0 && cq < cpr && wtail >= al_start) {
+            const float* __restrict__ src = static_cast<const float*>(p.in);
+            for (int rrow = tid; rrow < rows; rrow += 256) {
+                const int c = rrow / g.PR, pr = rrow - c * g.PR, hi = hi_start + pr;
+                if ((unsigned)hi >= (unsigned)p.H) continue;
+                const size_t base = (((size_t)n * p.Cin + c) * p.H + hi) * p.W;
+                for (int e = 0; e < 4; ++e)
+                    if (wtail + e < p.W) s_patch[((size_t)rrow * cpr + cq) * 4 + e] = src[base + wtail + e];
+            }
+        }
+        __syncthreads();
+    }
+    stem_compute<NFRAG, KS>(p, g, R, s_patch, n, tx0, ty0, shift);
+    __syncthreads();   // every wave is done with the patch before the next tile's DMA overwrites it
+    }
 }
 
-// stage 2 of both stem kernels: the patch is in LDS, wave w owns tile row w
+// weights, tap tables and bias of a lane.  EVERY load is issued unconditionally from a clamped index and masked afterwards: written as
+// `cond ? w[i] : 0` the compiler put each of the 160 loads of the 7x7 stem (176 with the bias) into its own exec-masked branch with an
+// s_waitcnt vmcnt(0) behind it - 176 dependent round trips of ~700 cycles per workgroup, which is where conv_stem_lds_kernel<4, 5> spent its
+// 148 us on ResNet-50's 224 x 224 batch 32 (12x its byte floor; profiles/r04_kernel_stats_c2_1ctx_lanes1.txt) and 888 us on RetinaFace's 1280 x 1280.
 template <int NFRAG, int KS>
-__device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g, const float* s_patch, int n, int tx0, int ty0, int shift) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+__device__ __forceinline__ void stem_setup(const ConvArgs& p, const StemGeom& g, StemRegs<NFRAG, KS>& R) {
+    const int lane = threadIdx.x & 63;
     const int khw = p.kh * p.kw;
     const int K = khw * p.Cin;
-    // ---- weights and tap tables
     const float* __restrict__ w = static_cast<const float*>(p.wgt);  // [tap = (c*kh + r)*kw + q][Cout]
     const int kq = (lane >> 4) * 8;
-    half8 wf[NFRAG][KS];
-    int l_off[KS][8];  // float index inside the patch of tap (c, r, q) relative to the pixel's top-left corner
+    auto& wf = R.wf;
+    auto& l_off = R.l_off;
+    auto& bias4 = R.bias4;
     const float inv_khw = 1.0f / (float)khw, inv_kw = 1.0f / (float)p.kw;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -266,21 +306,35 @@ __device__ __forceinline__ void stem_stage2(const ConvArgs& p, const StemGeom& g
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j) {
                 const int co = j * 16 + (lane & 15);
-                wf[j][ks][e] = (k < K && co < p.Cout) ? (_Float16)w[(size_t)k * p.Cout + co] : (_Float16)0.f;
+                const float wv = w[(size_t)(k < K ? k : K - 1) * p.Cout + (co < p.Cout ? co : p.Cout - 1)];
+                wf[j][ks][e] = (k < K && co < p.Cout) ? (_Float16)wv : (_Float16)0.f;
             }
         }
     const int ch4 = (lane >> 4) * 4;
-    float bias4[NFRAG][4];
+    const float* __restrict__ bsrc = p.bias ? p.bias : w;   // (wave-uniform; without a bias the loaded values are masked away)
 #pragma unroll
     for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = j * 16 + ch4 + e;
-            bias4[j][e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+            const float bv = bsrc[co < p.Cout ? co : p.Cout - 1];
+            bias4[j][e] = (p.bias && co < p.Cout) ? bv : 0.f;
         }
-    // ---- stage 2: wave w owns tile row w (64 pixels = 4 groups)
+}
+
+// stage 2 of both stem kernels: the patch is in LDS, wave w owns tile row w (64 pixels = 4 groups)
+template <int NFRAG, int KS>
+__device__ __forceinline__ void stem_compute(const ConvArgs& p, const StemGeom& g, const StemRegs<NFRAG, KS>& R, const float* s_patch, int n, int tx0, int ty0,
+                                             int shift) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int ch4 = (lane >> 4) * 4;
+    const auto& wf = R.wf;
+    const auto& l_off = R.l_off;
+    const auto& bias4 = R.bias4;
     _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
-#pragma unroll
+#pragma nounroll   // (unrolled, the <4, 5> instantiation is ~100 KB of code against a 64 KB instruction cache, walked once per tile)
     for (int gi = 0; gi < 4; ++gi) {
         const int ty = wave, tx = gi * 16 + (lane & 15);
         const int ho = ty0 + ty, wo = tx0 + tx;
@@ -334,8 +388,19 @@ void launch_lds(const ConvArgs& a, hipStream_t s) {
     g.chunks = a.Cin * g.PR * g.PCA / 4;
     const size_t lds = (size_t)((g.chunks + 255) / 256 * 256) * 16;  // whole 1 KiB DMA rows
     const unsigned in_bytes = (unsigned)((size_t)a.N * a.Cin * a.H * a.W * 4);
-    hipLaunchKernelGGL((conv_stem_lds_kernel<NFRAG, KS>), dim3((unsigned)(a.N * g.tiles_x * g.tiles_y)), dim3(256), lds, s, a, g,
-                       in_bytes);
+    const int total = a.N * g.tiles_x * g.tiles_y;
+    // as many workgroups as are resident at once (registers and this LDS size decide), each walking total / grid tiles
+    static thread_local int resident[2] = {0, 0};   // [0]: LDS bytes the figure was computed for, [1]: workgroups on the chip
+    if (resident[0] != (int)lds || resident[1] <= 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_stem_lds_kernel<NFRAG, KS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        resident[0] = (int)lds;
+        resident[1] = per_cu * cus;
+    }
+    const int grid = total < resident[1] ? total : resident[1];
+    hipLaunchKernelGGL((conv_stem_lds_kernel<NFRAG, KS>), dim3((unsigned)grid), dim3(256), lds, s, a, g, in_bytes, total);
 }
 
 template <int NFRAG, int KS>
@@ -379,7 +444,7 @@ int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s) {
     const int K = a.kh * a.kw * a.Cin;
     static const bool no_mfma = getenv("TRTX_STEM_FMA") != nullptr;  // A/B switch for the micro-benchmarks
     const size_t patch = (size_t)a.Cin * ((kStemTH - 1) * a.stride_h + a.kh) * ((kStemTW - 1) * a.stride_w + a.kw + 9) * 4;
-    if (!no_mfma && a.Cout % 16 == 0 && K <= 160 && a.W % 4 == 0 && patch <= 60 * 1024 &&
+    if (!no_mfma && a.Cout % 16 == 0 && K <= 160 && patch <= 60 * 1024 &&
         (size_t)a.N * a.Cin * a.H * a.W * 4 < 2000000000u && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0) {
         const int ks = K <= 32 ? 1 : 5;
         bool done = true;

@@ -500,3 +500,29 @@ print("GROUPED_EQUALS_SINGLE", sorted(outs[0]))
     env = dict(os.environ, TRTX_TUNE="0", TRTX_CONV_NOWSK="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "GROUPED_EQUALS_SINGLE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(3, 64, 7, 2, (45, 161)), (3, 64, 7, 2, (37, 130)), (3, 16, 3, 2, (33, 67)), (1, 32, 3, 1, (20, 135)), (3, 64, 7, 2, (40, 128))])
+def test_stem_kernel_on_ragged_widths(gpu, cin, cout, k, stride, hw):
+    """conv_stem_lds_kernel (round 4: persistent, unconditional weight loads, widths that are not a multiple of 4 - Faster R-CNN's 1333 -
+    through the 16-byte DMA rows + a scalar fix-up of the chunk that straddles the row end): a first layer on an fp32 NCHW input against
+    PyTorch on fp16-rounded operands (the kernel feeds fp16 MFMA operands, fp32 accumulate; one fp16 rounding of the output)."""
+    import torch.nn.functional as F
+    from tensorrtx_amd import builder
+    g = torch.Generator().manual_seed(cin * 1000 + cout + hw[1])
+    x = torch.rand(3, cin, *hw, generator=g) * 2 - 1
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    net = builder.Network(max_batch=3, fp16=True)
+    t = net.input("data", (cin,) + hw)
+    l = net.conv(t, w.numpy(), b.numpy(), stride=stride, padding=k // 2)
+    net.mark_output(net.out(net.activation(net.out(l), "relu")), "out")
+    plan = net.build()
+    net.close()
+    low = engine.describe_plan(plan, lowered=True)
+    assert [o for o in low["ops"] if o["kind"] == "conv"][0]["stem"]
+    ref = F.relu(F.conv2d(x.half().float(), w.half().float(), b, stride=stride, padding=k // 2))
+    got = _run(plan, {"data": x.numpy()}, 3, gpu)["out"].reshape(ref.shape)
+    err = (got - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err      # half an fp16 ulp of the output + the summation order
+    assert (got[..., -1] - ref[..., -1]).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())   # the last output column reads the ragged tail
