@@ -118,12 +118,16 @@ int32_t sort_keys(uint64_t* keys, int batch, int n_pad, hipStream_t s) {
 // (11 + 11 + 10 bits, histograms in LDS, the scores are read three times from L2), then compacts the selected elements IN INDEX
 // ORDER (ties of the pivot score go to the lowest indices, which is what the stable descending sort would keep), emitting the
 // same 64-bit (key, index) words as make_keys_kernel.  Only those <= top_n keys (padded to a power of two) are sorted.
+// Round 4 (284 us -> see profiles/r04_*): the bin walk that finds the pivot digit is a parallel scan (was thread 0 over 2048 bins, ~17 us a
+// pass), the histogram passes read four scores per lane and iteration, and the compaction has no workgroup barrier inside its loop: every
+// wave owns a CONTIGUOUS index range, counts its selected / tied elements, one barrier turns the 16 counts into bases, then each wave writes
+// its range with ballot / popcount offsets of its own.  Same selection, same order (index order, ties of the pivot to the lowest indices).
 __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, int n, int top_n, int n_sel_pad,
                                                            uint64_t* __restrict__ sel_keys) {
     __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_wsum[16];
     __shared__ unsigned s_prefix, s_remaining;
     __shared__ int s_wsel[16], s_weq[16];
-    __shared__ int s_base_sel, s_base_eq;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* sc = scores + (size_t)b * n;
     if (tid == 0) {
@@ -132,72 +136,96 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
     }
     const int shifts[3] = {21, 10, 0};
     const int bits[3] = {11, 11, 10};
+    const bool vec = (((uintptr_t)sc) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
     for (int pass = 0; pass < 3; ++pass) {
         for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
         const int hi_shift = pass == 0 ? 32 : shifts[pass - 1];
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned key = ~ord_f32(sc[i]);
-            if (pass > 0 && (key >> hi_shift) != prefix) continue;
-            atomicAdd(&s_hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1u)], 1u);
+        const unsigned dmask = (1u << bits[pass]) - 1u;
+        auto count = [&](float v) {
+            const unsigned key = ~ord_f32(v);
+            if (pass > 0 && (key >> hi_shift) != prefix) return;
+            atomicAdd(&s_hist[(key >> shifts[pass]) & dmask], 1u);
+        };
+        for (int i = tid; i < n4; i += 1024) {
+            const float4 v = reinterpret_cast<const float4*>(sc)[i];
+            count(v.x); count(v.y); count(v.z); count(v.w);
         }
+        for (int i = n4 * 4 + tid; i < n; i += 1024) count(sc[i]);
         __syncthreads();
-        if (tid == 0) {
-            unsigned rem = s_remaining, cum = 0;
-            int bin = 0;
-            const int nb = 1 << bits[pass];
-            for (; bin < nb; ++bin) {
-                if (cum + s_hist[bin] >= rem) break;
-                cum += s_hist[bin];
+        // the digit: the first bin at which the running count reaches `remaining`.  Thread t owns bins 2t, 2t + 1.
+        {
+            const unsigned rem = s_remaining;
+            const unsigned h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+            unsigned incl = h0 + h1;                      // inclusive scan over the threads' pair sums: wave, then across waves
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
             }
-            s_prefix = (prefix << bits[pass]) | (unsigned)bin;
-            s_remaining = rem - cum;  // how many of the elements inside this bin are still to be taken
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            unsigned before = 0;
+            for (int w = 0; w < wave; ++w) before += s_wsum[w];
+            const unsigned excl = before + incl - (h0 + h1);   // count in the bins below 2t
+            // exactly one bin satisfies excl_bin < rem <= excl_bin + hist[bin] (rem >= 1, the total count >= rem)
+            int bin = -1;
+            unsigned cum = 0;
+            if (excl < rem && rem <= excl + h0) { bin = 2 * tid; cum = excl; }
+            else if (excl + h0 < rem && rem <= excl + h0 + h1) { bin = 2 * tid + 1; cum = excl + h0; }
+            if (bin >= 0) {
+                s_prefix = (prefix << bits[pass]) | (unsigned)bin;
+                s_remaining = rem - cum;  // how many of the elements inside this bin are still to be taken
+            }
         }
         __syncthreads();
     }
     const unsigned pivot = s_prefix;      // the top_n-th smallest key (32-bit score part)
     const int take_eq = (int)s_remaining;  // elements with key == pivot to keep, lowest indices first
-    if (tid == 0) {
-        s_base_sel = 0;
-        s_base_eq = 0;
+    uint64_t* dst = sel_keys + (size_t)b * n_sel_pad;
+    // wave w owns indices [w * per, (w + 1) * per), per a multiple of 64
+    const int per = ((n + 15) / 16 + 63) / 64 * 64;
+    const int lo = wave * per, hi = lo + per < n ? lo + per : n;
+    int c_sel = 0, c_eq = 0;   // wave-uniform
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned key = 0xffffffffu;
+        if (i < hi) key = ~ord_f32(sc[i]);
+        c_sel += __popcll(__ballot(i < hi && key < pivot));
+        c_eq += __popcll(__ballot(i < hi && key == pivot));
+    }
+    if (lane == 0) {
+        s_wsel[wave] = c_sel;
+        s_weq[wave] = c_eq;
     }
     __syncthreads();
-    uint64_t* dst = sel_keys + (size_t)b * n_sel_pad;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
+    int base_eq = 0, base_less = 0;
+    for (int w = 0; w < wave; ++w) {
+        base_eq += s_weq[w];
+        base_less += s_wsel[w];
+    }
+    // output position of an element = (selected elements before it): less-than-pivot ones before it + tied ones before it that are taken
+    int run_less = base_less, run_eq = base_eq;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
         unsigned key = 0xffffffffu;
         bool eq = false, less = false;
-        if (i < n) {
+        if (i < hi) {
             key = ~ord_f32(sc[i]);
             eq = key == pivot;
             less = key < pivot;
         }
-        const unsigned long long meq = __ballot(eq);
-        const int eq_in_wave = __popcll(meq & ((1ull << lane) - 1ull));
-        if (lane == 0) s_weq[wave] = __popcll(meq);
-        __syncthreads();
-        int eq_rank = s_base_eq + eq_in_wave;
-        for (int w = 0; w < wave; ++w) eq_rank += s_weq[w];
+        const unsigned long long meq = __ballot(eq), mless = __ballot(less);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int eq_rank = run_eq + __popcll(meq & below);
         const bool sel = less || (eq && eq_rank < take_eq);
-        const unsigned long long msel = __ballot(sel);
-        const int sel_in_wave = __popcll(msel & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wsel[wave] = __popcll(msel);
-        __syncthreads();
-        int pos = s_base_sel + sel_in_wave;
-        int tot_sel = 0, tot_eq = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) pos += s_wsel[w];
-            tot_sel += s_wsel[w];
-            tot_eq += s_weq[w];
-        }
+        const int eq_taken_before = eq_rank < take_eq ? eq_rank : take_eq;   // tied elements before this one that were taken
+        const int pos = run_less + __popcll(mless & below) + eq_taken_before;
         if (sel) dst[pos] = ((uint64_t)key << 32) | (uint32_t)i;
-        __syncthreads();
-        if (tid == 0) {
-            s_base_sel += tot_sel;
-            s_base_eq += tot_eq;
-        }
-        __syncthreads();
+        run_less += __popcll(mless);
+        run_eq += __popcll(meq);
     }
     for (int i = top_n + tid; i < n_sel_pad; i += 1024) dst[i] = ~0ull;
 }
@@ -364,6 +392,75 @@ __global__ __launch_bounds__(1024) void greedy_nms_kernel(NmsArgs a) {
         }
         __syncthreads();
     }
+}
+
+// The same walk for n <= 1024 (BatchedNms: 1000 boxes per image, rcnn/BatchedNms.cu:28-88; soft-NMS cannot use the bit matrix below - a
+// suppressed box stays a suppressor with a decayed score).  The element of sorted rank t lives in thread t's REGISTERS for the whole walk -
+// box, class, score loaded once, the score stored once - where the kernel above goes to global memory twice per 64-box block (order -> box
+// -> score, then the scores back): 16 blocks x ~6 dependent round trips were most of its 672 us at C5 (profiles/r04_kernel_stats_c5_1ctx_lanes1.txt).
+// Wave w resolves block w among its own lanes by shuffles, publishes the block, every later rank applies it from LDS: the same
+// suppressors in the same order as above, hence the same bits.
+__global__ __launch_bounds__(1024) void greedy_nms_small_kernel(NmsArgs a) {
+    __shared__ float4 s_box[64];
+    __shared__ int s_cls[64];
+    __shared__ int s_act[64];
+    __shared__ int s_kept;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_kept = 0;
+    int n = a.n_cap;
+    if (a.n_dev) {
+        const int nd = a.n_dev[b];
+        n = nd < n ? nd : n;
+    }
+    const float* boxes = a.box_base + (size_t)b * a.box_batch_stride;
+    const float* cls = a.classes ? a.classes + (size_t)b * a.n_src : nullptr;
+    const int* order = a.order + (size_t)b * a.n_cap;
+    float* scores = a.scores + (size_t)b * a.n_cap;
+    const bool hard = a.mode == NMS_RPN || a.mode == NMS_RETINA || a.mode == NMS_HARD0;
+    const int nblk = (n + 63) >> 6;
+    const int r = tid;
+    const bool have = r < n;
+    float4 mb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int mc = 0;
+    float ms = -FLT_MAX;
+    if (have) {
+        const int idx = order[r];
+        mb = ldbox(boxes + (size_t)idx * a.box_stride);
+        mc = cls ? (int)cls[idx] : 0;
+        ms = scores[r];
+    }
+    __syncthreads();
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int base = bi << 6;
+        if (wave == bi) {
+            for (int k = 0; k < 63; ++k) {
+                const float sk = __shfl(ms, k);
+                if (base + k >= n) break;                // wave-uniform
+                if (!is_active(sk, a.mode)) continue;    // wave-uniform
+                const float4 kb = make_float4(__shfl(mb.x, k), __shfl(mb.y, k), __shfl(mb.z, k), __shfl(mb.w, k));
+                const int kc = __shfl(mc, k);
+                if (have && lane > k && !(hard && !is_active(ms, a.mode))) ms = apply_one(ms, mb, mc, kb, kc, a.thresh, a.mode);
+            }
+            s_box[lane] = mb;
+            s_cls[lane] = mc;
+            const bool act = have && is_active(ms, a.mode);
+            s_act[lane] = act ? 1 : 0;
+            const unsigned long long am = __ballot(act);
+            if (lane == 0) s_kept += __popcll(am);
+        }
+        __syncthreads();
+        if (hard && a.stop_after > 0 && s_kept >= a.stop_after) break;  // uniform: every thread reads the same count
+        if (have && r >= base + 64 && !(hard && !is_active(ms, a.mode))) {
+            for (int k = 0; k < 64; ++k) {
+                if (!s_act[k]) continue;
+                ms = apply_one(ms, mb, mc, s_box[k], s_cls[k], a.thresh, a.mode);
+                if (hard && !is_active(ms, a.mode)) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (have) scores[r] = ms;
 }
 
 // ---- hard class-agnostic NMS as suppression bit-matrix + scan (RPN: 6000 sorted boxes, first 1000 kept) ---------------
@@ -896,7 +993,8 @@ extern "C" int32_t trtx_retina_nms(const float* decode_out, int batch, int net_h
     a.thresh = nms_thresh;
     a.mode = NMS_RETINA;
     a.stop_after = max_keep;
-    hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
+    if (a.n_cap <= 1024) hipLaunchKernelGGL(greedy_nms_small_kernel, dim3(batch), dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(compact_kept_kernel, dim3(batch), dim3(1024), 0, stream, scores, order, n_valid, n_pad, max_keep, keep_idx,
                        keep_cnt, decode_out + 1, (long)out_elem, kRfDet, keep_det);
     return trtx::check_launch("trtx_retina_nms");
@@ -976,7 +1074,8 @@ static int32_t sorted_nms(int mode, int batch, const float* scores, const float*
                            thresh, mask_t);
         hipLaunchKernelGGL(hard_scan_kernel, dim3(batch), dim3(1024), 0, stream, mask_t, sorted, n, n_blk, a.stop_after);
     } else {
-        hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
+        if (a.n_cap <= 1024) hipLaunchKernelGGL(greedy_nms_small_kernel, dim3(batch), dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
     }
     hipLaunchKernelGGL(rekey_kernel, grid1(n_pad, batch), dim3(256), 0, stream, sorted, n, n_pad, keys);
     st = sort_keys(keys, batch, n_pad, stream);

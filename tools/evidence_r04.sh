@@ -21,7 +21,7 @@ if [ $PART = bench ] || [ $PART = all ]; then
   TRTX_FOLD_UPSAMPLE=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_c3_nofold.log 2>/dev/null
   timeout 500 python bench.py --steps 20 --warmup 5 --precision int8 > $E/bench_c3_int8.log 2>/dev/null
   for cfg in resnet50 retinaface_r50 rcnn_r50c4; do
-    timeout 400 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_$cfg.log 2>/dev/null
+    timeout 600 python bench.py --config $cfg --steps 20 --warmup 5 > $E/bench_$cfg.log 2>/dev/null
   done
   python tools/show_bench.py $E/bench_*.log
   timeout 300 python tools/layer_table.py $E/layer_table.json > $E/layer_table.txt 2>&1; tail -5 $E/layer_table.txt
