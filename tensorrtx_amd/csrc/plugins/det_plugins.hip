@@ -463,6 +463,105 @@ __global__ __launch_bounds__(1024) void greedy_nms_small_kernel(NmsArgs a) {
     if (have) scores[r] = ms;
 }
 
+// ---- BatchedNms (hard / soft-linear / soft-gaussian, class-aware; rcnn/BatchedNms.cu:28-88) with the pair work done up front -------------
+// Measured (round 4): moving the walk's state from global memory into registers (kernel above) left its 690 us at C5 unchanged - the walk
+// is 1000 DEPENDENT steps, and each step's chain (IoU with a correctly rounded division, the soft weight, ~80 instructions a lone wave
+// issues back to back) is what costs.  But only the SCORE update is sequential: whether suppressor k touches box i (same class, IoU above the
+// threshold) and by what factor - (1 - iou), exp(-iou^2 / sigma), or "to zero" - depends on the two boxes alone.  soft_factor_kernel
+// computes that factor for every (suppressor, later box) pair with the whole chip, one wave per 64 x 64 tile, into f_t[k][i] (k-major:
+// the walk reads a row of 64 consecutive boxes per load; -1 = no effect); the walk then is `s = f * s`, one multiply per step, the loads
+// independent of the scores.  The same operands in the same order as apply_one(): the same bits.
+__global__ __launch_bounds__(64) void soft_factor_kernel(const float* __restrict__ box_base, long box_batch_stride, const float* __restrict__ classes,
+                                                         int n_src, const int* __restrict__ order, int n, int n_blk, float thresh, int mode,
+                                                         float* __restrict__ f_t) {
+    const int c = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    if (c > r) return;
+    const int lane = threadIdx.x;
+    const float* boxes = box_base + (size_t)b * box_batch_stride;
+    const float* cls = classes + (size_t)b * n_src;
+    const int* ord = order + (size_t)b * n;
+    __shared__ float4 s_box[64];
+    __shared__ int s_cls[64];
+    const int j0 = c * 64 + lane;
+    s_box[lane] = j0 < n ? ldbox(boxes + (size_t)ord[j0] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s_cls[lane] = j0 < n ? (int)cls[ord[j0]] : -1;
+    __syncthreads();
+    const int i = r * 64 + lane;
+    const bool have = i < n;
+    const float4 ib = have ? ldbox(boxes + (size_t)ord[i] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ic = have ? (int)cls[ord[i]] : -2;
+    const size_t row_len = (size_t)n_blk * 64;
+    float* dst = f_t + ((size_t)b * n_blk + c) * 64 * row_len + i;
+    const int kend = (c == r) ? 63 : 64;   // (the diagonal tile's last suppressor has no later box in its block)
+    for (int k = 0; k < kend; ++k) {
+        float f = -1.0f;
+        if (have && (c != r || lane > k) && ic == s_cls[k]) {
+            const float ov = iou_plain(ib, s_box[k]);
+            if (ov > thresh) {
+                if (mode == NMS_SOFT_LINEAR) f = 1 - ov;
+                else if (mode == NMS_SOFT_GAUSS) {
+                    const float sigma = 0.5;
+                    f = expf(-(ov * ov) / sigma);
+                } else f = 0.0f;
+            }
+        }
+        dst[(size_t)k * row_len] = f;
+    }
+}
+
+// the walk of greedy_nms_small_kernel over precomputed factors (modes NMS_HARD0 / NMS_SOFT_LINEAR / NMS_SOFT_GAUSS, n <= 1024)
+__global__ __launch_bounds__(1024) void greedy_nms_factor_kernel(float* __restrict__ scores_all, int n, int n_blk, const float* __restrict__ f_t,
+                                                                 int mode, int stop_after) {
+    __shared__ int s_act[64];
+    __shared__ int s_kept;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_kept = 0;
+    float* scores = scores_all + (size_t)b * n;
+    const bool hard = mode == NMS_HARD0;
+    const int r = tid;
+    const bool have = r < n;
+    float ms = have ? scores[r] : -FLT_MAX;
+    const size_t row_len = (size_t)n_blk * 64;
+    const float* fb = f_t + (size_t)b * n_blk * 64 * row_len + r;
+    __syncthreads();
+    for (int bi = 0; bi < n_blk; ++bi) {
+        const int base = bi << 6;
+        const float* frow = fb + (size_t)base * row_len;   // factor of suppressor base + k on this thread's box: frow[k * row_len]
+        if (wave == bi) {
+            float fk[63];
+#pragma unroll
+            for (int k = 0; k < 63; ++k) fk[k] = (have && lane > k) ? frow[(size_t)k * row_len] : -1.0f;
+#pragma unroll
+            for (int k = 0; k < 63; ++k) {
+                const float sk = __shfl(ms, k);
+                if (base + k >= n) break;                // wave-uniform
+                if (!(sk > 0.0f)) continue;              // wave-uniform: an inactive box suppresses nothing
+                if (fk[k] >= 0.0f && !(hard && !(ms > 0.0f))) ms = hard ? 0.0f : fk[k] * ms;
+            }
+            const bool act = have && ms > 0.0f;
+            s_act[lane] = act ? 1 : 0;
+            const unsigned long long am = __ballot(act);
+            if (lane == 0) s_kept += __popcll(am);
+        }
+        __syncthreads();
+        if (hard && stop_after > 0 && s_kept >= stop_after) break;  // uniform: every thread reads the same count
+        if (have && r >= base + 64 && !(hard && !(ms > 0.0f))) {
+            float fk[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) fk[k] = frow[(size_t)k * row_len];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                if (!s_act[k]) continue;
+                if (fk[k] >= 0.0f) ms = hard ? 0.0f : fk[k] * ms;
+                if (hard && !(ms > 0.0f)) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (have) scores[r] = ms;
+}
+
 // ---- hard class-agnostic NMS as suppression bit-matrix + scan (RPN: 6000 sorted boxes, first 1000 kept) ---------------
 // The greedy kernel above walks 94 blocks of 64 boxes and, per block, makes every later box test up to 64 IoUs:
 // 3.6-5.3 ms per image on the R-CNN config.  Here the IoU work is done once, by the whole chip:
@@ -1073,9 +1172,16 @@ static int32_t sorted_nms(int mode, int batch, const float* scores, const float*
         hipLaunchKernelGGL(hard_mask_kernel, dim3(n_blk, n_blk, batch), dim3(64), 0, stream, boxes, (long)n * 4, order, n, n_blk,
                            thresh, mask_t);
         hipLaunchKernelGGL(hard_scan_kernel, dim3(batch), dim3(1024), 0, stream, mask_t, sorted, n, n_blk, a.stop_after);
+    } else if ((mode == NMS_HARD0 || mode == NMS_SOFT_LINEAR || mode == NMS_SOFT_GAUSS) && classes && n <= 1024 && !no_mask) {
+        const int n_blk = (n + 63) / 64;
+        float* f_t = c.take<float>((size_t)batch * n_blk * 64 * n_blk * 64);
+        if (!c.ok) return TRTX_ERR_WORKSPACE;
+        hipLaunchKernelGGL(soft_factor_kernel, dim3(n_blk, n_blk, batch), dim3(64), 0, stream, boxes, (long)n * 4, classes, n, order, n, n_blk, thresh,
+                           mode, f_t);
+        hipLaunchKernelGGL(greedy_nms_factor_kernel, dim3(batch), dim3(1024), 0, stream, sorted, n, n_blk, f_t, mode, a.stop_after);
     } else {
         if (a.n_cap <= 1024) hipLaunchKernelGGL(greedy_nms_small_kernel, dim3(batch), dim3(1024), 0, stream, a);
-    else hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL(greedy_nms_kernel, dim3(batch), dim3(1024), 0, stream, a);
     }
     hipLaunchKernelGGL(rekey_kernel, grid1(n_pad, batch), dim3(256), 0, stream, sorted, n, n_pad, keys);
     st = sort_keys(keys, batch, n_pad, stream);
@@ -1089,7 +1195,8 @@ extern "C" size_t trtx_sorted_nms_workspace(int batch, int n) {
     const size_t n_pad = next_pow2(n);
     const size_t n_blk = ((size_t)n + 63) / 64;
     const size_t mask = n <= kMaskMaxN ? align_up((size_t)batch * n_blk * n_blk * 64 * 8, 256) : 0;  // hard_mask_kernel
-    return align_up(batch * n_pad * 8, 256) + 2 * align_up((size_t)batch * n * 4, 256) + mask;
+    const size_t factors = n <= 1024 ? align_up((size_t)batch * n_blk * 64 * n_blk * 64 * 4, 256) : 0;   // soft_factor_kernel (BatchedNms)
+    return align_up(batch * n_pad * 8, 256) + 2 * align_up((size_t)batch * n * 4, 256) + (mask > factors ? mask : factors);
 }
 
 // rpnNms (RpnNms.cu:59-121)
