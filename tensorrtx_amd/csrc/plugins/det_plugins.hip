@@ -531,7 +531,10 @@ __global__ __launch_bounds__(1024) void greedy_nms_factor_kernel(float* __restri
         if (wave == bi) {
             float fk[63];
 #pragma unroll
-            for (int k = 0; k < 63; ++k) fk[k] = (have && lane > k) ? frow[(size_t)k * row_len] : -1.0f;
+            // unconditional: soft_factor_kernel wrote -1 for the lanes a suppressor does not reach (lane <= k, boxes past n).  Written as
+            // `cond ? load : -1` every one of the 63 loads sits in its own exec-masked branch with a full wait behind it - 63 L2 round
+            // trips in series per block, 600 us per launch (measured; the same trap as the stem kernel's weight loads)
+            for (int k = 0; k < 63; ++k) fk[k] = frow[(size_t)k * row_len];
 #pragma unroll
             for (int k = 0; k < 63; ++k) {
                 const float sk = __shfl(ms, k);
