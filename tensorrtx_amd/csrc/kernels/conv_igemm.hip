@@ -1240,6 +1240,7 @@ int conv_igemm_pick_cink(int cin, int bk) {
 }
 
 bool conv_igemm_supported(const ConvArgs& a) {
+    if (a.bn == 256) return conv_gemm256_possible(a) && a.t_r3 == 0 && a.Kpad == (a.kh * a.kw * a.CinK + 63) / 64 * 64;   // the 256 x 256 x 64 tactic
     if (a.in_i8 && (a.bk != 32 || a.CinK % 32 || a.scalar_out)) return false;  // int8: 64-channel k-steps, vector epilogue
     if (a.up_C != 0 && (a.up_C < 0 || a.in_i8 || a.kh != 1 || a.kw != 1 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h || a.pad_w || a.up_C % 64 || a.up_C >= a.Cin ||
                         a.H != 2 * a.up_H || a.W != 2 * a.up_W || a.up_ld % 8 || a.CinK == 16 || a.t_r3 != 0))
@@ -1284,6 +1285,9 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
     // two runs each on one box), and "one summation order per plan" is the simpler contract.
     if (ws_ok) push(a.bn, a.bk, 128, 1, 2);
     else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only) ? 2 : 1, 1);
+    // the 256 x 256 x 64 role-alternating tile for large plain GEMMs (conv_gemm256.hip): more work-efficient than any 128-row tile
+    static const bool no_g256 = getenv("TRTX_GEMM256") != nullptr && atoi(getenv("TRTX_GEMM256")) == 0;
+    if (fp16 && !no_g256 && conv_gemm256_possible(a)) push(256, 64, 256, 1, 1);
     const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
     static const int bns[5] = {128, 80, 64, 32, 16};
     for (int bi = 0; bi < 5; ++bi) {
@@ -1331,6 +1335,7 @@ void conv_apply_tactic(ConvArgs* a, const ConvTactic& t) {
 int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     if (!conv_igemm_supported(a0) || (a0.in_i8 && !a0.cscale)) return TRTX_ERR_UNSUPPORTED;
     const bool fp16 = !a0.in_i8 && !a0.out_i8 && !a0.res_i8;
+    if (a0.bn == 256) return conv_gemm256_f16(a0, s);
     // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel (t_ws: 0 = where supported, 1 = never, 2 = asked for)
     if (fp16 && a0.t_ws != 1 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.

@@ -97,6 +97,10 @@ void conv_apply_tactic(ConvArgs* a, const ConvTactic& t);
 constexpr int kMaxConvGroup = 4;
 bool conv_igemm_group_supported(const ConvArgs* a, int n);
 int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s);
+// Large plain-GEMM convolutions on the 256 x 256 x 64 role-alternating tile (conv_gemm256.hip): the tactic ConvArgs::bn == 256 of the
+// implicit-GEMM family (same packed weights, same bits); conv_igemm_f16 dispatches to it
+bool conv_gemm256_possible(const ConvArgs& a);
+int32_t conv_gemm256_f16(const ConvArgs& a, hipStream_t s);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);

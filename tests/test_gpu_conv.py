@@ -125,6 +125,10 @@ TACTIC_CASES = [
     (8, 160, 160, 48, 32, 1, 1, 0, "silu", False, "none"),   # 1x1 over a large map, 32-wide column tiles, Cin 48 in a 64-wide slice
     (16, 57, 55, 256, 256, 1, 1, 0, "relu", True, "relu"),   # the large-GEMM tile (256 x 128, 2 x 2 waves) joins: 1x1, ragged last tile
     (9, 56, 56, 128, 384, 3, 1, 1, "relu", False, "none"),   # ... and on a 3x3 (K = 1152), three column tiles
+    # round 4: the 256 x 256 x 64 role-alternating tile (conv_gemm256.hip) joins for large plain GEMMs: K >= 512, Cout a multiple of 256
+    (41, 40, 40, 512, 512, 1, 1, 0, "relu", True, "relu"),   # res5-like 512 -> 512 + shortcut, ragged last row tile (65 600 = 256 x 256 + 64)
+    (24, 56, 49, 1024, 256, 1, 1, 0, "silu", False, "none"),  # K = 1024, one column tile
+    (11, 57, 55, 2048, 512, 1, 1, 0, "none", False, "relu"),  # K = 2048 (res5's 2048 -> 512), odd tile count per XCD
 ]
 
 
@@ -149,6 +153,8 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
     assert len(tactics) >= 2 and len(set(tactics)) == len(tactics)
     if os.environ.get("TRTX_BIG_VARIANT") and Cout % 128 == 0 and Cin % 64 == 0 and N * Ho * Wo * (Cout // 128) >= 256 * 256:
         assert (128, 64, 256, 1, 1, 0) in tactics   # the large-GEMM configurations (experiments: tools/gemm_tactics.py)
+    if k == 1 and Cin >= 512:
+        assert (256, 64, 256, 1, 1, 0) in tactics   # conv_gemm256_possible
     exact = None
     try:
         for t in tactics:
