@@ -70,7 +70,7 @@ def _kernel_duration_from_profile(model):
     try:
         calls, tot = 0, 0.0
         for line in open(os.path.join(ROOT, "profiles", name)):
-            if "conv_igemm" in line or "conv_ws" in line:
+            if "conv_igemm" in line or "conv_ws" in line or "conv_gemm256" in line:
                 m = re.search(r"\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
                 if m:
                     calls += int(m.group(1))
