@@ -58,6 +58,10 @@ __device__ __forceinline__ float g256_act(float v, int act, float alpha) {
     return g256_act_slow(v, act, alpha);
 }
 
+// CONV3: the same GEMM over a 3x3 stride-1 pad-1 convolution's implicit A matrix (Cin a whole number of 64-channel K-tiles; K runs
+// (tap, channel slice) like the packed weights): a lane's four A rows carry the byte offset of their pixel's top-left tap and a 9-bit mask of the
+// taps that lie inside the image; stage() adds the K-tile's tap delta or range-checks the piece away (zero fill = the padding).
+template <bool CONV3>
 __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p, unsigned a_bytes, unsigned w_bytes, int tiles_n, int total_tiles, int xcd_chunk) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_B];
     const int tid = threadIdx.x;
@@ -80,18 +84,63 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ ((lane >> 4) | ((wave & 1) << 2));
     unsigned a_off[2][2], w_off[2][2];   // [half][piece]
+    unsigned a_taps[2][2];               // CONV3: bit (3 r + q) = tap (r, q) of this row's pixel lies inside the image (0 for rows past M)
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = __builtin_amdgcn_rcpf((float)HoWo), inv_wo = __builtin_amdgcn_rcpf((float)p.Wo);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = h * 128 + (8 * i + wave) * 8 + lrow;
-            a_off[h][i] = (m0 + r) < p.M ? (unsigned)(((size_t)(m0 + r) * lda + lchunk * 8) * 2) : kOOB;
+            const int m = m0 + r;
+            if constexpr (CONV3) {
+                const bool ok = m < p.M;
+                const int mm = ok ? m : 0;
+                int n = (int)((float)mm * inv_howo);   // small quotients: a float estimate is within +-1, fixed up exactly
+                int rem = mm - n * HoWo;
+                if (rem < 0) { --n; rem += HoWo; }
+                if (rem >= HoWo) { ++n; rem -= HoWo; }
+                int ho = (int)((float)rem * inv_wo);
+                int wo = rem - ho * p.Wo;
+                if (wo < 0) { --ho; wo += p.Wo; }
+                if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
+                // byte offset of (n, ho - 1, wo - 1, channel chunk): wraps for border pixels, whose taps are masked
+                a_off[h][i] = (unsigned)(((n * p.H + ho - 1) * p.W + wo - 1) * lda + lchunk * 8) * 2u;
+                unsigned rows = 0, cols = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    rows |= ((unsigned)(ho - 1 + t) < (unsigned)p.H ? 1u : 0u) << t;
+                    cols |= ((unsigned)(wo - 1 + t) < (unsigned)p.W ? 1u : 0u) << t;
+                }
+                unsigned taps = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) taps |= ((rows >> t) & 1u) ? (cols << (3 * t)) : 0u;
+                a_taps[h][i] = ok ? taps : 0u;
+            } else {
+                a_off[h][i] = m < p.M ? (unsigned)(((size_t)m * lda + lchunk * 8) * 2) : kOOB;
+                a_taps[h][i] = 0;
+            }
             w_off[h][i] = (n0 + r) < p.Cout_pad ? (unsigned)(((size_t)(n0 + r) * ldw + lchunk * 8) * 2) : kOOB;
         }
+    const int spt = CONV3 ? p.CinK / BK : 1;                       // K-tiles per tap
+    const unsigned spt_m = CONV3 ? (65536u + spt - 1) / spt : 0u;   // kt / spt == (kt * spt_m) >> 16 for kt < 65536 / spt (conv_gemm256_possible)
     // half-tile id: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; K-tiles beyond nk are range-checked away (zero fill)
     auto stage = [&](int buf, int hid, int kt) {
         const bool live = kt < nk;
         const unsigned koff = (unsigned)kt * (BK * 2);
+        if (CONV3 && hid < 2) {   // an A half-tile of the 3x3: K-tile kt = (tap, 64-channel slice)
+            const int tap = (int)(((unsigned)kt * spt_m) >> 16);
+            const int cs = kt - tap * spt;
+            const int r = (tap * 11) >> 5, q = tap - 3 * r;   // tap / 3 for tap < 12
+            const unsigned delta = (unsigned)((r * p.W + q) * lda * 2 + cs * (BK * 2));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                char* dst = smem + buf * BUF_B + hid * HALF_B + (8 * i + wave) * 1024;
+                const bool ok = live && ((a_taps[hid & 1][i] >> tap) & 1u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)dst, 16, ok ? a_off[hid & 1][i] + delta : kOOB, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             char* dst = smem + buf * BUF_B + hid * HALF_B + (8 * i + wave) * 1024;
@@ -197,6 +246,19 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
     const bool second = res || p.act2 != ACT_NONE;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+        // the shortcut values of this 64-row chunk, ALL EIGHT fetched before anything waits for one (unconditional loads from clamped
+        // rows): inside the store loop below each load sat in front of its use - 16 dependent HBM round trips per tile, a third of the
+        // 512 -> 2048 GEMM's time (round 4: 780 us with them in the loop against 498-535 us for the harness without a shortcut)
+        half8 rvs[8];
+        if (res) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + wm * 128 + c * 64 + it * 8 + (lane >> 3);
+                const int n = n0 + wn * 64 + (lane & 7) * 8;
+                const int mc = m < p.M ? m : p.M - 1, nc = n < p.Cout ? n : p.Cout - 8;
+                rvs[it] = *reinterpret_cast<const half8*>(res + (size_t)mc * p.ld_res + nc);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -233,7 +295,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
             if (m >= p.M || n >= p.Cout) continue;
             if (second) {
                 half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (res) rv = *reinterpret_cast<const half8*>(res + (size_t)m * p.ld_res + n);
+                if (res) rv = rvs[it];
                 if (p.act2 == ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
@@ -259,7 +321,12 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
 // tiles (the packed weights have exactly Cout_pad rows), 16-byte rows everywhere, the addressed slices below 2 GB, and enough tiles for the chip
 bool conv_gemm256_possible(const ConvArgs& a) {
     if (a.in_i8 || a.out_i8 || a.res_i8 || a.up_C || a.scalar_out || a.groups != 1) return false;
-    if (!(a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K)) return false;
+    const bool plain = a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K;
+    // ... or a 3x3 stride-1 pad-1 convolution over whole 64-channel K-tiles (res5's 512 -> 512 on 4000 RoIs, rcnn/backbone.hpp:100-229)
+    const bool conv3 = a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 &&
+                       a.Cin == a.CinK && a.CinK % 64 == 0 && a.Kpad == 9 * a.CinK && a.Ho == a.H && a.Wo == a.W && 9 * (a.CinK / 64) * (a.CinK / 64) < 60000 &&
+                       (double)a.N * a.H * a.W < 8.0e6;   // (pixel index split with float reciprocals; kt / spt by a 16-bit reciprocal)
+    if (!plain && !conv3) return false;
     if (a.Kpad % 64 || a.Kpad < 512 || a.Cout_pad % 256 || a.Cout % 8 || a.ld_in % 8 || a.ld_out % 8 || (a.residual && a.ld_res % 8)) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     if ((double)M * a.ld_in * 2.0 >= 2.0e9 || (double)a.Cout_pad * a.Kpad * 2.0 >= 2.0e9) return false;
@@ -273,7 +340,8 @@ int32_t conv_gemm256_f16(const ConvArgs& a0, hipStream_t s) {
     const unsigned a_bytes = (unsigned)((((size_t)a.M - 1) * a.ld_in + a.Cin) * 2);
     const unsigned w_bytes = (unsigned)((size_t)a.Cout_pad * a.Kpad * 2);
     const int tiles_n = a.Cout_pad / 256, total = ((a.M + 255) / 256) * tiles_n, chunk = (total + 7) / 8;
-    TRTX_LAUNCH(conv_gemm256_f16_kernel, dim3(chunk * 8), dim3(512), 0, s, a, a_bytes, w_bytes, tiles_n, total, chunk);
+    if (a.kh == 3) TRTX_LAUNCH(conv_gemm256_f16_kernel<true>, dim3(chunk * 8), dim3(512), 0, s, a, a_bytes, w_bytes, tiles_n, total, chunk);
+    else TRTX_LAUNCH(conv_gemm256_f16_kernel<false>, dim3(chunk * 8), dim3(512), 0, s, a, a_bytes, w_bytes, tiles_n, total, chunk);
     return check_launch("conv_gemm256_f16");
 }
 

@@ -129,6 +129,8 @@ TACTIC_CASES = [
     (41, 40, 40, 512, 512, 1, 1, 0, "relu", True, "relu"),   # res5-like 512 -> 512 + shortcut, ragged last row tile (65 600 = 256 x 256 + 64)
     (24, 56, 49, 1024, 256, 1, 1, 0, "silu", False, "none"),  # K = 1024, one column tile
     (11, 57, 55, 2048, 512, 1, 1, 0, "none", False, "relu"),  # K = 2048 (res5's 2048 -> 512), odd tile count per XCD
+    (11, 56, 56, 512, 512, 3, 1, 1, "relu", False, "none"),   # ... and its im2col form on a 3x3 (res5's 512 -> 512, K = 4608): borders, images, ragged last tile
+    (140, 23, 21, 256, 256, 3, 1, 1, "silu", True, "none"),    # small maps: most rows touch a border, tiles straddle several images
 ]
 
 
@@ -153,7 +155,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
     assert len(tactics) >= 2 and len(set(tactics)) == len(tactics)
     if os.environ.get("TRTX_BIG_VARIANT") and Cout % 128 == 0 and Cin % 64 == 0 and N * Ho * Wo * (Cout // 128) >= 256 * 256:
         assert (128, 64, 256, 1, 1, 0) in tactics   # the large-GEMM configurations (experiments: tools/gemm_tactics.py)
-    if k == 1 and Cin >= 512:
+    if (k == 1 and Cin >= 512) or (k == 3 and Cin % 64 == 0 and Cout % 256 == 0 and s == 1 and N * Ho * Wo >= 256 * 256 * 256 // Cout):
         assert (256, 64, 256, 1, 1, 0) in tactics   # conv_gemm256_possible
     exact = None
     try:
