@@ -155,7 +155,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
     assert len(tactics) >= 2 and len(set(tactics)) == len(tactics)
     if os.environ.get("TRTX_BIG_VARIANT") and Cout % 128 == 0 and Cin % 64 == 0 and N * Ho * Wo * (Cout // 128) >= 256 * 256:
         assert (128, 64, 256, 1, 1, 0) in tactics   # the large-GEMM configurations (experiments: tools/gemm_tactics.py)
-    if (k == 1 and Cin >= 512) or (k == 3 and Cin % 64 == 0 and Cout % 256 == 0 and s == 1 and N * Ho * Wo >= 256 * 256 * 256 // Cout):
+    if Cin % 64 == 0 and Cout % 256 == 0 and s == 1 and k * k * Cin >= 256 and (k == 3 or (k == 1 and p == 0)) and ((N * Ho * Wo + 255) // 256) * (Cout // 256) >= 96:
         assert (256, 64, 256, 1, 1, 0) in tactics   # conv_gemm256_possible
     exact = None
     try:
