@@ -328,6 +328,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
         const int row = (NW * j + wave) * RPI + lrow;
         b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;  // weights < 2 GB
     }
+    // Column tiles that are not a whole number of DMA passes (BN = 16 / 32 / 80 with 32-wide steps, 80 with 64-wide ones): in the LAST pass
+    // some waves' pieces lie wholly beyond the tile - rows nobody reads.  Those waves skip the instruction (round 4: a DMA piece costs its
+    // wave 60-185 cycles of issue and the loop is bound by exactly that; on the 80-wide detect-head arms three of four waves issued a
+    // dead piece per k-step) and wait on one load fewer per tile in flight.  Same LDS contents wherever anything is read: same bits.
+    constexpr bool B_PARTIAL = !RS && (BN % (NW * RPI) != 0);
+    const bool b_last_live = !B_PARTIAL || (NW * (B_PASSES - 1) + wave) * RPI < BN;   // wave-uniform
 
     // wave-uniform walk over K.  TPS == 1: the (tap, channel offset, byte offset) of k-step e is precomputed by lane e & 63 into
     // two VGPRs (a 64-step window, rebuilt every 64 steps) and fetched with v_readlane: the kernel is instruction-issue bound
@@ -422,6 +428,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
+            if (B_PARTIAL && j == B_PASSES - 1 && !b_last_live) continue;   // this wave's piece of the last pass lies beyond the column tile
             const unsigned voff = ONE ? b_off[j] : ((s_kt < nk && !(dbg & 2)) ? b_off[j] : kOOB);
             if constexpr (RS) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + (NW * j + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
@@ -524,7 +531,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 #define TRTX_KSTEP(S)                                                         \
     {                                                                         \
         TRTX_STAMP(0, kt);                                                    \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory"); \
+        if (B_PARTIAL && !b_last_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LOADS_PER_TILE - 1) * (NST - 2)) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory"); \
         TRTX_STAMP(1, kt);                                                    \
         __builtin_amdgcn_s_barrier();                                         \
         TRTX_STAMP(2, kt);                                                    \
