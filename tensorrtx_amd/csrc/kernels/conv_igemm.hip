@@ -110,6 +110,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
     static_assert(NWAVES * 16 * PS <= LDS_BYTES, "epilogue tile must fit in the stage buffers");
     constexpr int CPR = BN / 8;       // 8-channel items per row
     constexpr int ITEMS = 16 * CPR;   // items of one 16-row slab of this wave
+    // A lane's items q = lane, lane + 64, ... all sit in the same 8-channel column when CPR divides 64 (every tile width but 80): its bias
+    // is fetched ONCE, here, and the L2 round trip passes under the barrier and the staging writes below instead of standing in front of the
+    // first store of every slab (round 4).
+    constexpr bool BIAS_FIXED = (64 % CPR) == 0;
+    float4 bf0 = make_float4(0.f, 0.f, 0.f, 0.f), bf1 = bf0;
+    if (BIAS_FIXED && p.bias) {
+        const int co0 = n0 + (lane % CPR) * 8;
+        const int cc0 = co0 < p.Cout ? co0 : 0;   // (clamped, not conditional: a conditional load waits where it stands)
+        bf0 = *reinterpret_cast<const float4*>(p.bias + cc0);
+        bf1 = *reinterpret_cast<const float4*>(p.bias + cc0 + 4);
+    }
     __syncthreads();  // every wave is done reading the last stage
     char* mine = smem + wave * 16 * PS;
     const int rbase = row0 < 0 ? wave * WR : row0;   // first tile row of this wave (waves may also be split along N: WN below)
@@ -140,7 +151,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
             const floatx4 hi = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32 + 16);
             float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             if (p.bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                float4 b0 = bf0, b1 = bf1;
+                if constexpr (!BIAS_FIXED) {
+                    b0 = *reinterpret_cast<const float4*>(p.bias + co);
+                    b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                }
                 x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
                 x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
             }
