@@ -45,6 +45,35 @@ if [ $PART = prof ] || [ $PART = all ]; then
   TRTX_LANES=1 prof c4_1ctx_lanes1 "--config retinaface_r50 --contexts 1"
   TRTX_LANES=1 prof c5_1ctx_lanes1 "--config rcnn_r50c4 --contexts 1"
 fi
+if [ $PART = c3prof ]; then   # the C3 profiles and PMC pass alone (after the last small kernel changes of the round)
+  timeout 300 python bench.py --steps 5 --warmup 2 --repeats 3 --no-cpu-baseline > /dev/null 2>&1
+  prof() {
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_$1 -o p -- python $R/bench.py $2 --steps 20 --warmup 5 --no-cpu-baseline > $E/prof_$1.log 2>&1)
+    { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $2 --steps 20 --warmup 5 --no-cpu-baseline   (round 4, final build; TRTX_TACTIC_CACHE set: no tactic-timing launches inside)"; python tools/rocprof_summary.py $E/prof_$1; } > $E/kernel_stats_$1.txt 2>&1
+    head -9 $E/kernel_stats_$1.txt | cut -c1-170
+    rm -rf $E/prof_$1
+  }
+  prof c3 ""
+  TRTX_LANES=1 prof c3_1ctx_lanes1 "--contexts 1"
+  OUT=$E/pmc_yolov8n
+  (cd /tmp && timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $OUT -o c -- python $R/bench.py --config yolov8n --contexts 1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline > $OUT.log 2>&1)
+  python - <<PY
+import csv, glob, collections
+fs = glob.glob("$E/pmc_yolov8n/**/c_counter_collection.csv", recursive=True)
+per = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
+for r in csv.DictReader(open(fs[0])):
+    k = r["Kernel_Name"]
+    fam = "conv" if ("conv_igemm" in k or "conv_ws" in k or "conv_gemm256" in k) else ("conv_stem" if "conv_stem" in k else ("yolo" if "yolo" in k else "other"))
+    per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+    key = (r["Dispatch_Id"], fam)
+    if key not in seen:
+        seen.add(key); n[fam] += 1
+for fam, d in per.items():
+    rd, wr = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_WRREQ_sum", 0.0)
+    print(f"yolov8n {fam:12s} launches {n[fam]:6d}  RDREQ {rd:14.0f}  WRREQ {wr:14.0f}  bytes/launch {(2 * rd + wr) * 64 / max(n[fam], 1):14.0f}")
+PY
+  rm -rf $E/pmc_yolov8n/
+fi
 if [ $PART = c5 ]; then   # C5 again after the last kernel change of the round (conv_gemm256 on the 3x3, shortcut prefetch): bench line, both profiles, PMC
   timeout 600 python bench.py --config rcnn_r50c4 --steps 20 --warmup 5 > $E/bench_rcnn_r50c4.log 2>/dev/null
   prof() {
