@@ -16,7 +16,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc2_${TAG}_*/**/c_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_igemm" in r["Kernel_Name"] or "conv_ws" in r["Kernel_Name"]:
+        if "conv_igemm" in r["Kernel_Name"] or "conv_ws" in r["Kernel_Name"] or "conv_gemm256" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for c, v in sorted(acc.items()):
     print("$TAG", c, round(sum(v) / len(v)))
