@@ -29,6 +29,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Kernel arguments in device memory (the HIP runtime's own switch, read when it initialises - i.e. before torch is imported).  Every conv launch
+# starts by reading its ~270-byte ConvArgs; from host-visible memory that first read is a ~2 us round trip over the host link: measured on one box,
+# same build, HIP_FORCE_DEV_KERNARG=0 / 1: 1.113 / 1.011 ms of serialized conv time per step, 35.9k / 37.4k img/s (round 4).  ROCm 7.2's default
+# already behaves like 1 on the boxes of this round; set explicitly so that a box configured otherwise measures the same thing.  A caller's own value wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming copy reaches)
