@@ -113,7 +113,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
     // A lane's items q = lane, lane + 64, ... all sit in the same 8-channel column when CPR divides 64 (every tile width but 80): its bias
     // is fetched ONCE, here, and the L2 round trip passes under the barrier and the staging writes below instead of standing in front of the
     // first store of every slab (round 4).
+    // The 80-wide tile (CPR = 10) has no such column: its wave fetches the tile's 80 bias values once, four per lane, and keeps them in a
+    // private LDS strip behind the staging tiles; an item reads its eight from there (an LDS read where an L2 round trip stood).
     constexpr bool BIAS_FIXED = (64 % CPR) == 0;
+    constexpr int BIAS_LDS = BIAS_FIXED ? 0 : BN * 4;
+    static_assert(NWAVES * (16 * PS + BIAS_LDS) <= LDS_BYTES, "epilogue tile + bias strip must fit in the stage buffers");
     float4 bf0 = make_float4(0.f, 0.f, 0.f, 0.f), bf1 = bf0;
     if (BIAS_FIXED && p.bias) {
         const int co0 = n0 + (lane % CPR) * 8;
@@ -121,8 +125,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
         bf0 = *reinterpret_cast<const float4*>(p.bias + cc0);
         bf1 = *reinterpret_cast<const float4*>(p.bias + cc0 + 4);
     }
+    if (!BIAS_FIXED && p.bias) bf0 = *reinterpret_cast<const float4*>(p.bias + n0 + (lane < BN / 4 ? lane * 4 : 0));   // (n0 + BN <= Cout_pad)
     __syncthreads();  // every wave is done reading the last stage
     char* mine = smem + wave * 16 * PS;
+    char* bias_lds = smem + NWAVES * 16 * PS + wave * BIAS_LDS;
+    if (!BIAS_FIXED && p.bias && lane < BN / 4) *reinterpret_cast<float4*>(bias_lds + lane * 16) = bf0;   // wave-private: ordered with this wave's reads
     const int rbase = row0 < 0 ? wave * WR : row0;   // first tile row of this wave (waves may also be split along N: WN below)
 #pragma nounroll
     for (int i = 0; i < MI; ++i) {
@@ -153,8 +160,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
             if (p.bias) {
                 float4 b0 = bf0, b1 = bf1;
                 if constexpr (!BIAS_FIXED) {
-                    b0 = *reinterpret_cast<const float4*>(p.bias + co);
-                    b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                    b0 = *reinterpret_cast<const float4*>(bias_lds + cc * 32);
+                    b1 = *reinterpret_cast<const float4*>(bias_lds + cc * 32 + 16);
                 }
                 x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
                 x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
