@@ -36,6 +36,9 @@
 #ifndef TRTX_STAMP
 #define TRTX_STAMP(i, kt)
 #endif
+#ifndef TRTX_MARK   // launch anatomy (tools/hip/igemm_launch_anatomy.hip): 0 entry, 1 first tile issued, 2 k-loop done, 3 epilogue done
+#define TRTX_MARK(i)
+#endif
 // Ablation switches for the timing experiments of tools/conv_dbg.sh (build with -DTRTX_CONV_ABLATE to get them from the
 // TRTX_CONV_DBG environment variable: 1 A loads range-checked away, 2 B loads, 4 no ds_read/MFMA, 8 no epilogue, 16 no
 // k-loop).  In the product build the flag word is the constant 0 and every test on it folds away.
@@ -277,6 +280,7 @@ template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, 
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_bytes, unsigned w_bytes, const int m0, const int n0, int dbg_flags,
                                                 char* __restrict__ smem) {
     const int dbg = TRTX_DBG(dbg_flags);
+    TRTX_MARK(0);
     constexpr int BN = 16 * NFRAG;
     constexpr int WM = NW / WN;                    // waves along M (NW = waves per workgroup: 4, or 8 for the large-GEMM tile)
     constexpr int NFW = NFRAG / WN;                // 16-column fragments per wave
@@ -581,6 +585,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
         }
     } else {
     issue_tile(0);
+    TRTX_MARK(1);
     if (NST == 3) issue_tile(1);
     for (int kt = 0; !(dbg & 16);) {
         TRTX_KSTEP(0);
@@ -596,12 +601,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 #undef TRTX_KSTEP
     // the two run-out tiles were range-checked away (no memory access) but their LDS writes must retire before exit
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRTX_MARK(2);
 
     if (dbg & 8) return;
     conv_epilogue<NFW, MI, I8, LDS_BYTES, NW>(p, acc, acci, smem, wave, lane, n0 + wave_n * NFW * 16, [&](int t) {
         const int m = m0 + t;
         return m < p.M ? m : -1;
     }, wave_m * WR);
+    TRTX_MARK(3);
 }
 
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
