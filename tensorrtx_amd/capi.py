@@ -14,7 +14,8 @@ class TrtxError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libtrtx_hip.so")
+    # TRTX_HIP_LIB: another BUILD of this same library (A/B measurements of kernel changes on one box); never a different implementation
+    return os.environ.get("TRTX_HIP_LIB") or os.path.join(_HERE, "lib", "libtrtx_hip.so")
 
 
 def hip_runtimes_mapped():

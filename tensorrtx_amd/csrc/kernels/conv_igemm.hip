@@ -92,6 +92,91 @@ __device__ __forceinline__ int swz(int row) {
     return (row >> 1) & 7;
 }
 
+// The item loop of conv_epilogue's common case (see there), with (RES) or without a residual.
+template <int NFRAG, int MI, bool I8, bool RES, int PS, int BIAS_LDS_ON, typename PixelOf>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, floatx4 (&acc)[MI][NFRAG], intx4 (&acci)[MI][NFRAG], char* mine, const char* bias_lds, int lane,
+                                                   int n0, int rbase, float4 bf0, float4 bf1, bool second, PixelOf&& pixel_of) {
+    constexpr int BN = 16 * NFRAG, CPR = BN / 8, ITEMS = 16 * CPR, NIT = (ITEMS + 63) / 64;
+    constexpr bool BIAS_FIXED = !BIAS_LDS_ON;
+    _Float16* __restrict__ out = static_cast<_Float16*>(p.out);
+    const _Float16* __restrict__ res = static_cast<const _Float16*>(p.residual);
+    const int px_in = lane & 15;
+    const int ch_in = (lane >> 4) * 4;
+    const half8 zero8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma nounroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int ii = 0; ii < MI; ++ii) {
+            if (ii != i) continue;
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) {
+                floatx4 v = acc[ii][j];
+                if constexpr (I8) {
+                    const float4 cs = *reinterpret_cast<const float4*>(p.cscale + n0 + j * 16 + ch_in);
+                    v = floatx4{(float)acci[ii][j][0] * cs.x, (float)acci[ii][j][1] * cs.y, (float)acci[ii][j][2] * cs.z, (float)acci[ii][j][3] * cs.w};
+                }
+                *reinterpret_cast<floatx4*>(mine + px_in * PS + (j * 16 + ch_in) * 4) = v;
+            }
+        }
+        // item (q -> row, 8-channel column, pixel).  With a residual: its 16 bytes are fetched one item ahead, after the previous item's
+        // store, by an unconditional load from a clamped address (a conditional one would wait where it stands)
+        auto locate = [&](int q, int& row, int& cc, int& m) {
+            row = q / CPR, cc = q % CPR;
+            m = q < ITEMS ? pixel_of(rbase + i * 16 + row) : -1;
+            return m >= 0 && n0 + cc * 8 < p.Cout;
+        };
+        int row, cc, m;
+        bool ok = locate(lane, row, cc, m);
+        half8 rv = zero8;
+        if constexpr (RES) rv = *reinterpret_cast<const half8*>(res + (ok ? (size_t)m * p.ld_res + n0 + cc * 8 : (size_t)0));
+#pragma nounroll
+        for (int it = 0; it < NIT; ++it) {
+            half8 v = zero8;
+            if (ok) {
+                const floatx4 lo = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32);
+                const floatx4 hi = *reinterpret_cast<const floatx4*>(mine + row * PS + cc * 32 + 16);
+                float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (p.bias) {
+                    float4 b0 = bf0, b1 = bf1;
+                    if constexpr (!BIAS_FIXED) {
+                        b0 = *reinterpret_cast<const float4*>(bias_lds + cc * 32);
+                        b1 = *reinterpret_cast<const float4*>(bias_lds + cc * 32 + 16);
+                    }
+                    x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w;
+                    x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+                }
+                if (p.act1 == ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-x[e])));
+                } else if (p.act1 == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e] > 0.f ? x[e] : 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to_half(x[e]);
+                }
+                if (second) {
+                    if (p.act2 == ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = (float)v[e] + (float)rv[e];
+                            v[e] = round_to_half(t > 0.f ? t : 0.f);
+                        }
+                    }
+                }
+                *reinterpret_cast<half8*>(out + (size_t)m * p.ld_out + n0 + cc * 8) = v;
+            }
+            if (it + 1 < NIT) {
+                ok = locate(lane + (it + 1) * 64, row, cc, m);
+                if constexpr (RES) rv = *reinterpret_cast<const half8*>(res + (ok ? (size_t)m * p.ld_res + n0 + cc * 8 : (size_t)0));
+            }
+        }
+    }
+}
+
 // ---- epilogue shared by the implicit-GEMM kernels.  The accumulators (lane owns channels 16j + 4*(lane>>4) + [0,4) of pixel
 // 16i + (lane&15) of its wave's WR rows) go through a wave-private fp32 LDS tile, 16 rows at a time, and come back row-major:
 // one lane = 8 consecutive channels of one pixel, so residual reads and output stores are whole 16-byte chunks (128-byte lines
@@ -134,6 +219,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
     char* bias_lds = smem + NWAVES * 16 * PS + wave * BIAS_LDS;
     if (!BIAS_FIXED && p.bias && lane < BN / 4) *reinterpret_cast<float4*>(bias_lds + lane * 16) = bf0;   // wave-private: ordered with this wave's reads
     const int rbase = row0 < 0 ? wave * WR : row0;   // first tile row of this wave (waves may also be split along N: WN below)
+    // The common case - 16-byte fp16 stores, ReLU / SiLU / no activation, fp16 residual - has its own item loop (round 4).  In the general
+    // loop below the rare paths (int8 residual, element-wise ragged loads and stores, the slow activations) put global LOADS into the loop
+    // body; the compiler's wait for them (`s_waitcnt vmcnt(0)`, merged at the loop header) then also waits for the previous item's STORE
+    // to be acknowledged: 4-8 store round trips in series per wave, 2.3-3.9 us per tile measured (profiles/r04_launch_anatomy.txt).  The
+    // fast loop holds no load but the residual's, and fetches that one item ahead, so the wait it needs leaves the stores in flight.
+    const bool fast = !p.scalar_out && !p.out_i8 && !(res && p.res_i8) && (p.act1 == ACT_SILU || p.act1 == ACT_RELU || p.act1 == ACT_NONE) &&
+                      (p.act2 == ACT_NONE || p.act2 == ACT_RELU);
+#ifndef TRTX_NO_FAST_EPILOGUE   // (A/B builds of the round-4 measurement only)
+    if (fast) {
+        // two copies of the loop, with and without a residual: the one without holds no global load at all, so no wait for one either
+        if (res) conv_epilogue_fast<NFRAG, MI, I8, true, PS, !BIAS_FIXED>(p, acc, acci, mine, bias_lds, lane, n0, rbase, bf0, bf1, second, pixel_of);
+        else conv_epilogue_fast<NFRAG, MI, I8, false, PS, !BIAS_FIXED>(p, acc, acci, mine, bias_lds, lane, n0, rbase, bf0, bf1, second, pixel_of);
+        return;
+    }
+#endif
 #pragma nounroll
     for (int i = 0; i < MI; ++i) {
         // accumulators of row slab i -> LDS (int8: dequantised by input scale * weight scale of the channel)
@@ -584,18 +684,21 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
             if (++kt == nk) break;
         }
     } else {
-    issue_tile(0);
-    TRTX_MARK(1);
-    if (NST == 3) issue_tile(1);
+    // NST - 1 tiles in flight (two normally; the deep variants of the short, latency-bound layers keep five), then one k-step per stage in turn
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) {
+        issue_tile(st);
+        if (st == 0) TRTX_MARK(1);
+    }
     for (int kt = 0; !(dbg & 16);) {
-        TRTX_KSTEP(0);
-        if (++kt == nk) break;
-        TRTX_KSTEP(1);
-        if (++kt == nk) break;
-        if (NST == 3) {
-            TRTX_KSTEP(2);
-            if (++kt == nk) break;
+        bool done = false;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            if (done) continue;
+            TRTX_KSTEP(st);
+            if (++kt == nk) done = true;
         }
+        if (done) break;
     }
     }
 #undef TRTX_KSTEP
