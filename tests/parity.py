@@ -74,8 +74,8 @@ VALUES = {
     ('rcnn_fp16', '800x1067'): {'feat_rel_err': 0.00261, 'proposals_matched': 0.9906, 'detections_matched': 0.962, 'top_score_err': 0.000464},
     ('rcnn_fp16', '800x1333'): {'feat_rel_err': 0.00257, 'proposals_matched': 0.9906, 'detections_matched': 0.962, 'top_score_err': 0.000582},
     ('mask_rcnn_fp32', None): {'mask_err': 1.76e-06},
-    ('mask_rcnn_fp16', None): {'mask_err': 0.00121},
-    ('yolov8n_int8_320', None): {'head_max_abs_err_fp16': 0.0703, 'head_mean_rel_err_int8': 0.0491, 'head_max_err_over_span_int8': 0.435},
+    ('mask_rcnn_fp16', None): {'mask_err': 0.00139},
+    ('yolov8n_int8_320', None): {'head_max_abs_err_fp16': 0.0813, 'head_mean_rel_err_int8': 0.0491, 'head_max_err_over_span_int8': 0.435},
     ('yolov8n_int8_640', 'vs_fp32_oracle'): {'matched_iou50': 0.756, 'mean_iou': 0.838, 'mean_conf_err': 0.246},
     ('yolov8n_int8_640', 'vs_fp16_engine'): {'matched_iou50': 0.758, 'mean_iou': 0.838, 'mean_conf_err': 0.245},
     ('yolov8n_int8_640', 'minmax_vs_fp32_oracle'): {'matched_iou50': 0.924, 'matched_iou90': 0.825, 'mean_iou': 0.9473, 'mean_conf_err': 0.0877},
