@@ -653,12 +653,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
     };
 
     // one k-step: tile kt has landed once at most the LOADS_PER_TILE loads of tile kt+1 are still in flight; the
-    // barrier also guarantees every wave finished reading the stage that is refilled next.
+    // barrier also guarantees every wave finished reading the stage that is refilled next - FINISHED, not just issued: the wait names
+    // lgkmcnt(0) too.  Nothing else makes the compiler complete the previous step's fragment reads before this barrier (s_barrier is not a
+    // fence; the asm's "memory" clobber orders the issue of memory operations, not their completion, and the MFMAs that consume the
+    // fragments may be scheduled below the barrier).  In the row-reuse kernel's three-stage instantiations it did sink 1-7 reads and their
+    // MFMAs below the barrier, and under co-scheduling the next tile's range-checked-away DMA pieces (zero fill, no memory round trip)
+    // overtook them: the hazard of round 3 (profiles/r04_r3_bisect.txt).  In this kernel's instantiations the reads were complete anyway
+    // (tools/isa_barrier_reads.py over the compiled ISA, tests/test_isa_barrier_reads.py); now the source says so.
 #define TRTX_KSTEP(S)                                                         \
     {                                                                         \
         TRTX_STAMP(0, kt);                                                    \
-        if (B_PARTIAL && !b_last_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LOADS_PER_TILE - 1) * (NST - 2)) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory"); \
+        if (B_PARTIAL && !b_last_live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((LOADS_PER_TILE - 1) * (NST - 2)) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory"); \
         TRTX_STAMP(1, kt);                                                    \
         __builtin_amdgcn_s_barrier();                                         \
         TRTX_STAMP(2, kt);                                                    \
@@ -778,12 +784,19 @@ __global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGro
 // kernel above - and 40 KB instead of 60 KB of LDS (64-wide column tile) lets four workgroups share a CU instead of two
 // (SQ counters of the 64 -> 64 3x3 80x80 layer, profiles/r02_sq_counters_64x64_3x3_80.txt: at two workgroups per CU this kernel
 // already matches the kernel above at four, with half the wave-cycles and a third of the wait cycles).
-// ROUND 4: NOT PART OF THE PRODUCT LIBRARY.  Engines that had chosen this kernel returned results differing in the last fp16 places between
-// execution contexts running side by side (tests/test_gpu_multi_context.py: 4 of 6 runs with it among the tactics, 0 of 12 without); a
-// second reading of the code (round 4: load counts against the vmcnt immediates, the rows fa_off[q] reads beyond a wave's own, the DMA- /
-// read-side swizzle keys, the run-out tiles, the padded-column masks) did not locate the hazard, and a kernel whose bits depend on what
-// else is resident does not ship behind an environment variable.  It is compiled only with -DTRTX_EXPERIMENTAL_R3 (tools / bisecting);
-// without it r3_possible() is false, no tactic names it and ConvArgs::t_r3 != 0 is refused by conv_igemm_supported().
+// ROUND 4: NOT PART OF THE PRODUCT LIBRARY YET.  Round 3 found engines that had chosen this kernel returning results that differed between
+// execution contexts running side by side (tests/test_gpu_multi_context.py: 4 of 6 runs with it among the tactics, 0 of 12 without).  Root cause
+// (round 4, profiles/r04_r3_bisect.txt): in the THREE-stage instantiations the compiler placed the last 1-7 fragment reads of a k-step, and the
+// MFMAs that consume them, BELOW the next step's `s_waitcnt vmcnt` + `s_barrier` - nothing in the source forbade it - so a wave passed the barrier
+// that frees a stage with reads of that stage still queued.  The DMA pieces that refill the stage are, for this kernel's padding columns and
+// border rows, range-checked away: zero fill without a memory round trip, a few hundred cycles; with two 60 KB workgroups of this kernel and
+// another context's workgroups contending for the CU's LDS, those beat the queued reads.  Forced onto every layer it can take, three contexts in
+// flight: 64- and 32-wide three-stage tiles differ from the lone-context run in every run (whole XCD chunks of an early layer, errors O(1), no
+// NaN with poisoned LDS: stale-but-plausible data); two stages, and two stages with the three-stage LDS allocation, never; a second barrier after
+// the MFMAs or waiting for all loads does not help; `s_waitcnt lgkmcnt(0)` before the barrier does (identical in every run) - and is what the step
+// macro below now does.  The ISA scan tools/isa_barrier_reads.py finds the four three-stage instantiations of the round-3 kernel and nothing
+// else in the library.  The kernel stays compiled out (-DTRTX_EXPERIMENTAL_R3) until the fixed build has been through the full GPU suite and the
+// tuner's A/B again; without the define r3_possible() is false, no tactic names it and ConvArgs::t_r3 != 0 is refused.
 #ifdef TRTX_EXPERIMENTAL_R3
 template <int NFRAG, int BKT, int MI, int NSTAGES>
 __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int total_tiles,
@@ -805,16 +818,24 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
     constexpr int KSUB = BKT / 32;
     constexpr int NST = NSTAGES;
     static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+#if defined(R3_VARIANT) && R3_VARIANT == 8   // bisecting: the two-stage kernel with the LDS ALLOCATION of the three-stage one (the extra stage is never touched)
+    __shared__ __attribute__((aligned(16))) char smem[(NST + (BKT == 32 ? 1 : 0)) * STAGE_BYTES];
+#else
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
+#if defined(R3_VARIANT) && R3_VARIANT == 16
+    if (tile >= total_tiles) return;
+#else
     if (xcd_chunk) {
         tile = (tile & 7) * xcd_chunk + (tile >> 3);
         if (tile >= total_tiles) return;
     }
+#endif
     const int t0 = (tile / tiles_n) * BME;         // first position of the tile in the padded-column index space
     const int n0 = (tile % tiles_n) * BN;
     const int Wp = p.W + 2;
@@ -935,12 +956,21 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
             }
     };
 
+    // R3_VARIANT (bisecting builds, profiles/r04_r3_bisect.txt): 0 = the kernel with its fix (fragment reads complete, lgkmcnt(0), before the
+    // barrier that frees their stage); 32 = the round-3 kernel (no such wait: reproduces the hazard; "variant 0" in the record, which predates
+    // the fix); on top of the round-3 kernel: 1 = a second barrier after the MFMAs of a step, 2 = every step waits for ALL of the wave's loads
+    // (neither helps), 7 = both plus the lgkmcnt(0); 8 = two stages with the three-stage LDS allocation; 16 = plain tile order (no XCD chunks)
+#ifndef R3_VARIANT
+#define R3_VARIANT 0
+#endif
 #define TRTX_R3STEP(S)                                                                        \
     {                                                                                         \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory");     \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R3_VARIANT & 2) ? 0 : LOADS_PER_TILE * (NST - 2)) : "memory");     \
+        if (R3_VARIANT == 0 || R3_VARIANT == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* THE FIX (see the kernel's header) */ \
         __builtin_amdgcn_s_barrier();                                                         \
         issue_tile(((S) + NST - 1) % NST);                                                    \
         compute(S);                                                                           \
+        if (R3_VARIANT & 1) __builtin_amdgcn_s_barrier();                                     \
     }
     issue_tile(0);
     if (NST == 3) issue_tile(1);
@@ -1326,6 +1356,14 @@ bool r3_possible(const ConvArgs& a) {
            (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
 }
 #ifdef TRTX_EXPERIMENTAL_R3
+static int r3_forced() {
+    static const int v = getenv("TRTX_FORCE_R3") ? atoi(getenv("TRTX_FORCE_R3")) : 0;
+    return v;
+}
+static int r3_forced_bn() {   // TRTX_FORCE_R3_BN=64|80|128: force only the layers of that column-tile width
+    static const int v = getenv("TRTX_FORCE_R3_BN") ? atoi(getenv("TRTX_FORCE_R3_BN")) : 0;
+    return v;
+}
 template <int BKT, int NSTAGES>
 int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
@@ -1500,9 +1538,10 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
 #ifdef TRTX_EXPERIMENTAL_R3
-        } else if (a.t_r3 != 0 && r3_possible(a)) {
+        } else if ((a.t_r3 != 0 || (r3_forced() && (r3_forced_bn() == 0 || r3_forced_bn() == a.bn))) && r3_possible(a)) {   // TRTX_FORCE_R3=1|2 (bisecting): every layer the kernel can take, 3 | 2 stages
+            const int v = a.t_r3 ? a.t_r3 : r3_forced();
             st = a.bk == 64 ? launch_r3<64, 2>(a, in_bytes, w_bytes, s)
-                            : (a.t_r3 == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
+                            : (v == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
 #endif
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, ws_min_waves(ws_regs(TAPS, KC, NFW, WC, NF, RO
     int b = 0;
     for (; tile < tile_end; tile += per_xcd, b ^= 1) {
         // my DMA for this tile has landed (and my stores of the previous tile have been issued long ago) ...
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (lgkmcnt: my reads of the other buffer have COMPLETED - conv_igemm.hip, k-step comment)
         // ... so has everybody's, and every wave is done reading the other buffer
         __builtin_amdgcn_s_barrier();
         const int next = tile + per_xcd;

@@ -15,10 +15,12 @@ def _outputs(e, batch, gpu):
     return {i: torch.zeros(batch * int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(e.nb_bindings) if not e.is_input[i]}
 
 
-def _check(model, batch, h, w, xs, gpu, rounds=4, rec=0, poison=False, **opts):
+def _check(model, batch, h, w, xs, gpu, rounds=4, rec=0, poison=False, need_tactic=None, **opts):
     path, _ = synth_wts(model)
     e = engine.Engine(engine.build_plan(model, path, batch=batch, h=h, w=w, fp16=1, aux_streams=0, **opts))
     try:
+        if need_tactic:   # the test is about a kernel the tuner must have chosen somewhere in this engine
+            assert any(need_tactic in t["tactic"] for t in e.tactics()), f"no '{need_tactic}' tactic in {sorted({t['tactic'] for t in e.tactics()})}"
         n = len(xs)
         xs = [x.to(gpu) for x in xs]
         # reference: one context, one input after the other
@@ -80,3 +82,12 @@ def test_rcnn_three_contexts_in_flight(gpu):
     g = torch.Generator().manual_seed(60)
     xs = [torch.rand(2, 320, 416, 3, generator=g) * 255.0 for _ in range(3)]
     _check("rcnn_r50c4", 2, 320, 416, xs, gpu)
+
+
+def test_rcnn_three_contexts_in_flight_with_the_256x256_gemm_tiles(gpu):
+    """conv_gemm256 (one 128 KB workgroup per CU, two role-alternating wave groups) under co-scheduling: an image large enough for the tuner to
+    choose it on res4 / res5 (C5's regime); every context returns the lone context's bits.  Round 4 ran this once by hand while bisecting the
+    row-reuse kernel (profiles/r04_r3_bisect.txt): identical."""
+    g = torch.Generator().manual_seed(61)
+    xs = [torch.rand(2, 800, 1344, 3, generator=g) * 255.0 for _ in range(3)]
+    _check("rcnn_r50c4", 2, 800, 1344, xs, gpu, rounds=6, need_tactic="256x256x64")

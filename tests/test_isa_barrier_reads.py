@@ -1,0 +1,91 @@
+"""The LDS-pipelined kernels may not pass a barrier with fragment reads in flight (the barrier frees the buffer those reads come from): checked on the
+COMPILED ISA of every MFMA convolution kernel, because nothing in the language makes the compiler keep the property - round 3's row-reuse kernel lost it in
+its three-stage instantiations and returned different results under co-scheduling (profiles/r04_r3_bisect.txt, tools/isa_barrier_reads.py).
+hipcc cross-compiles gfx950 without a GPU; the five translation units compile side by side (the big one takes about a minute)."""
+import os
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_barrier_reads as scan  # noqa: E402
+
+CSRC = os.path.join(ROOT, "tensorrtx_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+UNITS = ["conv_igemm", "conv_gemm256", "conv_ws", "conv_chain", "conv_stem"]
+
+SNIPPET = """
+	.amdhsa_kernel k_%s
+k_%s:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+.LBB0_1:
+	ds_read_b128 v[0:3], v8
+	ds_read_b128 v[4:7], v8 offset:1024
+	s_waitcnt lgkmcnt(%d)
+	v_mfma_f32_16x16x32_f16 v[10:13], v[0:3], v[0:3], v[10:13]
+	s_waitcnt vmcnt(3)
+	s_barrier
+	s_waitcnt lgkmcnt(0)
+	v_mfma_f32_16x16x32_f16 v[10:13], v[4:7], v[4:7], v[10:13]
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def _asm(tmp, name, body):
+    p = os.path.join(tmp, name + ".s")
+    open(p, "w").write(body)
+    return p
+
+
+def test_scanner_flags_a_read_that_crosses_a_barrier_and_only_that():
+    with tempfile.TemporaryDirectory() as tmp:
+        n, bad = scan.scan(_asm(tmp, "bad", SNIPPET % ("bad", "bad", 1)))
+        assert n == 1 and bad == [("k_bad", [1])]
+        n, bad = scan.scan(_asm(tmp, "good", SNIPPET % ("good", "good", 0)))
+        assert n == 1 and bad == []
+
+
+def test_scanner_follows_branches_not_the_listing_order():
+    # the read sits in a block that jumps AWAY from the barrier that follows it in the listing; the barrier's real predecessor waited
+    asm = """
+	.amdhsa_kernel k
+k:
+	s_cbranch_scc0 .LBB0_2
+	ds_read_b128 v[0:3], v8
+	s_branch .LBB0_3
+.LBB0_2:
+	s_waitcnt lgkmcnt(0)
+	s_barrier
+.LBB0_3:
+	s_waitcnt lgkmcnt(0)
+	s_endpgm
+.Lfunc_end0:
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        assert scan.scan(_asm(tmp, "cfg", asm)) == (1, [])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
+    with tempfile.TemporaryDirectory() as tmp:
+        def compile_unit(u):
+            out = os.path.join(tmp, u + ".s")
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", "-mllvm",
+                                   "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels", u + ".hip")],
+                                  stderr=subprocess.DEVNULL)
+            return out
+        with ThreadPoolExecutor(len(UNITS)) as ex:
+            outs = list(ex.map(compile_unit, UNITS))
+        total = 0
+        for u, path in zip(UNITS, outs):
+            n, bad = scan.scan(path)
+            total += n
+            assert n > 0, f"{u}: no kernel found in the listing"
+            assert not bad, f"{u}: barrier reached with LDS reads in flight in {bad}"
+        assert total >= 250   # conv_igemm alone instantiates 218
