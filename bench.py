@@ -458,17 +458,13 @@ def main():
 
     cache = os.environ.get("TRTX_TEST_CACHE", "/tmp/trtx_test_cache")
     os.makedirs(cache, exist_ok=True)
-    if args.config == "yolov8n":
-        # seeded synthetic YOLOv8n weights (no trained weights offline), written once per box in the reference's .wts format
-        path = os.path.join(cache, "bench_yolov8n_seed0.wts")
-        if not os.path.exists(path):
-            tmp = f"{path}.{os.getpid()}.tmp"
-            wts_writer.write_wts(tmp, synth.yolov8n_state(seed=0), dialect="double")
-            os.replace(tmp, path)
-    else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from util import synth_wts  # seeded synthetic weights through the product-side writer
-        path, _ = synth_wts(args.config)
+    # seeded synthetic weights (no trained weights offline) from the PRODUCT-side generators (tensorrtx_amd/synth.py; the same draws as the test
+    # suite's oracle-driven generator - tests/test_runtime_cpu.py), written once per box in the reference's .wts format
+    path = os.path.join(cache, f"bench_{args.config}_seed0.wts")
+    if not os.path.exists(path):
+        tmp = f"{path}.{os.getpid()}.tmp"   # ranks of a multi-GPU bench may write the same file concurrently
+        wts_writer.write_wts(tmp, synth.STATE[args.config](seed=0), dialect="double")
+        os.replace(tmp, path)
     n_ctx = max(1, args.contexts)
     calib_cache = {}
 

@@ -174,6 +174,141 @@ def yolov8n_state(seed=0, num_class=80):
     return OrderedDict((k, v.numpy()) for k, v in sd.items())
 
 
+class _Draw:
+    """Seeded tensor provider of the synthetic-weight generators below: the draw order and distributions are those of the test-suite's
+    generator (oracle/models_torch.py run in init mode), so both write the same file - tests/test_runtime_cpu.py asserts it per model.
+    A name drawn twice keeps its first position and its LAST value (the R-CNN generator touches res5 from the box and the mask branch)."""
+
+    def __init__(self, seed):
+        import torch
+        from collections import OrderedDict
+        self.torch = torch
+        self.g = torch.Generator().manual_seed(seed)
+        self.sd = OrderedDict()
+
+    def randn(self, *shape):
+        return self.torch.randn(*shape, generator=self.g)
+
+    def rand(self, *shape):
+        return self.torch.rand(*shape, generator=self.g)
+
+    def conv_w(self, name, cout, cin, k, gain=2.0):
+        import math
+        self.sd[name] = (self.randn(cout, cin, k, k) * math.sqrt(gain / (cin * k * k))).float()
+
+    def bn(self, prefix, c, gamma_scale=1.0):
+        self.sd[prefix + ".weight"] = (gamma_scale * (0.9 + 0.2 * self.rand(c))).float()
+        self.sd[prefix + ".bias"] = (0.1 * self.randn(c)).float()
+        self.sd[prefix + ".running_mean"] = (0.1 * self.randn(c)).float()
+        self.sd[prefix + ".running_var"] = (0.8 + 0.4 * self.rand(c)).float()
+        self.sd[prefix + ".num_batches_tracked"] = self.torch.zeros(1)
+
+    def state(self):
+        from collections import OrderedDict
+        return OrderedDict((k, v.numpy()) for k, v in self.sd.items())
+
+
+def _resnet50_body(d, prefix, bn3_gamma):
+    """conv1 / bn1 + the 16 bottlenecks of torchvision's ResNet-50 naming (resnet/resnet50.cpp:155-229, retinaface/retina_r50.cpp:100-140)"""
+    def conv_bn(cname, bname, cout, cin, k):
+        d.conv_w(cname + ".weight", cout, cin, k)
+        d.bn(bname, cout, bn3_gamma if bname.endswith("bn3") else 1.0)
+    conv_bn(prefix + "conv1", prefix + "bn1", 64, 3, 7)
+    inch = 64
+    for stage, nblk in enumerate((3, 4, 6, 3)):
+        width = 64 << stage
+        for b in range(nblk):
+            l = f"{prefix}layer{stage + 1}.{b}."
+            stride = 2 if (b == 0 and stage > 0) else 1
+            conv_bn(l + "conv1", l + "bn1", width, inch, 1)
+            conv_bn(l + "conv2", l + "bn2", width, width, 3)
+            conv_bn(l + "conv3", l + "bn3", width * 4, width, 1)
+            if stride != 1 or inch != width * 4:
+                conv_bn(l + "downsample.0", l + "downsample.1", width * 4, inch, 1)
+            inch = width * 4
+
+
+def resnet50_state(seed=0):
+    """Seeded synthetic ResNet-50 weights under the keys resnet/resnet50.cpp reads (torchvision state_dict): OrderedDict name -> fp32 array."""
+    import math
+    d = _Draw(seed)
+    _resnet50_body(d, "", 1.0)
+    d.sd["fc.weight"] = (d.randn(1000, 2048) * math.sqrt(1.0 / 2048)).float()
+    d.sd["fc.bias"] = (0.1 * d.randn(1000)).float()
+    return d.state()
+
+
+def retinaface_r50_state(seed=0, head_gain=0.5):
+    """Seeded synthetic RetinaFace-R50 weights (retinaface/retina_r50.cpp:100-212 key names).  The last BatchNorm of every residual branch has a
+    small gamma so that activations stay O(1-10) through 16 bottlenecks (fp16 storage, the exp() of the decode)."""
+    d = _Draw(seed)
+    _resnet50_body(d, "body.", 0.25)
+
+    def cbr(name, cout, cin, k):
+        d.conv_w(name + ".0.weight", cout, cin, k)
+        d.bn(name + ".1", cout)
+    cbr("fpn.output1", 256, 512, 1)
+    cbr("fpn.output2", 256, 1024, 1)
+    cbr("fpn.output3", 256, 2048, 1)
+    cbr("fpn.merge2", 256, 256, 3)
+    cbr("fpn.merge1", 256, 256, 3)
+    for l in ("ssh1", "ssh2", "ssh3"):
+        cbr(l + ".conv3X3", 128, 256, 3)
+        cbr(l + ".conv5X5_1", 64, 256, 3)
+        cbr(l + ".conv5X5_2", 64, 64, 3)
+        cbr(l + ".conv7X7_2", 64, 64, 3)
+        cbr(l + ".conv7x7_3", 64, 64, 3)
+    for l in range(3):
+        for name, ch in (("BboxHead", 8), ("ClassHead", 4), ("LandmarkHead", 20)):
+            d.conv_w(f"{name}.{l}.conv1x1.weight", ch, 256, 1, gain=head_gain)
+            d.sd[f"{name}.{l}.conv1x1.bias"] = (0.1 * d.randn(ch)).float()
+    return d.state()
+
+
+def rcnn_r50c4_state(seed=0, num_classes=80, anchors=15):
+    """Seeded synthetic Faster / Mask R-CNN R50-C4 weights (detectron2 export after fuse-bn, the keys of rcnn/rcnn.cpp:79-278 and
+    rcnn/backbone.hpp:26-229): every conv has a bias; small gains on the residual branches and the stem bring the (x - mean) input to O(1)."""
+    import math
+    d = _Draw(seed)
+
+    def conv(name, cout, cin, k, gain=2.0):
+        d.conv_w(name + ".weight", cout, cin, k, gain=gain)
+        d.sd[name + ".bias"] = (0.05 * d.randn(cout)).float()
+
+    def stage(n, inch, mid, outch, l):
+        for i in range(n):
+            b = f"{l}.{i}"
+            conv(b + ".conv1", mid, inch, 1)
+            conv(b + ".conv2", mid, mid, 3)
+            conv(b + ".conv3", outch, mid, 1, gain=0.125)
+            if inch != outch:
+                conv(b + ".shortcut", outch, inch, 1, gain=1.0)
+            inch = outch
+
+    conv("backbone.stem.conv1", 64, 3, 7, gain=2.0 / 70.0 ** 2)
+    inch, mid, outch = 64, 64, 256
+    for s_, n in enumerate((3, 4, 6)):
+        stage(n, inch, mid, outch, f"backbone.res{s_ + 2}")
+        inch, mid, outch = outch, mid * 2, outch * 2
+    conv("proposal_generator.rpn_head.conv", 1024, 1024, 3)
+    conv("proposal_generator.rpn_head.objectness_logits", anchors, 1024, 1, gain=8.0)
+    conv("proposal_generator.rpn_head.anchor_deltas", 4 * anchors, 1024, 1, gain=0.05)
+    stage(3, 1024, 512, 2048, "roi_heads.res5")
+    nc = num_classes
+    d.sd["roi_heads.box_predictor.cls_score.weight"] = (d.randn(nc + 1, 2048) * 0.06).float()
+    d.sd["roi_heads.box_predictor.cls_score.bias"] = (0.1 * d.randn(nc + 1)).float()
+    d.sd["roi_heads.box_predictor.bbox_pred.weight"] = (d.randn(4 * nc, 2048) * 0.01).float()
+    d.sd["roi_heads.box_predictor.bbox_pred.bias"] = (0.01 * d.randn(4 * nc)).float()
+    stage(3, 1024, 512, 2048, "roi_heads.res5")   # the mask branch runs res5 again: second draw, first position (see _Draw)
+    d.sd["roi_heads.mask_head.deconv.weight"] = (d.randn(2048, 256, 2, 2) * math.sqrt(2.0 / 2048)).float()
+    d.sd["roi_heads.mask_head.deconv.bias"] = (0.05 * d.randn(256)).float()
+    conv("roi_heads.mask_head.predictor", nc, 256, 1, gain=4.0)
+    return d.state()
+
+
+STATE = {"resnet50": resnet50_state, "retinaface_r50": retinaface_r50_state, "rcnn_r50c4": rcnn_r50c4_state}   # (yolov8n_state is added below its definition)
+
+
 YOLOV5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yolov5s P3/P4/P5 (ultralytics yaml)
 
 
@@ -203,3 +338,6 @@ def yolov5_head_tensors(batch, classes=80, net_h=640, net_w=640, strides=(8, 16,
                 outs[l][b, k, 5 + c, e] = rng.uniform(3.0, 7.0)
                 outs[l][b, k, 0:4, e] = rng.normal(0, 0.4, size=4)
     return [x.reshape(batch, 3 * info, -1) for x in outs]
+
+
+STATE["yolov8n"] = yolov8n_state

@@ -334,6 +334,16 @@ def test_product_side_yolov8n_weights_match_the_test_generator():
     assert all(np.array_equal(sd[k], tensors[k].numpy()) for k in sd)
 
 
+@pytest.mark.parametrize("model", ["resnet50", "retinaface_r50", "rcnn_r50c4"])
+def test_product_side_weights_of_the_other_bench_configs_match_the_test_generator(model):
+    """bench.py takes the C2 / C4 / C5 weights from tensorrtx_amd.synth too (no tests/ or oracle/ import outside its
+    cpu_baseline leg); same names, same order, same bytes as the oracle-driven generator, so the engines and their numbers are the same."""
+    _, tensors = synth_wts(model)
+    sd = synth.STATE[model](0)
+    assert list(sd) == list(tensors)
+    assert all(np.array_equal(sd[k], tensors[k].numpy()) for k in sd)
+
+
 def test_mask_rcnn_builder_matches_pytorch_restatement():
     """MASK_ON (rcnn.cpp:202-232): second RoIAlign on the final boxes, res5 with shared weights, ConvTranspose + ReLU,
     1x1 predictor, MaskRcnnInference plugin; interpreted layer by layer == the PyTorch restatement."""
