@@ -1627,7 +1627,10 @@ struct Lowerer {
                 {
                     const double flop_px = 2.0 * a.Cout * (double)a.kh * a.kw * a.Cin;
                     const double byte_px = 2.0 * ((double)a.Cin * a.stride_h * a.stride_w + (double)a.Cout * (op.in.size() > 1 ? 2 : 1));
-                    t.t_rs = (net.max_aux_streams == 0 && flop_px / byte_px < 312.0) ? 1 : 0;
+                    // TRTX_RS_RIDGE=<FLOP per byte> (A/B at build time): the 80 -> 80 3x3 arms of the detect head sit at 360 FLOP/B, just above the
+                    // default, at 14 % of the MFMA peak - whether they belong on the register path too is an open measurement
+                    static const double ridge = getenv("TRTX_RS_RIDGE") ? atof(getenv("TRTX_RS_RIDGE")) : 312.0;
+                    t.t_rs = (net.max_aux_streams == 0 && flop_px / byte_px < ridge) ? 1 : 0;
                 }
                 if (conv_igemm_supported(t)) {
                     a = t;
