@@ -32,6 +32,7 @@
 #include "../common.h"
 #include "kernels.h"
 #include "launch.h"
+#include "patch_index.h"
 
 #ifndef TRTX_STAMP
 #define TRTX_STAMP(i, kt)
@@ -1000,6 +1001,168 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
 #endif  // TRTX_EXPERIMENTAL_R3
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 variant with a RESIDENT INPUT PATCH ("patch"; experimental, -DTRTX_EXPERIMENTAL_PATCH).  The kernels
+// above bring an A tile from global memory to LDS for every (tile, tap, channel slice): a 3x3 layer's input crosses the global -> LDS path
+// nine times per column tile, and on YOLOv8n / ResNet-50 that path - not HBM, not the MFMA pipe - is the largest term of a step
+// (tools/lds_fill_model.py: 5.6 GB per b32 step for 2.3 GB of HBM bytes).  Here an output tile is a TH x 16 block of ONE image, its
+// (TH + 2) x 18 input patch is brought to LDS once (one plane per 32-channel slice, conv_ws.hip's swizzled layout), the nine taps read
+// their A fragments from it at shifted addresses, and only the weight tile of a k-step (BN x 32) streams through the three-stage ring:
+// per 128 output pixels and 64 -> 64 channels 30 + 73 KB instead of 147 + 73 KB through the fill path (16 rows: 27 + 37 per 128 pixels).
+// K is walked (tap, channel slice) as in the main kernel and every output element accumulates in the same order with the same MFMA: results
+// are bit-identical to the main kernel's (tests/test_gpu_conv.py treats it as one more exchangeable tile shape, ConvArgs::t_ws == 3).
+// All index arithmetic lives in patch_index.h and is replayed lane by lane on the CPU (tests/test_patch_index_cpu.py).
+// NOT YET RUN ON A GPU (written at the end of round 4 without GPU minutes): compiled only with the define; without it no tactic names it.
+#ifdef TRTX_EXPERIMENTAL_PATCH
+template <int NFRAG, int KC, int MI>
+__global__ __launch_bounds__(256) void conv_patch_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int tiles_x, int tiles_y,
+                                                             int total_tiles, int xcd_chunk) {
+    namespace px = patchidx;
+    constexpr int BN = 16 * NFRAG;
+    constexpr int TH = 4 * MI;
+    constexpr int PLANE = (TH + 2) * px::kPitch * px::kPixelBytes;
+    constexpr int PIECES = (TH + 2) * px::kPitch / 16;            // DMA pieces per plane
+    constexpr int B_PASSES = (BN + 63) / 64;
+    constexpr int STAGE_B = B_PASSES * 64 * 64;                    // weight tile of one k-step (rows beyond BN are dummy targets)
+    constexpr int NST = 3;
+    constexpr int PATCH_BYTES = KC * PLANE;
+    constexpr int LDS_BYTES = PATCH_BYTES + NST * STAGE_B;
+    constexpr int NK = 9 * KC;
+    static_assert(MI == 2 || MI == 4, "8- or 16-row tiles");
+    static_assert(PLANE % 1024 == 0, "a plane is a whole number of DMA pieces");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    if (xcd_chunk) {
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    const px::Tile T = px::tile_of(tile, tiles_n, tiles_x, tiles_y, TH, BN);
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
+
+    // ---- the patch: every plane's pieces, dealt to the waves; padding ring, pitch padding and ragged channels are range-checked away (zero fill)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        for (int piece = wave; piece < PIECES; piece += 4) {
+            const px::DmaLane d = px::dma_lane(piece, lane);
+            const int hi = T.y0 - 1 + d.py, wi = T.x0 - 1 + d.px;
+            const bool ok = d.px < px::kPW && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && kc * 32 + d.clog * 8 < p.Cin;
+            const unsigned voff = ok ? (unsigned)((((T.n * p.H + hi) * p.W + wi) * p.ld_in + kc * 32 + d.clog * 8) * 2) : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + kc * PLANE + piece * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+    // ---- weight tiles: conv_igemm's B layout for 32-wide steps; k-step e = tap * KC + kc starts at k = 32 e of the packed row
+    unsigned b_off[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+        const px::WLane w = px::w_lane(j, wave, lane);
+        b_off[j] = w.row < BN ? (unsigned)(((T.n0 + w.row) * p.Kpad + w.clog * 8) * 2) : kOOB;   // (kOOB + any k offset < 2^30 stays out of range)
+    }
+    int issued = 0;
+    auto issue_w = [&](int stage) {
+        char* sb = smem + PATCH_BYTES + stage * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) {
+            const unsigned voff = issued < NK ? b_off[j] : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sb + (4 * j + wave) * 1024), 16, voff, 0, 0, 0);
+            b_off[j] += 64;
+        }
+        ++issued;
+    };
+
+    floatx4 acc[MI][NFRAG];
+    intx4 acci[MI][NFRAG];  // unused (the shared epilogue's int8 leg)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) {
+            acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            acci[i][j] = intx4{0, 0, 0, 0};
+        }
+    int a_off[MI][3];   // fragment i of this wave = tile row wave * MI + i; tap column q; filter row r adds kRowStepBytes
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_off[i][q] = px::frag_offset(wave * MI + i, lane & 15, 0, q, lane >> 4);
+    int fb_off[NFRAG];
+#pragma unroll
+    for (int j = 0; j < NFRAG; ++j) fb_off[j] = px::w_frag_offset(j, lane);
+
+    issue_w(0);
+    issue_w(1);
+    // One k-step: the patch (first step) and weight tile e have landed once only tile e + 1's loads are in flight; every wave's fragment reads of
+    // step e - 1 have COMPLETED (lgkmcnt(0): the k-step comment of the main kernel) before the barrier that frees their stage for tile e + 2.
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int e = (r * 3 + q) * KC + kc;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B_PASSES) : "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_w((e + 2) % NST);
+                const char* pa = smem + kc * PLANE + r * px::kRowStepBytes;
+                const char* pb = smem + PATCH_BYTES + (e % NST) * STAGE_B;
+                half8 af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(pa + a_off[i][q]);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    const half8 bf = *reinterpret_cast<const half8*>(pb + fb_off[j]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+    // the two run-out weight tiles were range-checked away (no memory access) but their LDS writes must retire before the epilogue reuses the space
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // row t of the tile (t = 16 * tile row + column) -> output pixel, or -1 beyond the image
+    conv_epilogue<NFRAG, MI, false, LDS_BYTES>(p, acc, acci, smem, wave, lane, T.n0, [&](int t) {
+        const int y = T.y0 + (t >> 4), x = T.x0 + (t & 15);
+        return (y < p.H && x < p.W) ? (T.n * p.H + y) * p.W + x : -1;
+    });
+}
+
+template <int NFRAG, int KC>
+void launch_patch_mi(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, int th, hipStream_t s) {
+    const int tiles_n = a.Cout_pad / (16 * NFRAG), tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th;
+    const int total = a.N * tiles_y * tiles_x * tiles_n, chunk = (total + 7) / 8;
+    if (th == 16) TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 4>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+    else TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+}
+template <int NFRAG>
+int32_t launch_patch_kc(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, int th, hipStream_t s) {
+    switch (a.CinK / 32) {
+        case 1: launch_patch_mi<NFRAG, 1>(a, in_bytes, w_bytes, th, s); break;
+        case 2: launch_patch_mi<NFRAG, 2>(a, in_bytes, w_bytes, th, s); break;
+        case 3: launch_patch_mi<NFRAG, 3>(a, in_bytes, w_bytes, th, s); break;
+        case 4: launch_patch_mi<NFRAG, 4>(a, in_bytes, w_bytes, th, s); break;
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+    return TRTX_OK;
+}
+// rows per tile: 16 where the LDS plan leaves two workgroups per CU and the map is tall enough to fill them, else 8
+int patch_tile_rows(const ConvArgs& a) {
+    const int kc = a.CinK / 32;
+    return (kc <= 2 && a.H >= 16) ? 16 : 8;
+}
+int32_t launch_patch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    const int th = patch_tile_rows(a);
+    switch (a.bn) {
+        case 64: return launch_patch_kc<4>(a, in_bytes, w_bytes, th, s);
+        case 80: return launch_patch_kc<5>(a, in_bytes, w_bytes, th, s);
+        case 128: return launch_patch_kc<8>(a, in_bytes, w_bytes, th, s);
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+}
+#endif  // TRTX_EXPERIMENTAL_PATCH
+
+// ---------------------------------------------------------------------------------------------------------------
 // Small-M variant (20x20 maps at batch 32 give M = 12800: 100 tiles of 128 rows for 256 CUs, and a 3x3 conv over 256
 // channels is a chain of 72 dependent k-steps).  Here a workgroup owns a 64 x BN tile and its four waves SPLIT K: each
 // wave runs its own quarter of the k-steps through a wave-private LDS pipeline (no barrier inside the loop, no coupling
@@ -1378,6 +1541,15 @@ int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStr
     return TRTX_OK;
 }
 #endif
+#ifdef TRTX_EXPERIMENTAL_PATCH
+// the resident-patch kernel: fp16 3x3 stride 1 pad 1 over at most 128 input channels, 16-byte output stores, 64 / 80 / 128-wide column tiles
+bool patch_possible(const ConvArgs& a) {
+    return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
+           a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 && a.bk == 32 && a.CinK % 32 == 0 && a.CinK <= 128 && a.Cin % 8 == 0 && a.Kpad == 9 * a.CinK &&
+           !a.scalar_out && a.Ho == a.H && a.Wo == a.W && (a.bn == 64 || a.bn == 80 || a.bn == 128) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128) &&
+           a.t_r3 == 0;
+}
+#endif
 // 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 // ... 256-row tiles too, for 32/64/80-wide column tiles
@@ -1487,6 +1659,11 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             static const bool big_on = getenv("TRTX_BIG_VARIANT") != nullptr;
             if (big_on && big_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 256) push(bn, t.bk, 256, 1, 1);
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
+#ifdef TRTX_EXPERIMENTAL_PATCH
+            // the resident-patch kernel (ws == 3): a candidate only on request until it has been through the GPU suite (TRTX_CONV_PATCH=1)
+            static const bool allow_patch = getenv("TRTX_CONV_PATCH") != nullptr && atoi(getenv("TRTX_CONV_PATCH")) != 0;
+            if (allow_patch && fp16 && patch_possible(t)) push(bn, t.bk, 128, 1, 3);
+#endif
             // The 3x3 row-reuse kernel is a candidate only on request (TRTX_TACTICS_R3=1).  Round 3 found engines that had chosen it
             // returning results that differ in the last fp16 places between execution contexts running side by side (and only then:
             // tests/test_gpu_multi_context.py failed in 4 of 6 runs with it among the candidates, 0 of 12 without) - an ordering hazard in
@@ -1515,7 +1692,7 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     const bool fp16 = !a0.in_i8 && !a0.out_i8 && !a0.res_i8;
     if (a0.bn == 256) return conv_gemm256_f16(a0, s);
     // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel (t_ws: 0 = where supported, 1 = never, 2 = asked for)
-    if (fp16 && a0.t_ws != 1 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);
+    if (fp16 && a0.t_ws != 1 && a0.t_ws != 3 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);   // (3 = the resident-patch kernel, below)
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
@@ -1542,6 +1719,10 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
             const int v = a.t_r3 ? a.t_r3 : r3_forced();
             st = a.bk == 64 ? launch_r3<64, 2>(a, in_bytes, w_bytes, s)
                             : (v == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
+#endif
+#ifdef TRTX_EXPERIMENTAL_PATCH
+        } else if (a.t_ws == 3 && patch_possible(a)) {
+            st = launch_patch(a, in_bytes, w_bytes, s);
 #endif
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
@@ -1570,7 +1751,7 @@ bool plain_gemm(const ConvArgs& a) {   // the ONE instantiation's condition (lau
 // what the single-problem dispatch would run for this layer must be the plain 128-row / 32-wide-step main kernel
 bool group_member_ok(const ConvArgs& a) {
     return conv_igemm_supported(a) && !a.in_i8 && !a.out_i8 && !a.res_i8 && !a.up_C && !a.scalar_out && a.CinK != 16 && a.bk == 32 && (a.bn == 64 || a.bn == 80) &&
-           (a.bm == 0 || a.bm == 128) && a.t_r3 == 0 && a.t_wsk != 2 && (double)a.N * a.H * a.W * a.ld_in * 2.0 < 2.0e9;
+           (a.bm == 0 || a.bm == 128) && a.t_r3 == 0 && a.t_wsk != 2 && a.t_ws != 3 && (double)a.N * a.H * a.W * a.ld_in * 2.0 < 2.0e9;
 }
 template <int NFRAG, bool RS, bool ONE>
 void launch_group(const ConvGroupArgs& g, hipStream_t s) {

@@ -166,7 +166,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
             got = y.float().cpu()
             err = (got - ref).abs().max().item()
             assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"tactic {t}: max err {err} (scale {scale})"
-            if t[3] == 1 and t[4] == 1 and t[5] == 0:  # plain implicit-GEMM tiles
+            if t[3] == 1 and t[4] in (1, 3) and t[5] == 0:  # plain implicit-GEMM tiles (ws 3: the resident-patch kernel of experimental builds walks K in the same order)
                 if exact is None:
                     exact = got
                 else:
