@@ -1014,8 +1014,12 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
 // NOT YET RUN ON A GPU (written at the end of round 4 without GPU minutes): compiled only with the define; without it no tactic names it.
 #ifdef TRTX_EXPERIMENTAL_PATCH
 template <int NFRAG, int KC, int MI>
-__global__ __launch_bounds__(256) void conv_patch_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int tiles_x, int tiles_y,
-                                                             int total_tiles, int xcd_chunk) {
+constexpr int patch_lds_bytes() {
+    return KC * (4 * MI + 2) * patchidx::kPitch * patchidx::kPixelBytes + 3 * ((16 * NFRAG + 63) / 64) * 64 * 64;
+}
+// one output tile (T) of one problem (p); `smem` is the workgroup's patch_lds_bytes<NFRAG, KC, MI>() of LDS
+template <int NFRAG, int KC, int MI>
+__device__ __forceinline__ void conv_patch_tile(const ConvArgs& p, unsigned in_bytes, unsigned w_bytes, const patchidx::Tile& T, char* smem) {
     namespace px = patchidx;
     constexpr int BN = 16 * NFRAG;
     constexpr int TH = 4 * MI;
@@ -1029,17 +1033,11 @@ __global__ __launch_bounds__(256) void conv_patch_f16_kernel(const ConvArgs p, u
     constexpr int NK = 9 * KC;
     static_assert(MI == 2 || MI == 4, "8- or 16-row tiles");
     static_assert(PLANE % 1024 == 0, "a plane is a whole number of DMA pieces");
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    static_assert(LDS_BYTES == patch_lds_bytes<NFRAG, KC, MI>(), "the entry points allocate what the tile function uses");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
-    if (xcd_chunk) {
-        tile = (tile & 7) * xcd_chunk + (tile >> 3);
-        if (tile >= total_tiles) return;
-    }
-    const px::Tile T = px::tile_of(tile, tiles_n, tiles_x, tiles_y, TH, BN);
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
@@ -1128,6 +1126,41 @@ __global__ __launch_bounds__(256) void conv_patch_f16_kernel(const ConvArgs p, u
     });
 }
 
+template <int NFRAG, int KC, int MI>
+__global__ __launch_bounds__(256) void conv_patch_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int tiles_x, int tiles_y,
+                                                             int total_tiles, int xcd_chunk) {
+    __shared__ __attribute__((aligned(16))) char smem[patch_lds_bytes<NFRAG, KC, MI>()];
+    int tile = blockIdx.x;
+    if (xcd_chunk) {
+        tile = (tile & 7) * xcd_chunk + (tile >> 3);
+        if (tile >= total_tiles) return;
+    }
+    conv_patch_tile<NFRAG, KC, MI>(p, in_bytes, w_bytes, patchidx::tile_of(tile, tiles_n, tiles_x, tiles_y, 4 * MI, 16 * NFRAG), smem);
+}
+
+// Grouped launch: 2..4 independent layers of one instantiation (the detect head's second 3x3 of every level: 64 -> 64 and 80 -> 80 at 80 / 40 / 20
+// pixels) in one grid; the tile -> problem mapping of conv_igemm_group_f16_kernel (per-problem XCD chunks, the host orders the problems).
+struct ConvPatchGroupArgs {
+    int n;
+    int slot_start[kMaxConvGroup + 1];
+    int chunk[kMaxConvGroup], tiles[kMaxConvGroup], tiles_n[kMaxConvGroup], tiles_x[kMaxConvGroup], tiles_y[kMaxConvGroup];
+    unsigned in_bytes[kMaxConvGroup], w_bytes[kMaxConvGroup];
+    ConvArgs p[kMaxConvGroup];
+};
+template <int NFRAG, int KC, int MI>
+__global__ __launch_bounds__(256) void conv_patch_group_f16_kernel(const ConvPatchGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[patch_lds_bytes<NFRAG, KC, MI>()];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int pid = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxConvGroup; ++k) pid += (k < g.n && slot >= g.slot_start[k]) ? 1 : 0;
+    pid = __builtin_amdgcn_readfirstlane(pid);
+    const int local = xcd * g.chunk[pid] + (slot - g.slot_start[pid]);
+    if (local >= g.tiles[pid]) return;
+    conv_patch_tile<NFRAG, KC, MI>(g.p[pid], g.in_bytes[pid], g.w_bytes[pid],
+                                   patchidx::tile_of(local, g.tiles_n[pid], g.tiles_x[pid], g.tiles_y[pid], 4 * MI, 16 * NFRAG), smem);
+}
+
 template <int NFRAG, int KC>
 void launch_patch_mi(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, int th, hipStream_t s) {
     const int tiles_n = a.Cout_pad / (16 * NFRAG), tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th;
@@ -1159,6 +1192,59 @@ int32_t launch_patch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hip
         case 128: return launch_patch_kc<8>(a, in_bytes, w_bytes, th, s);
         default: return TRTX_ERR_UNSUPPORTED;
     }
+}
+template <int NFRAG, int KC>
+void launch_patch_group_mi(const ConvPatchGroupArgs& g, int th, hipStream_t s) {
+    if (th == 16) TRTX_LAUNCH((conv_patch_group_f16_kernel<NFRAG, KC, 4>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g);
+    else TRTX_LAUNCH((conv_patch_group_f16_kernel<NFRAG, KC, 2>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g);
+}
+bool patch_possible(const ConvArgs& a);   // (defined with the other tactic predicates below)
+// every member a resident-patch layer of ONE instantiation (column-tile width, channel slices, tile rows)?
+bool patch_group_possible(const ConvArgs* a, int n) {
+    for (int k = 0; k < n; ++k)
+        if (!patch_possible(a[k]) || a[k].bn != a[0].bn || a[k].CinK != a[0].CinK || patch_tile_rows(a[k]) != patch_tile_rows(a[0]) || a[k].bn == 128 ||
+            (double)a[k].N * a[k].H * a[k].W * a[k].ld_in * 2.0 >= 2.0e9)
+            return false;
+    return true;
+}
+int32_t launch_patch_group(const ConvArgs* a, int n, hipStream_t s) {
+    ConvPatchGroupArgs g{};
+    g.n = n;
+    const int th = patch_tile_rows(a[0]);
+    int order[kMaxConvGroup];   // same k-steps per tile everywhere: the big maps first
+    for (int k = 0; k < n; ++k) order[k] = k;
+    std::sort(order, order + n, [&](int x, int y) {
+        const long mx = (long)a[x].N * a[x].H * a[x].W, my = (long)a[y].N * a[y].H * a[y].W;
+        return mx != my ? mx > my : x < y;
+    });
+    int slots = 0;
+    for (int k = 0; k < n; ++k) {
+        const ConvArgs& ak = a[order[k]];
+        g.p[k] = ak;
+        g.p[k].M = ak.N * ak.Ho * ak.Wo;
+        g.tiles_n[k] = ak.Cout_pad / ak.bn;
+        g.tiles_x[k] = (ak.W + 15) / 16;
+        g.tiles_y[k] = (ak.H + th - 1) / th;
+        g.tiles[k] = ak.N * g.tiles_y[k] * g.tiles_x[k] * g.tiles_n[k];
+        g.chunk[k] = (g.tiles[k] + 7) / 8;
+        g.slot_start[k] = slots;
+        slots += g.chunk[k];
+        g.in_bytes[k] = (unsigned)((((size_t)ak.N * ak.H * ak.W - 1) * ak.ld_in + ak.Cin) * 2);
+        g.w_bytes[k] = (unsigned)((size_t)ak.Cout_pad * ak.Kpad * 2);
+    }
+    for (int k = n; k <= kMaxConvGroup; ++k) g.slot_start[k] = slots;
+    const int kc = a[0].CinK / 32;
+#define TRTX_PG(NF)                                           \
+    switch (kc) {                                             \
+        case 1: launch_patch_group_mi<NF, 1>(g, th, s); break; \
+        case 2: launch_patch_group_mi<NF, 2>(g, th, s); break; \
+        case 3: launch_patch_group_mi<NF, 3>(g, th, s); break; \
+        case 4: launch_patch_group_mi<NF, 4>(g, th, s); break; \
+        default: return TRTX_ERR_UNSUPPORTED;                  \
+    }
+    if (a[0].bn == 64) { TRTX_PG(4) } else { TRTX_PG(5) }
+#undef TRTX_PG
+    return TRTX_OK;
 }
 #endif  // TRTX_EXPERIMENTAL_PATCH
 
@@ -1772,6 +1858,14 @@ bool conv_igemm_group_supported(const ConvArgs* a, int n) {
 
 int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     if (!conv_igemm_group_supported(a, n)) return TRTX_ERR_UNSUPPORTED;
+#ifdef TRTX_EXPERIMENTAL_PATCH
+    // TRTX_CONV_PATCH=2: groups whose members are all resident-patch layers of one instantiation run on that kernel (groups are not tuned: an A/B switch)
+    static const bool patch_groups = getenv("TRTX_CONV_PATCH") != nullptr && atoi(getenv("TRTX_CONV_PATCH")) >= 2;
+    if (patch_groups && patch_group_possible(a, n)) {
+        const int32_t st = launch_patch_group(a, n, s);
+        return st != TRTX_OK ? st : check_launch("conv_patch_group_f16");
+    }
+#endif
     ConvGroupArgs g{};
     g.n = n;
     int order[kMaxConvGroup];   // falling k-steps per tile (ties: more rows first)

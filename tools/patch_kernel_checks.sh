@@ -29,11 +29,14 @@ export TRTX_HIP_LIB=$L/libtrtx_hip.so TRTX_CONV_PATCH=1
 timeout 400 python -m pytest tests/test_gpu_conv.py -m gpu -q -x 2>&1 | tail -5 | tee $O/pytest_conv.txt
 timeout 300 python -m pytest tests/test_gpu_multi_context.py tests/test_gpu_tactics.py -m gpu -q 2>&1 | tail -3 | tee $O/pytest_ctx.txt
 timeout 300 python tools/conv_shape_ab.py 2>&1 | tee $O/shape_ab.txt
+# grouped launches on the patch kernel against the same engine with the groups on the main kernel: every output bit for bit (one context, then three in flight)
+TRTX_CONV_PATCH=2 timeout 200 python -m pytest tests/test_gpu_engine.py -m gpu -q -k "group" 2>&1 | tail -3 | tee $O/pytest_groups.txt
 for round in 1 2; do
-  for v in product patch patch_ungrouped; do
+  for v in product patch patch_groups patch_ungrouped; do
     case $v in
       product) unset TRTX_HIP_LIB TRTX_CONV_PATCH TRTX_GROUP_CONVS;;
       patch) export TRTX_HIP_LIB=$L/libtrtx_hip.so TRTX_CONV_PATCH=1; unset TRTX_GROUP_CONVS;;
+      patch_groups) export TRTX_HIP_LIB=$L/libtrtx_hip.so TRTX_CONV_PATCH=2; unset TRTX_GROUP_CONVS;;   # ... and the grouped launches whose members all qualify (the head's second 3x3s)
       patch_ungrouped) export TRTX_HIP_LIB=$L/libtrtx_hip.so TRTX_CONV_PATCH=1 TRTX_GROUP_CONVS=0;;
     esac
     TRTX_TACTIC_CACHE=/tmp/tc_$v.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${v}_$round.json 2> /dev/null
