@@ -75,17 +75,22 @@ k:
 def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
     with tempfile.TemporaryDirectory() as tmp:
         def compile_unit(u):
+            # "conv_igemm+experimental": the same file with the two experimental kernels compiled in (the row-reuse kernel with its fix, the resident-patch
+            # kernel) - they are not in the product library, and they must not lose the property while they wait for their GPU checks
+            name, defs = (u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DTRTX_EXPERIMENTAL_PATCH"]) if "+" in u else (u, [])
             out = os.path.join(tmp, u + ".s")
             subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", "-mllvm",
-                                   "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels", u + ".hip")],
+                                   "-amdgpu-mfma-vgpr-form", *defs, "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels", name + ".hip")],
                                   stderr=subprocess.DEVNULL)
             return out
-        with ThreadPoolExecutor(len(UNITS)) as ex:
-            outs = list(ex.map(compile_unit, UNITS))
-        total = 0
-        for u, path in zip(UNITS, outs):
+        units = UNITS + ["conv_igemm+experimental"]
+        with ThreadPoolExecutor(len(units)) as ex:
+            outs = list(ex.map(compile_unit, units))
+        counts = {}
+        for u, path in zip(units, outs):
             n, bad = scan.scan(path)
-            total += n
+            counts[u] = n
             assert n > 0, f"{u}: no kernel found in the listing"
             assert not bad, f"{u}: barrier reached with LDS reads in flight in {bad}"
-        assert total >= 250   # conv_igemm alone instantiates 218
+        assert sum(counts[u] for u in UNITS) >= 250   # conv_igemm alone instantiates 218
+        assert counts["conv_igemm+experimental"] >= counts["conv_igemm"] + 12 + 40   # + the row-reuse and the resident-patch instantiations
