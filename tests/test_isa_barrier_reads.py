@@ -77,13 +77,17 @@ def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
         def compile_unit(u):
             # "conv_igemm+experimental": the same file with the two experimental kernels compiled in (the row-reuse kernel with its fix, the resident-patch
             # kernel) - they are not in the product library, and they must not lose the property while they wait for their GPU checks
-            name, defs = (u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DTRTX_EXPERIMENTAL_PATCH"]) if "+" in u else (u, [])
+            name, defs = u, []
+            if u.endswith("+experimental"):
+                name, defs = u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DTRTX_EXPERIMENTAL_PATCH"]
+            elif u.endswith("+round3_r3"):   # the row-reuse kernel as round 3 shipped it (no lgkmcnt(0) before the barrier): the scan must FIND its hazard
+                name, defs = u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DR3_VARIANT=32"]
             out = os.path.join(tmp, u + ".s")
             subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", "-mllvm",
                                    "-amdgpu-mfma-vgpr-form", *defs, "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels", name + ".hip")],
                                   stderr=subprocess.DEVNULL)
             return out
-        units = UNITS + ["conv_igemm+experimental"]
+        units = UNITS + ["conv_igemm+experimental", "conv_igemm+round3_r3"]
         with ThreadPoolExecutor(len(units)) as ex:
             outs = list(ex.map(compile_unit, units))
         counts = {}
@@ -91,6 +95,11 @@ def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
             n, bad = scan.scan(path)
             counts[u] = n
             assert n > 0, f"{u}: no kernel found in the listing"
+            if u.endswith("+round3_r3"):
+                # fails-before-the-fix: exactly the three-stage instantiations of the row-reuse kernel (<NFRAG, 32, 2, 3>), nothing else
+                names = sorted(name for name, _ in bad)
+                assert len(names) == 4 and all("conv_igemm_r3_f16_kernel" in x and x.endswith("ELi32ELi2ELi3EEEvNS_8ConvArgsEjjiii") for x in names), names
+                continue
             assert not bad, f"{u}: barrier reached with LDS reads in flight in {bad}"
         assert sum(counts[u] for u in UNITS) >= 250   # conv_igemm alone instantiates 218
         assert counts["conv_igemm+experimental"] >= counts["conv_igemm"] + 12 + 40   # + the row-reuse and the resident-patch instantiations

@@ -31,6 +31,8 @@ for st in 1 2; do for rep in 1 2 3; do
 done; done | tee $O/forced.txt
 TRTX_TUNE=0 TRTX_GROUP_CONVS=0 TRTX_FORCE_R3=1 timeout 120 python tools/coscheduling_bisect.py 20 poison 2>&1 | grep "serial-repeatable" | sed "s/^/forced, 20 rounds, poisoned LDS: /" | tee -a $O/forced.txt
 TRTX_TACTICS_R3=1 timeout 400 python -m pytest tests/test_gpu_conv.py tests/test_gpu_multi_context.py tests/test_gpu_tactics.py -m gpu -q 2>&1 | tail -3 | tee $O/pytest.txt
+# VERDICT r3 item 3's bar: 20 consecutive green runs of the three-context test with the kernel among the tactics
+for i in $(seq 1 20); do TRTX_TACTICS_R3=1 timeout 60 python -m pytest tests/test_gpu_multi_context.py -m gpu -q -k "yolov8n_three_contexts_in_flight" 2>&1 | tail -1; done | sort | uniq -c | tee $O/twenty_runs.txt
 for round in 1 2; do
   for v in product r3 r3_ungrouped; do
     case $v in
