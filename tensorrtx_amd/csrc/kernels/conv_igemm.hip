@@ -1165,8 +1165,13 @@ template <int NFRAG, int KC>
 void launch_patch_mi(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, int th, hipStream_t s) {
     const int tiles_n = a.Cout_pad / (16 * NFRAG), tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th;
     const int total = a.N * tiles_y * tiles_x * tiles_n, chunk = (total + 7) / 8;
-    if (th == 16) TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 4>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
-    else TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+    if constexpr (KC <= 4) {   // 16-row tiles exist up to four planes (LDS)
+        if (th == 16) {
+            TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 4>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+            return;
+        }
+    }
+    TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 2>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
 }
 template <int NFRAG>
 int32_t launch_patch_kc(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, int th, hipStream_t s) {
@@ -1175,6 +1180,7 @@ int32_t launch_patch_kc(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, 
         case 2: launch_patch_mi<NFRAG, 2>(a, in_bytes, w_bytes, th, s); break;
         case 3: launch_patch_mi<NFRAG, 3>(a, in_bytes, w_bytes, th, s); break;
         case 4: launch_patch_mi<NFRAG, 4>(a, in_bytes, w_bytes, th, s); break;
+        case 8: launch_patch_mi<NFRAG, 8>(a, in_bytes, w_bytes, 8, s); break;   // 256 input channels: eight planes of an 8-row patch = 120 KB, one workgroup per CU
         default: return TRTX_ERR_UNSUPPORTED;
     }
     return TRTX_OK;
@@ -1202,7 +1208,7 @@ bool patch_possible(const ConvArgs& a);   // (defined with the other tactic pred
 // every member a resident-patch layer of ONE instantiation (column-tile width, channel slices, tile rows)?
 bool patch_group_possible(const ConvArgs* a, int n) {
     for (int k = 0; k < n; ++k)
-        if (!patch_possible(a[k]) || a[k].bn != a[0].bn || a[k].CinK != a[0].CinK || patch_tile_rows(a[k]) != patch_tile_rows(a[0]) || a[k].bn == 128 ||
+        if (!patch_possible(a[k]) || a[k].CinK > 128 || a[k].bn != a[0].bn || a[k].CinK != a[0].CinK || patch_tile_rows(a[k]) != patch_tile_rows(a[0]) || a[k].bn == 128 ||
             (double)a[k].N * a[k].H * a[k].W * a[k].ld_in * 2.0 >= 2.0e9)
             return false;
     return true;
@@ -1628,10 +1634,10 @@ int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStr
 }
 #endif
 #ifdef TRTX_EXPERIMENTAL_PATCH
-// the resident-patch kernel: fp16 3x3 stride 1 pad 1 over at most 128 input channels, 16-byte output stores, 64 / 80 / 128-wide column tiles
+// the resident-patch kernel: fp16 3x3 stride 1 pad 1 over at most 128 (or exactly 256) input channels, 16-byte output stores, 64 / 80 / 128-wide column tiles
 bool patch_possible(const ConvArgs& a) {
     return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
-           a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 && a.bk == 32 && a.CinK % 32 == 0 && a.CinK <= 128 && a.Cin % 8 == 0 && a.Kpad == 9 * a.CinK &&
+           a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 && a.bk == 32 && a.CinK % 32 == 0 && (a.CinK <= 128 || a.CinK == 256) && a.Cin % 8 == 0 && a.Kpad == 9 * a.CinK &&
            !a.scalar_out && a.Ho == a.H && a.Wo == a.W && (a.bn == 64 || a.bn == 80 || a.bn == 128) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128) &&
            a.t_r3 == 0;
 }

@@ -51,7 +51,7 @@ def _conv_ref(x, w):
     return out
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,bn,mi", [(2, 19, 21, 64, 64, 64, 2), (1, 20, 16, 64, 128, 64, 4), (1, 9, 33, 80, 80, 80, 2), (1, 17, 17, 32, 128, 128, 4)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,bn,mi", [(2, 19, 21, 64, 64, 64, 2), (1, 20, 16, 64, 128, 64, 4), (1, 9, 33, 80, 80, 80, 2), (1, 17, 17, 32, 128, 128, 4), (1, 10, 18, 256, 64, 64, 2)])
 def test_lane_level_replay_of_the_patch_kernel_is_the_convolution(shim, N, H, W, Cin, Cout, bn, mi):
     L = shim
     rng = np.random.default_rng(N * 1000 + H * 10 + Cin)
