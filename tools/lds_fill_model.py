@@ -49,7 +49,16 @@ def main(model="yolov8n", B=32, H=640, W=640):
             a, b = M * cink * 2 * 1.3 * ct, 0.0
         a_row = a / 3 if (kh == 3 and kw == 3 and s1 and not ws) else a
         a_patch = M * cink * 2 * 1.3 * ct if (kh == 3 and kw == 3 and s1) else a
-        rows.append(dict(name=o["name"][-24:] + (" [ws]" if ws else ""), cin=cin, cout=cout, k=kh, hw=Ho, bn=bn, a=a, b=b, a_row=a_row, a_patch=a_patch, hbm=o["bytes"] * B,
+        # the resident-patch kernel AS WRITTEN (conv_igemm.hip, experimental build): 64 / 80 / 128-wide column tiles, <= 128 or exactly 256 input channels;
+        # 16-row tiles (B per 256 pixels) up to 64 channels on maps of 16+ rows, else 8-row tiles; patch = (TH + 2) x 18 pixels per TH x 16 outputs
+        elig = kh == 3 and kw == 3 and s1 and not ws and bn in (64, 80, 128) and cink % 32 == 0 and (cink <= 128 or cink == 256)
+        if elig:
+            th = 16 if (cink <= 64 and Ho >= 16) else 8
+            a_kern = M * cink * 2 * ((th + 2) * 18 / (th * 16.0)) * ct
+            b_kern = math.ceil(M / (th * 16)) * coutp * K * 2
+        else:
+            a_kern, b_kern = a, b
+        rows.append(dict(name=o["name"][-24:] + (" [ws]" if ws else (" [p]" if elig else "")), a_kern=a_kern, b_kern=b_kern, cin=cin, cout=cout, k=kh, hw=Ho, bn=bn, a=a, b=b, a_row=a_row, a_patch=a_patch, hbm=o["bytes"] * B,
                          flop=o["flops"] * B))
 
     for o in d["ops"]:
@@ -66,6 +75,7 @@ def main(model="yolov8n", B=32, H=640, W=640):
     for label, a, b in (("row reuse on the 3x3 stride-1 layers", T("a_row"), T("b")), ("resident patch on the 3x3 stride-1 layers", T("a_patch"), T("b")),
                         ("resident patch + 256-row tiles", T("a_patch"), T("b") / 2)):
         print(f"  with {label:44s} A {a / 1e9:.2f} + B {b / 1e9:.2f} = {(a + b) / 1e9:6.2f} GB")
+    print(f"  with the resident-patch kernel as written, on the layers it takes ([p] below): A {T('a_kern') / 1e9:.2f} + B {T('b_kern') / 1e9:.2f} = {(T('a_kern') + T('b_kern')) / 1e9:6.2f} GB")
     for rate in (15, 30, 60):
         print(f"fill time at {rate:2d} B/clk per CU x 256 CUs x 2.4 GHz: today {(T('a') + T('b')) / (rate * 256 * 2.4e9) * 1e3:.3f} ms")
     print("\nlargest layers (MB through the fill path: A, B | algorithmic HBM MB | GFLOP)")
