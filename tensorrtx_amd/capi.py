@@ -248,6 +248,49 @@ def conv2d_nhwc_f16(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", re
     return out
 
 
+# ---------------------------------------------------------------------------------------------------- fp32 engines: conv on the fp32 MFMA (tests / tools)
+def pack_conv_weights_f32(w_kcrs, cin_pad=None, ch_scale=None):
+    """Host: KCRS fp32 numpy -> (packed float32 [Cout_pad, Kpad], cout_pad, kpad, cink) for conv2d_nhwc_f32."""
+    import numpy as np
+    L = lib()
+    w = np.ascontiguousarray(w_kcrs, dtype=np.float32)
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin_pad or (cin + 3) // 4 * 4
+    cp, kp, ck = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(L.trtx_conv_packed_dims_f32(cout, cin_pad, kh, kw, ctypes.byref(cp), ctypes.byref(kp), ctypes.byref(ck)), "trtx_conv_packed_dims_f32")
+    packed = np.zeros((cp.value, kp.value), dtype=np.float32)
+    sc = np.ascontiguousarray(ch_scale, dtype=np.float32) if ch_scale is not None else None
+    check(L.trtx_conv_pack_weights_f32(w.ctypes.data_as(ctypes.c_void_p), cout, cin, kh, kw, cin_pad,
+                                       sc.ctypes.data_as(ctypes.c_void_p) if sc is not None else None,
+                                       packed.ctypes.data_as(ctypes.c_void_p)), "trtx_conv_pack_weights_f32")
+    return packed, cp.value, kp.value, ck.value
+
+
+def conv2d_nhwc_f32(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", residual=None, act2="none", out=None, out_ld=None, tile=None):
+    """Single fused conv launch on NHWC fp32 tensors (x: [N,H,W,Cin] CUDA float32, Cin % 4 == 0); tile = (bn, bm, operand path) or None."""
+    import torch
+    L = lib()
+    N, H, W, Cin = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    ld_out = out_ld or out.shape[-1]
+    t2 = (ctypes.c_int32 * 3)(*tile) if tile is not None else None
+    check(L.trtx_op_conv2d_nhwc_f32(_p(x), N, H, W, Cin, x.stride(2), _p(wpacked), _p(bias), _p(out), cout, ld_out, kh, kw, stride, stride, pad, pad,
+                                    ACT[act1], _p(residual), residual.stride(2) if residual is not None else 0, ACT[act2], t2, _stream()),
+          "trtx_op_conv2d_nhwc_f32")
+    return out
+
+
+def conv2d_tactics_f32(N, H, W, Cin, Cout, k, stride, pad, residual=False, ld_in=None, ld_out=None, ld_res=None, max_out=32):
+    """The launch configurations (bn, bm, operand path) of one fp32 conv layer (host only); [0] is the launcher's own choice."""
+    arr = (ctypes.c_int32 * (3 * max_out))()
+    n = lib().trtx_op_conv2d_tactics_f32(N, H, W, Cin, ld_in or Cin, Cout, ld_out or Cout, k, k, stride, stride, pad, pad, 1 if residual else 0,
+                                         (ld_res or Cout) if residual else 0, arr, max_out)
+    return [(arr[3 * i], arr[3 * i + 1], arr[3 * i + 2]) for i in range(n)]
+
+
 # ---------------------------------------------------------------------------------------------------- fused conv chains (tests / tools)
 def pack_chain_weights_f16(w_kcrs, ch_scale=None):
     """Host: KCRS fp32 numpy [Cout, Cin, k, k] -> packed uint16 [Cout, k*k*ceil(Cin/32)*32] for trtx_op_conv_chain_nhwc_f16."""

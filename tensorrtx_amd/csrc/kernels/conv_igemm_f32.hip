@@ -1,0 +1,222 @@
+// The convolutions of an fp32 engine on the matrix cores: NHWC fp32 activations, fp32 weights packed [Cout_pad][Kpad], v_mfma_f32_16x16x4_f32
+// (fp32 operands, fp32 accumulate: bit-for-bit a k-ordered fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s on the chip - MI355X_MICROARCH.md).
+//
+// Why this exists.  The reference builds every model in one of three precisions (yolov8/include/config.h:1-3 USE_FP16 / USE_FP32 / USE_INT8,
+// yolov8/src/model.cpp:314-324; retinaface/retina_r50.cpp:12), and BASELINE's tolerance - boxes within 1e-3 IoU, logits within 1e-4 of the
+// reference's fp32 outputs - is a property of fp32 arithmetic: no engine that stores weights or activations in fp16 reaches it (DESIGN 2,
+// profiles/r04_fp16_budget.txt).  Until round 5 the build without kFP16 ran conv_direct_kernel (nhwc_ops.hip): one thread per output, a scalar
+// fmaf loop, no MFMA, no LDS.  This file puts that build on the implicit-GEMM skeleton of igemm_tile.h.
+//
+// How.  An fp32 k-step is 16 channels = a 64-byte LDS row - byte for byte the geometry of the fp16 kernel's 32-half step.  The launcher hands the
+// kernel its input-side geometry in 2-byte units (Cin, ld_in, CinK, K, Kpad, up_C, up_ld doubled - what the int8 path does with pairs of int8
+// channels), so the whole operand path is the fp16 one: range-checked LDS-DMA gather, XOR-swizzled rows, tap masks, three stages, one barrier
+// per step, plain-GEMM addressing for 1x1 layers, the folded upsample, two filter taps per step for Cin <= 8.  What differs is compute() - one
+// 16-byte fragment read feeds four MFMAs of 32 cycles each - and the epilogue, which needs no LDS: a lane's accumulator fragment is four
+// consecutive channels of one pixel, a 16-byte fp32 store (conv_epilogue_f32).
+// The kernel is MFMA-bound by construction: a 128 x 64 tile issues 32 MFMAs = 1024 cycles per k-step and wave against ~150 other instructions,
+// 12 KB of LDS fill and 6 fragment reads; the 20 - 40 % of the fp16 kernels' time that is LDS fill, address arithmetic and barriers sits in the
+// shadow of the matrix pipe here.  Every tile shape sums K in the same order: all tactics return the same bits.
+#include "igemm_tile.h"
+
+namespace trtx {
+namespace {
+
+// kernel-side view of an fp32 launch: the input side in 2-byte units (see the header)
+ConvArgs kernel_units(const ConvArgs& a) {
+    ConvArgs k = a;
+    k.Cin = 2 * a.Cin; k.ld_in = 2 * a.ld_in; k.CinK = 2 * a.CinK; k.K = 2 * a.K; k.Kpad = 2 * a.Kpad;
+    k.up_C = 2 * a.up_C; k.up_ld = 2 * a.up_ld;
+    k.bk = 32;
+    return k;
+}
+
+bool plain_gemm_f32(const ConvArgs& a) {
+    return a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K && a.up_C == 0;
+}
+
+// operands through registers (global -> VGPR -> ds_write, two LDS stages) instead of LDS-DMA (three stages): ConvArgs::t_ws == 5, same bits.  Instantiated for
+// the 64- and 128-row tiles of the general and the plain-GEMM walk
+bool rs_exists(const ConvArgs& a, int bn, int bm) { return a.CinK != 8 && a.up_C == 0 && bm <= 128 && bn >= 32; }
+
+template <int NFRAG, int MI>
+void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    const int BN = 16 * NFRAG, BMT = 64 * MI;
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.Cout_pad / BN;
+    const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
+    const dim3 grid(chunk * 8), block(256);
+#ifdef TRTX_CONV_ABLATE   // timing experiments only (tools/f32_ablation.sh): TRTX_CONV_DBG as in the fp16 kernel, TRTX_F32_NST = 4 / 6 LDS stages (128 x 64 tile)
+    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
+    static const int nst = getenv("TRTX_F32_NST") ? atoi(getenv("TRTX_F32_NST")) : 0;
+    if constexpr (MI == 2 && NFRAG == 4) {
+        if (a.CinK != 8 && !a.up_C && !plain_gemm_f32(a) && a.t_ws != 5) {
+            if (nst == 4) TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 4, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            else if (nst == 6) TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 6, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            else TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, dbg);
+            return;
+        }
+    }
+#endif
+    if constexpr (MI <= 2 && NFRAG >= 2) {
+        if (a.t_ws == 5 && rs_exists(a, BN, BMT)) {
+            if (plain_gemm_f32(a))
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, true, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            else
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, true, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            return;
+        }
+    }
+    if (a.CinK == 8) {   // two filter taps per k-step (the 3-channel stems, padded to 4)
+        if constexpr (MI == 2 && NFRAG <= 4)
+            TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 2, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+    } else if (a.up_C > 0) {
+        if constexpr (MI <= 2 && NFRAG >= 2)
+            TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, true, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+    } else if (plain_gemm_f32(a)) {
+        TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+    } else {
+        TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+    }
+}
+
+// which (column-tile width, rows per tile) pairs are instantiated
+bool tile_exists(const ConvArgs& a, int bn, int bm) {
+    if (bn != 16 && bn != 32 && bn != 64 && bn != 80 && bn != 128) return false;
+    if (bm != 64 && bm != 128 && bm != 256) return false;
+    if (bm == 256 && bn == 128) return false;               // 128 accumulator registers + 48 of fragments: no
+    if (a.CinK == 8) return bm == 128 && bn <= 64;
+    if (a.up_C > 0) return bm <= 128 && bn >= 32;
+    return true;
+}
+
+template <int MI>
+int32_t launch_f32_bn(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    switch (a.bn) {
+        case 16: launch_f32<1, MI>(a, k, in_bytes, w_bytes, s); break;
+        case 32: launch_f32<2, MI>(a, k, in_bytes, w_bytes, s); break;
+        case 64: launch_f32<4, MI>(a, k, in_bytes, w_bytes, s); break;
+        case 80: launch_f32<5, MI>(a, k, in_bytes, w_bytes, s); break;
+        case 128:
+            if constexpr (MI <= 2) { launch_f32<8, MI>(a, k, in_bytes, w_bytes, s); break; }
+            return TRTX_ERR_UNSUPPORTED;
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+    return TRTX_OK;
+}
+
+// The untuned tile of a layer.  The kernel is bound by the matrix pipe, so what a tile shape decides is how evenly the 256 CUs are loaded
+// (tiles per CU: the last round of a launch with 1.2 tiles per CU runs at 20 % occupancy) against what a smaller tile re-reads (the weight tile
+// per row tile, the A tile per column tile - L2 traffic that stays far below the fill rate here): the largest tile that still leaves >= 4 tiles
+// per CU, otherwise the smallest instantiated one.
+void default_tile(const ConvArgs& a, int* bn_out, int* bm_out) {
+    static const int bns[5] = {128, 80, 64, 32, 16};
+    static const int bms[3] = {256, 128, 64};
+    int best_bn = 0, best_bm = 0;
+    long best_area = 0;
+    int small_bn = 0, small_bm = 0;
+    long small_tiles = -1;
+    for (int bn : bns) {
+        if (a.Cout_pad % bn) continue;
+        if (bn <= 32 && a.Cout_pad > 2 * bn && a.Cout_pad % 64 == 0) continue;   // narrow tiles only where the layer is narrow
+        for (int bm : bms) {
+            if (!tile_exists(a, bn, bm)) continue;
+            const long tiles = ((long)a.M + bm - 1) / bm * (a.Cout_pad / bn);
+            const long area = (long)bn * bm;
+            if (tiles >= 4 * 256 && area > best_area) { best_area = area; best_bn = bn; best_bm = bm; }
+            if (tiles > small_tiles) { small_tiles = tiles; small_bn = bn; small_bm = bm; }
+        }
+    }
+    *bn_out = best_bn ? best_bn : small_bn;
+    *bm_out = best_bn ? best_bm : small_bm;
+}
+
+}  // namespace
+
+int conv_igemm_f32_pick_cink(int cin) { return cin <= 8 ? 8 : (cin + 15) / 16 * 16; }
+
+bool conv_igemm_f32_supported(const ConvArgs& a) {
+    if (!a.f32 || a.in_i8 || a.out_i8 || a.res_i8) return false;
+    if (a.groups != 1 || a.dil_h != 1 || a.dil_w != 1) return false;
+    if (a.Cin % 4 || a.ld_in % 4) return false;                      // 16-byte channel chunks
+    if (a.CinK != conv_igemm_f32_pick_cink(a.Cin) || a.K != a.kh * a.kw * a.CinK || a.Kpad != (a.K + 15) / 16 * 16) return false;
+    if (a.CinK == 8 ? (a.kh > 30 || a.kw > 30) : (a.kh * a.kw > kMaxTaps)) return false;   // two taps per step: row and column masks are separate words
+    if (a.Cout_pad % 16 || a.Cout_pad < a.Cout) return false;
+    const bool out_vec = a.ld_out % 4 == 0 && a.Cout % 4 == 0 && (!a.residual || a.ld_res % 4 == 0);
+    if (!out_vec && !a.scalar_out) return false;
+    if (a.up_C != 0 && (a.up_C < 0 || a.kh != 1 || a.kw != 1 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h || a.pad_w || a.up_C % 16 || a.up_C >= a.Cin ||
+                        a.H != 2 * a.up_H || a.W != 2 * a.up_W || a.up_ld % 4 || a.CinK == 8))
+        return false;
+    if ((double)a.H * a.W * a.ld_in * 4.0 >= 2.0e9 || (double)a.Cout_pad * a.Kpad * 4.0 >= 2.0e9) return false;
+    if (a.bn || a.bm) {   // a tactic was named
+        const int bm = a.bm ? a.bm : 128;
+        if (!a.bn || a.Cout_pad % a.bn || !tile_exists(a, a.bn, bm)) return false;
+        if (a.t_ws == 5 && !rs_exists(a, a.bn, bm)) return false;
+    }
+    return true;
+}
+
+int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
+    ConvArgs a = a0;
+    a.bn = 0; a.bm = 0;
+    if (!conv_igemm_f32_supported(a)) return 0;
+    int n = 0;
+    auto push = [&](int bn, int bm, int ws = 1) {
+        for (int i = 0; i < n; ++i)
+            if (out[i].bn == bn && out[i].bm == bm && out[i].ws == ws) return;
+        if (n < max_out) out[n++] = ConvTactic{bn, 16, bm, 1, ws, 0};
+    };
+    int bn0, bm0;
+    default_tile(a, &bn0, &bm0);
+    push(bn0, bm0);
+    static const int bns[5] = {128, 80, 64, 32, 16};
+    static const int bms[3] = {128, 64, 256};
+    for (int bn : bns) {
+        if (a.Cout_pad % bn) continue;
+        if (bn <= 32 && a.Cout_pad > 2 * bn) continue;
+        for (int bm : bms)
+            if (tile_exists(a, bn, bm)) {
+                push(bn, bm);
+                if (rs_exists(a, bn, bm)) push(bn, bm, 5);
+            }
+    }
+    return n;
+}
+
+int32_t conv_igemm_f32(const ConvArgs& a0, hipStream_t s) {
+    if (!conv_igemm_f32_supported(a0)) return TRTX_ERR_UNSUPPORTED;
+    const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 4;
+    const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
+    const unsigned w_bytes = (unsigned)((size_t)a0.Cout_pad * a0.Kpad * 4);
+    for (int n0 = 0; n0 < a0.N; n0 += per) {
+        ConvArgs a = a0;
+        a.N = std::min(per, a0.N - n0);
+        a.M = a.N * a.Ho * a.Wo;
+        a.in = static_cast<const char*>(a0.in) + (size_t)n0 * img_in;
+        a.out = static_cast<char*>(a0.out) + (size_t)n0 * a.Ho * a.Wo * a.ld_out * 4;
+        if (a0.residual) a.residual = static_cast<const char*>(a0.residual) + (size_t)n0 * a.Ho * a.Wo * a.ld_res * 4;
+        if (a0.up_C) a.up_in = static_cast<const char*>(a0.up_in) + (size_t)n0 * a.up_H * a.up_W * a.up_ld * 4;
+        if (!a.bn) default_tile(a, &a.bn, &a.bm);
+        if (!a.bm) a.bm = 128;
+        const ConvArgs k = kernel_units(a);
+        const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 4);
+        int32_t st;
+        if (a.bm == 64) st = launch_f32_bn<1>(a, k, in_bytes, w_bytes, s);
+        else if (a.bm == 256) st = launch_f32_bn<4>(a, k, in_bytes, w_bytes, s);
+        else st = launch_f32_bn<2>(a, k, in_bytes, w_bytes, s);
+        if (st != TRTX_OK) return st;
+    }
+    return check_launch("conv_igemm_f32");
+}
+
+// fp32 [Cout_pad][Kpad], k = (r*kw + q)*cink + c, zero padded; the folded BatchNorm scale multiplied in (fp32)
+void conv_pack_weights_igemm_f32(const float* w, int cout, int cin, int kh, int kw, int cink, int kpad, int cout_pad, const float* ch_scale, float* packed) {
+    memset(packed, 0, sizeof(float) * (size_t)cout_pad * kpad);
+    for (int co = 0; co < cout; ++co) {
+        const float sc = ch_scale ? ch_scale[co] : 1.0f;
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int q = 0; q < kw; ++q)
+                    packed[(size_t)co * kpad + (size_t)(r * kw + q) * cink + c] = w[(((size_t)co * cin + c) * kh + r) * kw + q] * sc;
+    }
+}
+
+}  // namespace trtx

@@ -45,7 +45,7 @@ struct ConvArgs {
     // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
     int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
-    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 3 = the resident-patch 3x3
+    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 3 = the resident-patch 3x3
                 // kernel instead (conv_igemm.hip, builds with -DTRTX_EXPERIMENTAL_PATCH only)
     int t_rs;   // implicit-GEMM operands through registers (global -> VGPR -> ds_write) instead of LDS-DMA: 0 = no, 1 = yes (same bits)
     int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two
@@ -55,6 +55,9 @@ struct ConvArgs {
     // without the upsampled tensor ever existing.  up_C = 0: off.
     const void* up_in;
     int up_C, up_ld, up_H, up_W;
+    // fp32 engines (builds without kFP16; conv_igemm_f32.hip): activations, residual and packed weights are fp32, the k-step is 16 channels
+    // (bk == 16; CinK = Cin rounded up to 16, or 8 for Cin <= 8: two filter taps per step), Kpad = K rounded up to 16.  All fields in channels.
+    int f32;
 };
 
 // One launch configuration of an implicit-GEMM layer.  All tactics of a layer share its packed weights (Cout_pad, CinK, Kpad), so
@@ -102,6 +105,12 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s);
 // implicit-GEMM family (same packed weights, same bits); conv_igemm_f16 dispatches to it
 bool conv_gemm256_possible(const ConvArgs& a);
 int32_t conv_gemm256_f16(const ConvArgs& a, hipStream_t s);
+// fp32 engines: the same skeleton on v_mfma_f32_16x16x4_f32 (conv_igemm_f32.hip).  ConvArgs::f32 = 1, bn / bm = 0: the launcher's own tile choice
+int conv_igemm_f32_pick_cink(int cin);
+bool conv_igemm_f32_supported(const ConvArgs& a);
+int32_t conv_igemm_f32(const ConvArgs& a, hipStream_t s);
+int conv_tactics_f32(const ConvArgs& a, ConvTactic* out, int max_out);   // (bn, bm) pairs; out[0] = the untuned choice; every pair returns the same bits
+void conv_pack_weights_igemm_f32(const float* w_kcrs, int cout, int cin, int kh, int kw, int cink, int kpad, int cout_pad, const float* ch_scale, float* packed);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);
@@ -137,6 +146,9 @@ void conv_chain_pack_weights(const float* w_kcrs, int cout, int cin, int k, cons
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);
+// ... and of an fp32 engine (conv_stem_f32.hip): the same input and weight layout, NHWC fp32 out, Cout a multiple of 16
+bool conv_stem_f32_supported(const ConvArgs& a);
+int32_t conv_stem_nchw_f32_out_f32(const ConvArgs& a, hipStream_t s);
 // The stem fed by camera frames instead of the fp32 network input: image n of the batch is the letterbox (yolov8/src/preprocess.cu) of
 // frames[n] - a device-resident uint8 HWC BGR image of w x h pixels with d2s = the inverse affine map trtx_letterbox_matrix computes
 // for (w, h) -> (a.W, a.H) - sampled inside the kernel's patch fill.  a.in is ignored.  3-channel stems on the LDS / MFMA path only

@@ -125,6 +125,81 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     return st;
 }
 
+// --- fp32 engines: the implicit-GEMM convolution on the fp32 MFMA (kernels/conv_igemm_f32.hip), test / tool entry points
+static ConvArgs op_conv_args_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int act1, int has_res, int ld_res, int act2) {
+    ConvArgs a{};
+    a.f32 = 1;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in;
+    a.Ho = (H + 2 * ph - kh) / sh + 1;
+    a.Wo = (W + 2 * pw - kw) / sw + 1;
+    a.Cout = Cout;
+    a.Cout_pad = (Cout + 15) / 16 * 16;
+    a.ld_out = ld_out; a.ld_res = ld_res;
+    a.kh = kh; a.kw = kw; a.stride_h = sh; a.stride_w = sw; a.pad_h = ph; a.pad_w = pw; a.dil_h = 1; a.dil_w = 1;
+    a.groups = 1;
+    a.bk = 16;
+    a.CinK = conv_igemm_f32_pick_cink(Cin);
+    a.K = kh * kw * a.CinK;
+    a.Kpad = (a.K + 15) / 16 * 16;
+    a.M = N * a.Ho * a.Wo;
+    a.act1 = act1; a.act2 = act2; a.alpha1 = 0.1f; a.alpha2 = 0.1f;
+    a.scalar_out = (Cout % 4 || ld_out % 4 || (has_res && ld_res % 4)) ? 1 : 0;
+    return a;
+}
+
+extern "C" int32_t trtx_conv_packed_dims_f32(int cout, int cin_pad, int kh, int kw, int32_t* cout_pad, int32_t* kpad, int32_t* cink) {
+    if (cout < 1 || cin_pad < 1 || kh < 1 || kw < 1) return TRTX_ERR_INVALID;
+    const int ck = conv_igemm_f32_pick_cink(cin_pad);
+    if (cout_pad) *cout_pad = (cout + 15) / 16 * 16;
+    if (kpad) *kpad = (kh * kw * ck + 15) / 16 * 16;
+    if (cink) *cink = ck;
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_conv_pack_weights_f32(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad, const float* ch_scale, float* packed) {
+    if (!w_kcrs || !packed || cin_pad < cin) return TRTX_ERR_INVALID;
+    const int ck = conv_igemm_f32_pick_cink(cin_pad);
+    conv_pack_weights_igemm_f32(w_kcrs, cout, cin, kh, kw, ck, (kh * kw * ck + 15) / 16 * 16, (cout + 15) / 16 * 16, ch_scale, packed);
+    return TRTX_OK;
+}
+
+extern "C" int32_t trtx_op_conv2d_tactics_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph,
+                                              int pw, int has_residual, int ld_res, int32_t* out2, int32_t max_out) {   // (3 ints per entry)
+    if (!out2 || max_out < 1 || N < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1) return 0;
+    ConvArgs a = op_conv_args_f32(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, 0, has_residual, ld_res, 0);
+    a.residual = has_residual ? reinterpret_cast<const void*>(1) : nullptr;
+    std::vector<ConvTactic> t(max_out);
+    const int n = conv_tactics_f32(a, t.data(), max_out);
+    for (int i = 0; i < n; ++i) {
+        out2[3 * i + 0] = t[i].bn;
+        out2[3 * i + 1] = t[i].bm;
+        out2[3 * i + 2] = t[i].ws;
+    }
+    return n;
+}
+
+extern "C" int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked, const float* bias, void* out,
+                                           int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int act1, const void* residual,
+                                           int ld_res, int act2, const int32_t* tile2, trtx_stream_t stream) {
+    ConvArgs a = op_conv_args_f32(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, act1, residual != nullptr, ld_res, act2);
+    a.in = in;
+    a.wgt = wpacked;
+    a.bias = bias;
+    a.out = out;
+    a.residual = residual;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) || (residual && (reinterpret_cast<uintptr_t>(residual) & 15))) a.scalar_out = 1;
+    if (tile2) {
+        a.bn = tile2[0];
+        a.bm = tile2[1];
+        a.t_ws = tile2[2];
+    }
+    static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;   // timing tools only
+    int32_t st = TRTX_OK;
+    for (int r = 0; r < reps && st == TRTX_OK; ++r) st = conv_igemm_f32(a, stream);
+    return st;
+}
+
 // --- kINT8 conv, test / tool entry points.  Packed dims: cink = Cin rounded up to 64 channels, kpad = kh*kw*cink (bytes per row).
 extern "C" int32_t trtx_conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw, const float* ch_scale, int8_t* packed,
                                              float* wscale_out, int32_t* cout_pad_out, int32_t* kpad_out) {

@@ -232,12 +232,29 @@ __global__ __launch_bounds__(kChunk) void yolo_emit_kernel(LevelTable t, int cla
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 struct HeadTable {
-    const _Float16* in[kMaxLevels];
+    const void* in[kMaxLevels];
     int ld[kMaxLevels];
     int cell_off[kMaxLevels + 1];
     int n_levels;
 };
 
+// eight consecutive channels of a cell as floats: one 16-byte load of an fp16 engine's tensor, two of an fp32 engine's
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&x)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (float)v[i];
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+        x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+}
+
+// T = element type of the NHWC head tensors: _Float16 (kFP16 engines) or float (fp32 engines, round 5: the build that meets BASELINE's tolerance
+// had run the un-fused graph, ~30 layout / shuffle / softmax launches)
+template <typename T>
 __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int classes, int total_cells,
                                                               const float* __restrict__ dfl_w,
                                                               float* __restrict__ score, int* __restrict__ cls_out,
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
         for (int i = 1; i < kMaxLevels; ++i)
             if (i < t.n_levels && gg >= t.cell_off[i]) l = i;
         const int cells = t.cell_off[l + 1] - t.cell_off[l];
-        return t.in[l] + ((size_t)b * cells + (gg - t.cell_off[l])) * t.ld[l];
+        return static_cast<const T*>(t.in[l]) + ((size_t)b * cells + (gg - t.cell_off[l])) * t.ld[l];
     };
     // ---- phase 1, every cell: the cell can only survive if some sigmoid(logit) >= 0.1, i.e. some logit >= -2.1972.  The
     // maximum of the raw fp16 logits (exact, packed max, no exp) settles that; possible survivors are compacted into a
@@ -278,9 +295,9 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
         const int n = cells_here * pieces;
         for (int j = lane; j < n; j += 64) {
             const int c = j / pieces, q = j - c * pieces;
-            half8_t v = *reinterpret_cast<const half8_t*>(cell_ptr(g0 + c) + 64 + q * 8);
-            float m = fmaxf(fmaxf(fmaxf((float)v[0], (float)v[1]), fmaxf((float)v[2], (float)v[3])),
-                            fmaxf(fmaxf((float)v[4], (float)v[5]), fmaxf((float)v[6], (float)v[7])));
+            float v[8];
+            load8(cell_ptr(g0 + c) + 64 + q * 8, v);
+            float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
             if (m > -2.3f) s_list[wave0 + c] = 1;
         }
     }
@@ -308,20 +325,20 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
     int kept = 0;
     for (int k = threadIdx.x; k < s_n; k += 256) {
         const int gg = blockIdx.x * 256 + s_list[k];
-        const _Float16* cell = cell_ptr(gg);
+        const T* cell = cell_ptr(gg);
         float w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) w[i] = dfl_w[i];
         float side[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const half8_t lo = *reinterpret_cast<const half8_t*>(cell + s * 16);
-            const half8_t hi = *reinterpret_cast<const half8_t*>(cell + s * 16 + 8);
-            float x[16];
+            float lo[8], hi[8], x[16];
+            load8(cell + s * 16, lo);
+            load8(cell + s * 16 + 8, hi);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                x[i] = (float)lo[i];
-                x[8 + i] = (float)hi[i];
+                x[i] = lo[i];
+                x[8 + i] = hi[i];
             }
             float mx = x[0];
 #pragma unroll
@@ -337,12 +354,13 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
         }
         float best = 0.0f;
         int bcls = 0;
-        const _Float16* cl = cell + 64;
+        const T* cl = cell + 64;
         for (int c0 = 0; c0 < classes; c0 += 8) {  // classes % 8 == 0 on this path
-            const half8_t v = *reinterpret_cast<const half8_t*>(cl + c0);
+            float v[8];
+            load8(cl + c0, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float pr = logist((float)v[i]);
+                const float pr = logist(v[i]);
                 if (pr > best) {
                     best = pr;
                     bcls = c0 + i;
@@ -435,10 +453,8 @@ extern "C" size_t trtx_yolo_head_decode_workspace(int batch, int net_h, int net_
            trtx::align_up((size_t)batch * n_chunks * sizeof(int), 256);
 }
 
-extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const int* ld, int n_levels, int batch,
-                                              int classes, int net_h, int net_w, const int* strides,
-                                              const float* dfl_weights, int max_out, float* output, void* workspace,
-                                              size_t workspace_bytes, hipStream_t stream) {
+static int32_t head_decode(const void* const* heads, const int* ld, int elem_bytes, int n_levels, int batch, int classes, int net_h, int net_w, const int* strides,
+                           const float* dfl_weights, int max_out, float* output, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (n_levels < 1 || n_levels > kMaxLevels || batch < 1 || classes < 8 || classes % 8 || max_out < 1 || !heads ||
         !ld || !dfl_weights || !output || !workspace)
         return TRTX_ERR_INVALID;
@@ -449,8 +465,8 @@ extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const in
     int off = 0;
     for (int i = 0; i < n_levels; ++i) {
         const int gh = net_h / strides[i], gw = net_w / strides[i];
-        if (ld[i] % 8 || (reinterpret_cast<uintptr_t>(heads[i]) & 15)) return TRTX_ERR_UNSUPPORTED;
-        h.in[i] = static_cast<const _Float16*>(heads[i]);
+        if (ld[i] % (16 / elem_bytes) || (reinterpret_cast<uintptr_t>(heads[i]) & 15)) return TRTX_ERR_UNSUPPORTED;
+        h.in[i] = heads[i];
         h.ld[i] = ld[i];
         h.cell_off[i] = t.cell_off[i] = off;
         t.grid_w[i] = gw;
@@ -470,9 +486,26 @@ extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const in
     int* chunk_cnt = reinterpret_cast<int*>(ws);
     if (hipMemsetAsync(chunk_cnt, 0, (size_t)batch * n_chunks * sizeof(int), stream) != hipSuccess) return TRTX_ERR_HIP;
     const int out_elem = 1 + max_out * trtx::kYoloDetFloats;
-    hipLaunchKernelGGL(yolo_head_score_kernel, dim3((total_cells + 255) / 256, batch), dim3(256), 0, stream, h, classes,
-                       total_cells, dfl_weights, score, cls, boxes, chunk_cnt, n_chunks);
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(yolo_head_score_kernel<_Float16>, dim3((total_cells + 255) / 256, batch), dim3(256), 0, stream, h, classes, total_cells, dfl_weights,
+                           score, cls, boxes, chunk_cnt, n_chunks);
+    else
+        hipLaunchKernelGGL(yolo_head_score_kernel<float>, dim3((total_cells + 255) / 256, batch), dim3(256), 0, stream, h, classes, total_cells, dfl_weights,
+                           score, cls, boxes, chunk_cnt, n_chunks);
     hipLaunchKernelGGL(yolo_emit_kernel, dim3(n_chunks, batch), dim3(kChunk), 0, stream, t, classes, total_cells, score,
                        cls, chunk_cnt, n_chunks, max_out, out_elem, output, (const float4*)boxes, YoloBranches{0, 0, 0, 0, 0.f});
     return trtx::check_launch("trtx_yolo_head_decode_nhwc");
+}
+
+extern "C" int32_t trtx_yolo_head_decode_nhwc(const void* const* heads, const int* ld, int n_levels, int batch,
+                                              int classes, int net_h, int net_w, const int* strides,
+                                              const float* dfl_weights, int max_out, float* output, void* workspace,
+                                              size_t workspace_bytes, hipStream_t stream) {
+    return head_decode(heads, ld, 2, n_levels, batch, classes, net_h, net_w, strides, dfl_weights, max_out, output, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t trtx_yolo_head_decode_nhwc_f32(const void* const* heads, const int* ld, int n_levels, int batch, int classes, int net_h, int net_w,
+                                                  const int* strides, const float* dfl_weights, int max_out, float* output, void* workspace,
+                                                  size_t workspace_bytes, hipStream_t stream) {
+    return head_decode(heads, ld, 4, n_levels, batch, classes, net_h, net_w, strides, dfl_weights, max_out, output, workspace, workspace_bytes, stream);
 }

@@ -167,12 +167,12 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                 if (op.kind == OP_DECONV)
                     st = deconv_direct(a, op.dtype, stream);
                 else if (op.stem && c->frames)
-                    st = conv_stem_frames_f32(a, c->frames, stream);   // letterbox fused into the stem (trtx_context_enqueue_frames)
+                    st = a.f32 ? TRTX_ERR_UNSUPPORTED : conv_stem_frames_f32(a, c->frames, stream);   // letterbox fused into the stem (trtx_context_enqueue_frames; kFP16 engines)
                 else if (op.stem)
-                    st = conv_stem_nchw_f32(a, stream);
+                    st = a.f32 ? conv_stem_nchw_f32_out_f32(a, stream) : conv_stem_nchw_f32(a, stream);
                 else if (op.igemm) {
                     if (prof && probes[k].start && probes[k].stop) conv_set_launch_probe(&probes[k]);
-                    st = conv_igemm_f16(a, stream);
+                    st = a.f32 ? conv_igemm_f32(a, stream) : conv_igemm_f16(a, stream);
                     conv_set_launch_probe(nullptr);
                 } else
                     st = conv_direct(a, op.dtype, stream);
@@ -362,10 +362,9 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     heads[k] = R.ptr(op.in[k]);
                     lds[k] = plan.tensors[op.in[k]].ld;
                 }
-                st = trtx_yolo_head_decode_nhwc(heads, lds, nl, batch, op.i[0], op.i[1], op.i[2], &op.i[5],
-                                                reinterpret_cast<const float*>(W + op.w_off), op.i[3],
-                                                static_cast<float*>(R.ptr(op.out[0])),
-                                                static_cast<char*>(c->d_arena) + op.ws_off, op.ws_bytes, stream);
+                st = (t0.dtype == DT_F32 ? trtx_yolo_head_decode_nhwc_f32 : trtx_yolo_head_decode_nhwc)(
+                        heads, lds, nl, batch, op.i[0], op.i[1], op.i[2], &op.i[5], reinterpret_cast<const float*>(W + op.w_off), op.i[3],
+                        static_cast<float*>(R.ptr(op.out[0])), static_cast<char*>(c->d_arena) + op.ws_off, op.ws_bytes, stream);
                 break;
             }
             case OP_ROI_ALIGN: {

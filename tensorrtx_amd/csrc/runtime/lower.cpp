@@ -125,7 +125,7 @@ struct Lowerer {
                 t.W = (int)d.d[d.nb - 1];
                 if (d.nb == 4) t.nmul = (int)d.d[0];
             }
-            t.Calloc = dt == DT_F16 ? (t.C + 7) / 8 * 8 : t.C;
+            t.Calloc = dt == DT_F16 ? (t.C + 7) / 8 * 8 : (t.C + 3) / 4 * 4;   // a pixel's channels start on a 16-byte boundary
         } else {
             t.dtype = DT_F32;
             if (net.explicit_batch) t.batched = false;
@@ -414,7 +414,7 @@ struct Lowerer {
         return true;
     }
     void analyse_yolo_head() {
-        if (dt != DT_F16 || net.explicit_batch) return;
+        if (net.explicit_batch) return;   // (fp16 and, since round 5, fp32 engines: the kernel reads either element type)
         for (size_t li = 0; li < net.layers.size(); ++li) {
             const LayerDef& l = net.layers[li];
             if (l.kind != L_PLUGIN || l.outputs.size() != 1) continue;
@@ -457,7 +457,7 @@ struct Lowerer {
         for (size_t k = 0; k < f.params.strides.size(); ++k) op.i[5 + k] = f.params.strides[k];
         op.ws_bytes = trtx_yolo_head_decode_workspace(plan.max_batch, f.params.net_h, f.params.net_w, f.params.strides.data(),
                                                       (int)f.params.strides.size());
-        for (int t : ins) op.bytes += 2.0 * plan.tensors[t].dims.volume();
+        for (int t : ins) op.bytes += (double)dtype_size(dt) * plan.tensors[t].dims.volume();
         op.bytes += 4.0 * net.tensors[l.outputs[0]].dims.volume();
         pt_of[l.outputs[0]] = out;
         return true;
@@ -476,6 +476,11 @@ struct Lowerer {
                    g.residual < 0 && g.act2 == ACT_NONE && l.groups == 1 && l.dilation[0] == 1 && l.dilation[1] == 1 &&
                    (l.nb_out == 8 || l.nb_out == 16 || l.nb_out == 32 || l.nb_out == 64) &&
                    (size_t)l.kernel[0] * l.kernel[1] * cin * l.nb_out * 4 <= 48 * 1024;
+            // fp32 engines (round 5): kernels/conv_stem_f32.hip, the same idea on the vector ALU - the layer is HBM-bound and 3x padding on the MFMA path
+            static const bool no_stem32 = getenv("TRTX_F32_DIRECT") != nullptr;
+            if (dt == DT_F32 && !no_stem32)
+                stem = l.kind == L_CONV && di.nb == (net.explicit_batch ? 4 : 3) && src.layout == LAY_LINEAR && pt_nhwc[l.inputs[0]] < 0 && cin <= 4 && g.residual < 0 &&
+                       g.act2 == ACT_NONE && l.groups == 1 && l.dilation[0] == 1 && l.dilation[1] == 1 && l.nb_out % 16 == 0 && l.nb_out <= 256;
         }
         const int in = stem ? pt_of[l.inputs[0]] : need_nhwc(l.inputs[0]);
         PTensor ti = plan.tensors[in];
@@ -1501,7 +1506,7 @@ struct Lowerer {
     // per step become 19.5 MB read); every product is formed from the same operands in the same order: bit-identical outputs.
     // TRTX_FOLD_UPSAMPLE=0 keeps the resize (A/B, tests).  Not with kINT8 (the int8 resize requantises between two scales).
     void fold_upsample() {
-        if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
+        if (net.int8 || CalibrationLowering::active()) return;   // (fp16 and fp32 engines: both MFMA kernels fetch the slice from the half-resolution tensor)
         if (const char* e = getenv("TRTX_FOLD_UPSAMPLE"))
             if (atoi(e) == 0) return;
         auto top = [&](int t) {
@@ -1567,6 +1572,7 @@ struct Lowerer {
             a.up_W = tu.W;
         }
         op.igemm = false;
+        a.f32 = (op.stem && dt == DT_F32) ? 1 : 0;   // (the fp32 stem kernel; the MFMA path sets it below)
         if (op.kind == OP_CONV && !op.stem && dt == DT_F16 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
             int cin_eff = a.Cin;
             bool ok = true;
@@ -1633,6 +1639,41 @@ struct Lowerer {
                     t.t_rs = (net.max_aux_streams == 0 && flop_px / byte_px < ridge) ? 1 : 0;
                 }
                 if (conv_igemm_supported(t)) {
+                    a = t;
+                    op.igemm = true;
+                }
+            }
+        }
+        // fp32 engines: the same skeleton on the fp32 MFMA (kernels/conv_igemm_f32.hip), 16-channel k-steps; the tile shape is the launcher's
+        if (op.kind == OP_CONV && !op.stem && dt == DT_F32 && ti.dtype == DT_F32 && to.dtype == DT_F32 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
+            static const bool off = getenv("TRTX_F32_DIRECT") != nullptr;   // A/B: the scalar direct kernel of rounds 1-4
+            int cin_eff = a.Cin;
+            bool ok = !off;
+            if (cin_eff % 4) {
+                const PTensor& own = plan.tensors[ti.parent >= 0 ? ti.parent : ti.id];
+                ok = ok && ti.parent < 0 && own.pad_zeroed;
+                cin_eff = (a.Cin + 3) / 4 * 4;
+            }
+            ok = ok && ti.rcoff % 4 == 0 && ti.ld % 4 == 0;
+            bool vec_out = a.Cout % 4 == 0 && to.rcoff % 4 == 0 && to.ld % 4 == 0;
+            if (op.in.size() > 1) {
+                const PTensor& tr = plan.tensors[op.in[1]];
+                vec_out = vec_out && tr.rcoff % 4 == 0 && tr.ld % 4 == 0;
+            }
+            ok = ok && a.kh * a.kw * cin_eff >= 16 && a.Cout >= 8;   // tiny reductions / single-channel outputs (the DFL 1x1) stay on the direct kernel
+            if (ok) {
+                ConvArgs t = a;
+                t.f32 = 1;
+                t.scalar_out = vec_out ? 0 : 1;
+                t.Cin = cin_eff;
+                t.bk = 16;
+                t.bn = 0;
+                t.bm = 0;
+                t.CinK = conv_igemm_f32_pick_cink(cin_eff);
+                t.K = t.kh * t.kw * t.CinK;
+                t.Kpad = (t.K + 15) / 16 * 16;
+                t.Cout_pad = (t.Cout + 15) / 16 * 16;
+                if (conv_igemm_f32_supported(t)) {
                     a = t;
                     op.igemm = true;
                 }
@@ -1715,7 +1756,7 @@ struct Lowerer {
             ConvArgs& a = op.conv;
             const PTensor& ti = plan.tensors[op.in[0]];
             const PTensor& to = plan.tensors[op.out[0]];
-            if (op.stem && (to.ld % 8 || to.rcoff % 8)) return fail(op.name + ": stem convolution output is not 16-byte aligned");
+            if (op.stem && (dt == DT_F16 ? (to.ld % 8 || to.rcoff % 8) : (to.ld % 4 || to.rcoff % 4))) return fail(op.name + ": stem convolution output is not 16-byte aligned");
             choose_conv_kernel(op);
             if (!op.extra_in.empty() && !op.igemm) return fail(op.name + ": folded upsample on a convolution that cannot take the MFMA path");
             if ((ti.dtype == DT_I8 || to.dtype == DT_I8 || (op.in.size() > 1 && plan.tensors[op.in[1]].dtype == DT_I8)) && !op.igemm)
@@ -2025,6 +2066,10 @@ bool pack_weights(const Network& net, Plan* plan) {
                 for (float& v : wscale) v *= s_in;
                 op.s_off = reserve(wscale.size() * 4);
                 memcpy(blob.data() + op.s_off, wscale.data(), wscale.size() * 4);
+            } else if (op.igemm && a.f32) {
+                op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 4);
+                conv_pack_weights_igemm_f32(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.Kpad, a.Cout_pad, sc.data(),
+                                            reinterpret_cast<float*>(blob.data() + op.w_off));
             } else if (op.igemm) {
                 op.w_off = reserve((size_t)a.Cout_pad * a.Kpad * 2);
                 pack_conv_weights_f16(l.w0.data(), cout, cin_logical, a.kh, a.kw, a.CinK, a.bk, sc.data(),
@@ -2036,7 +2081,7 @@ bool pack_weights(const Network& net, Plan* plan) {
             }
             op.b_off = reserve(bias.size() * 4);
             memcpy(blob.data() + op.b_off, bias.data(), bias.size() * 4);
-            op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * 2 : (size_t)cout * a.K * 4);
+            op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * (a.f32 ? 4 : 2) : (size_t)cout * a.K * 4);
         } else if (op.kind == OP_CONV_CHAIN) {
             for (POp::ChainStage& st : op.chain) {
                 const LayerDef& l = net.layers[st.src_layer];

@@ -32,6 +32,8 @@ SPEC = {
     ("resnet50_64", "fp16"): {"max_abs_err": ("max",)},
     ("resnet50_224_b32", None): {"max_abs_err": ("max",)},              # logits up to 1787
     ("yolov8n_fp32_128", None): {"head_max_abs_err": ("max",)},         # north_star: 1e-4 on O(10) logits
+    ("yolov8n_fp32_640_b32", None): {"head_max_abs_err": ("max",), "matched_fraction": ("min", 1 / 945), "min_iou": ("min",), "max_conf_err": ("max",)},   # the fp32
+    # build at the bench configuration (round 5: v_mfma_f32_16x16x4_f32 convolutions) - THE row BASELINE's tolerance is asserted on
     ("yolov8n_fp16_640", None): {"cls_logit_max_abs_err": ("max",), "box_ltrb_max_abs_err": ("max",), "matched_fraction": ("min",),
                                  "min_iou": ("min",), "max_conf_err": ("max",)},
     ("yolov8n_fp16_640_fused", None): {"matched_fraction": ("min",), "min_iou": ("min",), "max_conf_err": ("max",)},
@@ -105,6 +107,8 @@ CEILINGS = {
     ("resnet50_64", "fp16"): {"max_abs_err": fp16_walk(107, 720)},               # 53 convs + fc: 54 weight + 53 activation sites -> 5.5
     ("resnet50_224_b32", None): {"max_abs_err": fp16_walk(107, 1787)},           # fp16, logits up to 1787 -> 13.5
     ("yolov8n_fp32_128", None): {"head_max_abs_err": NS_LOGIT},
+    ("yolov8n_fp32_640_b32", None): {"head_max_abs_err": NS_LOGIT, "matched_fraction": 1.0 - 1 / 945, "min_iou": 1 - NS_IOU, "max_conf_err": NS_LOGIT},   # (a confidence is
+    # sigmoid(logit): slope <= 1/4; one candidate of ~900 may sit on the 0.1 threshold)
     ("yolov8n_fp16_640", None): {"cls_logit_max_abs_err": fp16_walk(133, 16), "box_ltrb_max_abs_err": fp16_walk(133, 16) / 4,   # DFL: expectation over
                                  # softmax(16 logits) in cells, d(expectation)/d(logit) <= 1/4 of the bin span per unit logit for a unimodal side
                                  "matched_fraction": 1 - FP16_MATCH, "min_iou": 1 - FP16_IOU, "max_conf_err": fp16_walk(133, 16) / 4},   # sigmoid' <= 1/4

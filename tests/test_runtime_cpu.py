@@ -598,8 +598,8 @@ def _upsample_concat_net(extra_reader=False, cin_up=64, cin_skip=32, k=1, fp16=T
 
 def test_upsample_is_folded_only_where_it_is_safe(monkeypatch):
     """lower.cpp fold_upsample: the resize disappears into the 1x1 convolution that reads the concat buffer - but not when something else
-    reads the upsampled tensor, not into a 3x3, not when the slice is not a whole number of 64-channel k-steps, not in fp32, and not
-    with TRTX_FOLD_UPSAMPLE=0."""
+    reads the upsampled tensor, not into a 3x3, not when the slice is not a whole number of 64-channel k-steps, and not with
+    TRTX_FOLD_UPSAMPLE=0.  Since round 5 fp32 engines fold too (their convolutions run on the same skeleton, kernels/conv_igemm_f32.hip)."""
     def kinds(plan):
         low = engine.describe_plan(plan, lowered=True)
         return [o["kind"] for o in low["ops"]], [o for o in low["ops"] if o["kind"] == "conv"]
@@ -608,7 +608,8 @@ def test_upsample_is_folded_only_where_it_is_safe(monkeypatch):
     assert "resize" in kinds(_upsample_concat_net(extra_reader=True)[0])[0]
     assert "resize" in kinds(_upsample_concat_net(k=3)[0])[0]
     assert "resize" in kinds(_upsample_concat_net(cin_up=32)[0])[0]
-    assert "resize" in kinds(_upsample_concat_net(fp16=False)[0])[0]
+    k32, convs32 = kinds(_upsample_concat_net(fp16=False)[0])
+    assert "resize" not in k32 and [o["up_c"] for o in convs32 if o["up_c"]] == [64]
     monkeypatch.setenv("TRTX_FOLD_UPSAMPLE", "0")
     assert "resize" in kinds(_upsample_concat_net()[0])[0]
 
