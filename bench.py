@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: fp32 operands, exact fp32 (MI355X_MICROARCH.md) - the fp32 engine's convolutions
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming copy reaches)
 N_INPUT_SETS = 8                 # rotating input batches: a step never re-reads the batch the previous step left in the caches
 
@@ -85,7 +86,7 @@ def _kernel_duration_from_profile(model):
         return None, None
 
 
-def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0, precision="fp16"):
+def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.0, precision="fp16", extra=None):
     """The oracle (PyTorch-CPU fp32 restatement of the reference graph + C decode/NMS) timed on the host cores on a bounded
     sample of the same workload: reported next to the GPU number, never the thing measured.  The same oracle outputs are
     compared with what the GPU produced for the same images -> `parity` (what the fp16 engine is off by)."""
@@ -110,6 +111,9 @@ def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.
         keep["heads"], keep["dec"] = heads, dec
         keep["nms"] = yp.batch_nms_c(dec)
 
+    with torch.inference_mode():   # the same graph in double (untimed): the value every fp32 evaluation - the oracle's own included - is a rounding of
+        keep["heads64"] = mt.yolov8_det(mt.Params64(params), x.double())[0]
+
     once()  # warm-up
     t0 = time.perf_counter()
     n = 0
@@ -122,7 +126,23 @@ def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.
     base = {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} images ({nb}/iter) 640x640 fp32, PyTorch-CPU restatement of the reference graph + C decode/NMS"}
     # parity of the fp16 engine vs the fp32 oracle on those same images: head logits and decoded boxes
+    if extra:   # further engines against the same oracle outputs: {name: (heads, decode buffer, description)} -> parity objects under "extra"
+        more = {}
+        for name, (eh, ed, what) in extra.items():
+            more[name] = _yolo_parity(keep, eh, ed, nb, what)
+    par = _yolo_parity(keep, gpu_heads, gpu_dec, nb, "fp16 build (fp16 storage of 63 layers)" if precision == "fp16" else
+                       "int8 build (int8 activations and weights behind the first two layers, fp16 elsewhere)")
+    if extra:
+        par["extra"] = more
+    return base, par
+
+
+def _yolo_parity(keep, gpu_heads, gpu_dec, nb, what):
+    import numpy as np
     logit_err = max(float((g[:nb] - h.numpy().reshape(g[:nb].shape)).__abs__().max()) for g, h in zip(gpu_heads, keep["heads"]))
+    logit_max = max(float(h.abs().max()) for h in keep["heads"])
+    err64 = max(float(np.abs(g[:nb].astype(np.float64) - h.numpy().reshape(g[:nb].shape)).max()) for g, h in zip(gpu_heads, keep["heads64"]))
+    oracle64 = max(float((h.double() - h64).abs().max()) for h, h64 in zip(keep["heads"], keep["heads64"]))
     ious, matched, total, loose = [], 0, 0, []
     for b in range(nb):
         nr, ng = int(keep["dec"][b, 0]), int(gpu_dec[b, 0])
@@ -142,13 +162,14 @@ def cpu_baseline_and_parity(path, gpu_heads, gpu_dec, images, seconds_budget=20.
             if iou.max() > 0.9:
                 matched += 1
                 ious.append(float(iou.max()))
-    what = "fp16 build (fp16 storage of 63 layers)" if precision == "fp16" else "int8 build (int8 activations and weights behind the first two layers, fp16 elsewhere)"
-    parity = {"vs": "fp32 PyTorch-CPU oracle, same weights and images", "images": nb, "head_logit_max_abs_err": logit_err,
+    met = logit_err <= 1e-4 and bool(ious) and min(ious) >= 0.999 and matched == total
+    parity = {"vs": "fp32 PyTorch-CPU oracle, same weights and images", "images": nb, "head_logit_max_abs_err": logit_err, "largest_oracle_logit": logit_max,
+              "head_logit_max_abs_err_vs_the_graph_in_double": err64, "the_fp32_oracle_vs_the_graph_in_double": oracle64,
               "oracle_candidates_conf>0.25": total, "matched_same_class_iou>0.9": matched, "matched_same_class_iou>0.5": len(loose),
               "min_box_iou": min(ious) if ious else None, "mean_box_iou_of_iou>0.5_matches": float(np.mean(loose)) if loose else None,
-              "north_star_tolerance": "1e-4 logit / 1e-3 IoU: met by the fp32 build (tests), NOT by this " + what,
+              "north_star_tolerance": ("1e-4 logit / 1e-3 IoU: MET by this " if met else "1e-4 logit / 1e-3 IoU: NOT met by this ") + what,
               "nms_kept_indices": "bit-exact vs the oracle on identical decode buffers (tests/test_gpu_yolo_plugins.py, test_ref_pinning.py)"}
-    return base, parity
+    return parity
 
 
 def _box_match(R, G, iou_floor=0.5):
@@ -396,6 +417,8 @@ def main():
     ap.add_argument("--replicas", default="processes", choices=["processes", "in-process"],
                     help="processes (default, the driver's contract): one rank per GPU; in-process: this one process drives --gpus devices through DeviceReplicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="leave the process's CPU affinity alone (default: the cores of the GPU's NUMA node)")
+    ap.add_argument("--no-tolerance-engine", action="store_true", help="skip the fp32-engine leg (yolov8n fp16 runs print it as `tolerance_engine`)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of this script's control flow (ranks over gloo, rank 0 builds and broadcasts the plan, legs / barriers / "
                          "max-over-ranks, JSON assembly) with stand-ins for every GPU object (tensorrtx_amd/dryrun.py); the line is marked dry_run and "
@@ -441,6 +464,8 @@ def main():
     pin = (lambda t: t) if dry else (lambda t: t.pin_memory())
 
     from tensorrtx_amd import capi, engine, replicas, synth
+    # each rank on the cores of its GPU's NUMA node, before any worker thread or pinned buffer exists
+    affinity_note = "dry run" if dry else ("off (--no-pin)" if args.no_pin else replicas.pin_to_gpu_numa_node(tc.current_device(), local, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     from tensorrtx_amd import wts as wts_writer
 
     cfg = CONFIGS[args.config]
@@ -635,6 +660,35 @@ def main():
     if n_ctx > 1:
         dt_single, single_legs, _ = legs(one, n_side, warmup=min(args.warmup, 5))
 
+    # The tolerance-meeting engine: the SAME network built WITHOUT BuilderFlag::kFP16 - the reference's USE_FP32 build
+    # (yolov8/include/config.h:1-3, model.cpp:314-324) - whose convolutions run on the fp32 MFMA (kernels/conv_igemm_f32.hip).  BASELINE's
+    # tolerance (1e-4 logit / 1e-3 IoU against the reference's fp32 outputs) is a property of fp32 arithmetic, so this is the engine it can be
+    # stated for; timed exactly like `value` (same contexts in flight, same inputs, barrier + synchronize, max over ranks), never `value`.
+    tol = None
+    if args.config == "yolov8n" and args.precision == "fp16" and not args.no_tolerance_engine:
+        def build32(aux):
+            plan32 = None
+            if rank == 0:
+                opts = dict(batch=batch, h=H, w=W, fp16=0)
+                if aux >= 0:
+                    opts["aux_streams"] = aux
+                plan32 = engine.build_plan(args.config, path, **opts)
+            if dist:
+                box = [plan32]
+                dist.broadcast_object_list(box, src=0)
+                plan32 = box[0]
+            return plan32
+        plan32 = build32(0 if n_ctx > 1 else -1)
+        eng32 = make_engine(plan32)
+        slots32 = make_slots(eng32, n_ctx)
+        for k in range(2 * n_ctx):
+            slots32[k % n_ctx].run(inputs[k % len(inputs)])
+        tc.synchronize()
+        dt32, legs32, _ = legs(slots32, n_side)
+        one32 = make_slots(eng32, 1) if n_ctx > 1 else slots32
+        dt32_1, legs32_1, _ = legs(one32, 3, warmup=min(args.warmup, 5)) if n_ctx > 1 else (dt32, legs32, None)
+        tol = {"plan": plan32, "eng": eng32, "slots": slots32, "dt": dt32, "legs": legs32, "dt1": dt32_1, "legs1": legs32_1}
+
     # Host-fed variant (not `value`): what a caller pays when the boundary hands over HOST images, as the reference's demo does
     # (yolov8_det.cpp:146-160: cuda_batch_preprocess of cv::Mat frames, infer, D2H).  Raw uint8 HWC frames sit in pinned host
     # memory; a copy stream uploads batch k+1 while the slots run letterbox (preprocess.cu twin) -> enqueue -> NMS -> D2H of the
@@ -806,7 +860,7 @@ def main():
                                f", {len(inputs)} rotating input batches resident in HBM",
                    "contexts": n_ctx,
                    "global_batch": global_batch, "parallelism": f"replica-per-GPU x{world} (image-sharded, no data-path collective; RCCL only brackets the timed region)",
-                   "weights": "seeded synthetic .wts (no trained weights offline)"},
+                   "weights": "seeded synthetic .wts (no trained weights offline)", "cpu_affinity_rank0": affinity_note},
         "roofline": roofline,
     }
     if dt_single is not None:
@@ -817,6 +871,32 @@ def main():
         res["single_context"]["roofline"] = {"avg_launch_us": c1_ms * 1e3 / max(n1, 1), "conv_ms_per_step": c1_ms, "all_kernels_ms_per_step": t1_ms,
                                              "hbm_frac": alg_bytes / (c1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "mfma_frac": flop_per_step / (c1_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                              "tactics": tac1}
+    if tol is not None:
+        imgs_step = (global_batch if mode == "strong" else world * batch)
+        low32 = engine.describe_plan(tol["plan"], lowered=True)
+        c32 = k32 = 0.0
+        rows32 = []
+        if not dry:
+            for _ in range(3):
+                rows32 = tol["eng"].profile(batch, tol["slots"][0].bindings(inputs[0]))
+                conv32 = [r for r, o in zip(rows32, low32["ops"]) if o["kind"] == "conv" and o.get("igemm")]
+                c32 += sum(r["ms"] for r in conv32) / 3
+                k32 += (sum(r["kernel_ms"] for r in conv32) if all(r.get("kernel_ms", -1) > 0 for r in conv32) else float("nan")) / 3
+        conv32_ms = k32 if (k32 == k32 and 0.5 * c32 < k32 <= 1.02 * c32) else c32
+        flop32 = sum(o["flops"] for o in low32["ops"] if o["kind"] == "conv" and o.get("igemm")) * batch
+        n32 = sum(1 for o in low32["ops"] if o["kind"] == "conv" and o.get("igemm"))
+        res["tolerance_engine"] = {
+            "what": ("the same network built WITHOUT kFP16 (the reference's USE_FP32 build, yolov8/include/config.h:1-3): fp32 storage, every convolution on "
+                     "v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, two-level K sum), fp32 stem kernel, fused DFL + decode on fp32 head tensors; "
+                     "timed like `value` (same contexts in flight, inputs resident, decode + NMS included)"),
+            "value": imgs_step * args.steps / tol["dt"], "unit": "images/sec", "ms_per_step": tol["dt"] / args.steps * 1e3, "legs_ms": tol["legs"],
+            "dtype": "f32", "contexts": n_ctx,
+            "single_context": {"value": imgs_step * args.steps / tol["dt1"], "ms_per_step": tol["dt1"] / args.steps * 1e3, "legs_ms": tol["legs1"]},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16_kernel<..., F32> (kernels/conv_igemm_f32.hip, all instantiations)", "launches_per_step": n32,
+                         "flop_per_step": flop32, "conv_ms_per_step": conv32_ms, "achieved": flop32 / (conv32_ms * 1e-3) / 1e12 if conv32_ms else None,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop32 / (conv32_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if conv32_ms else None,
+                         "frac_describes": "every fp32 conv launch alone (serialized profile pass), against the fp32-operand MFMA peak (1/16 of the fp16 one)"},
+        }
     if cfg["nms"]:
         res["d2h_inclusive"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_d2h, "unit": "images/sec",
                                 "ms_per_step": dt_d2h / args.steps * 1e3, "legs_ms": d2h_legs,
@@ -868,7 +948,23 @@ def main():
             s0.ctx.enqueue(batch, s0.bindings(torch.from_numpy(np.ascontiguousarray(mixed)).to(dev)), stream=s0.stream.cuda_stream)
             tc.synchronize()
             dec = s0.outs[eng.names.index("output")].cpu().numpy().reshape(batch, -1)[:nb]
-            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(path, heads, dec, imgs, precision=args.precision)
+            extra = None
+            if tol is not None:
+                e32h = engine.Engine(engine.build_plan("yolov8n", path, batch=nb, h=H, w=W, fp16=0, mark_heads=1))
+                b32 = [torch.from_numpy(imgs).to(dev)] + [torch.empty(nb * int(np.prod(e32h.dims[i])), dtype=torch.float32, device=dev) for i in range(1, e32h.nb_bindings)]
+                e32h.enqueue(nb, b32)
+                tc.synchronize()
+                heads32 = [b32[e32h.names.index(f"head{i}")].cpu().numpy().reshape(nb, -1) for i in range(3)]
+                e32h.close()
+                t0s = tol["slots"][0]
+                t0s.ctx.enqueue(batch, t0s.bindings(torch.from_numpy(np.ascontiguousarray(mixed)).to(dev)), stream=t0s.stream.cuda_stream)
+                tc.synchronize()
+                dec32 = t0s.outs[tol["eng"].names.index("output")].cpu().numpy().reshape(batch, -1)[:nb]
+                extra = {"tolerance_engine": (heads32, dec32, "fp32 build (fp32 storage, fp32 MFMA)")}
+            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(path, heads, dec, imgs, precision=args.precision, extra=extra)
+            if tol is not None:
+                res["tolerance_engine"]["parity"] = res["parity"].pop("extra")["tolerance_engine"]
+                res["tolerance_engine"]["parity"]["boxes_from"] = "the TIMED fp32 engine (batch %d, production plan)" % batch
             res["parity"]["boxes_from"] = "the TIMED engine (batch %d, production plan: fused head, folded upsample, grouped launches)" % batch
             res["parity"]["head_logits_from"] = "a batch-4 plan of the same network with the three head tensors marked as outputs (the timed plan fuses them into the decode kernel)"
         elif not args.no_cpu_baseline and not dry:
@@ -889,6 +985,8 @@ def main():
                 sample = np.ascontiguousarray(sample.transpose(0, 2, 3, 1))
             res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity_other(args.config, path, H, W, np.ascontiguousarray(sample, dtype=np.float32), gpu_out)
         print(json.dumps(res), flush=True)
+    if tol is not None:
+        tol["eng"].close()
     eng.close()
     if dist:
         dist.destroy_process_group()

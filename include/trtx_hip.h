@@ -259,15 +259,15 @@ int32_t trtx_op_conv_force_tactic(const int32_t* tactic6);
 /* The same launch in an fp32 engine (builds without BuilderFlag::kFP16: yolov8/include/config.h:1-3 USE_FP32, yolov8/src/model.cpp:314-324):
  * NHWC fp32 in / out / residual, fp32 weights packed [cout_pad][kpad] (k = tap * cink + c, cink = Cin rounded up to the 16-channel k-step, or 8 for
  * Cin <= 8; Cin itself a multiple of 4), fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and sums).  trtx_op_conv2d_tactics_f32 lists the tile
- * configurations of the layer, 3 ints each {column-tile width, rows per tile, operand path: 1 = LDS-DMA, 5 = through registers} - entry 0 the launcher's
- * own choice, every entry the same bits -; tile3 pins one for this call (NULL: the launcher's choice). */
+ * configurations of the layer, 4 ints each {column-tile width, rows per tile, operand path: 1 = LDS-DMA, 5 = through registers, channels per k-step: 16 / 32} -
+ * entry 0 the launcher's own choice, every entry the same bits -; tile4 pins one for this call (NULL: the launcher's choice). */
 int32_t trtx_conv_packed_dims_f32(int cout, int cin_pad, int kh, int kw, int32_t* cout_pad, int32_t* kpad, int32_t* cink);
 int32_t trtx_conv_pack_weights_f32(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad, const float* ch_scale, float* packed);
 int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked, const float* bias, void* out, int Cout,
                                 int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int act1, const void* residual, int ld_res, int act2,
-                                const int32_t* tile3, trtx_stream_t stream);
+                                const int32_t* tile4, trtx_stream_t stream);
 int32_t trtx_op_conv2d_tactics_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
-                                   int has_residual, int ld_res, int32_t* out3, int32_t max_out);
+                                   int has_residual, int ld_res, int32_t* out4, int32_t max_out);
 /* Fused convolution chain, one launch: up to three stride-1 convolutions (3x3 pad 1 or 1x1, the same Cout in {16,32,64,80,128})
  * whose intermediate tensors stay in LDS - the C2f bottleneck 3x3 -> 3x3 (+ shortcut) of yolov8/src/block.cpp:98-110 and the
  * detect-head arms 3x3 -> 3x3 -> 1x1 of yolov8/src/model.cpp:188-251.  residual[s] != 0 adds the chain input to stage s (needs

@@ -62,6 +62,16 @@ class Params:
 
 
 # --------------------------------------------------------------------------------------------- LeNet-5
+
+class Params64(Params):
+    """load mode only: the same fp32 weights widened to float64 - the forward functions then evaluate the reference graph in double, the value an fp32
+    implementation (this oracle's own fp32 pass included: 5e-5 on YOLOv8n's O(30) head logits at 640 x 640) is a rounding of."""
+
+    def _get(self, name, shape, init):
+        v = torch.as_tensor(np.asarray(self.src[name], dtype=np.float32)).double().reshape(shape)
+        self.t[name] = v
+        return v
+
 def lenet(p: Params, x):
     """lenet/gen_wts.py:26-45 (max pooling; softmax appended as in lenet.cpp:133-137)."""
     y = F.conv2d(x, p._get("conv1.weight", (6, 1, 5, 5), lambda: p.randn(6, 1, 5, 5) * 0.2),

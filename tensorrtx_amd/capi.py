@@ -267,7 +267,7 @@ def pack_conv_weights_f32(w_kcrs, cin_pad=None, ch_scale=None):
 
 
 def conv2d_nhwc_f32(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", residual=None, act2="none", out=None, out_ld=None, tile=None):
-    """Single fused conv launch on NHWC fp32 tensors (x: [N,H,W,Cin] CUDA float32, Cin % 4 == 0); tile = (bn, bm, operand path) or None."""
+    """Single fused conv launch on NHWC fp32 tensors (x: [N,H,W,Cin] CUDA float32, Cin % 4 == 0); tile = (bn, bm, operand path, channels per k-step) or None."""
     import torch
     L = lib()
     N, H, W, Cin = x.shape
@@ -276,7 +276,7 @@ def conv2d_nhwc_f32(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", re
     if out is None:
         out = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     ld_out = out_ld or out.shape[-1]
-    t2 = (ctypes.c_int32 * 3)(*tile) if tile is not None else None
+    t2 = (ctypes.c_int32 * 4)(*tile) if tile is not None else None
     check(L.trtx_op_conv2d_nhwc_f32(_p(x), N, H, W, Cin, x.stride(2), _p(wpacked), _p(bias), _p(out), cout, ld_out, kh, kw, stride, stride, pad, pad,
                                     ACT[act1], _p(residual), residual.stride(2) if residual is not None else 0, ACT[act2], t2, _stream()),
           "trtx_op_conv2d_nhwc_f32")
@@ -284,11 +284,11 @@ def conv2d_nhwc_f32(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", re
 
 
 def conv2d_tactics_f32(N, H, W, Cin, Cout, k, stride, pad, residual=False, ld_in=None, ld_out=None, ld_res=None, max_out=32):
-    """The launch configurations (bn, bm, operand path) of one fp32 conv layer (host only); [0] is the launcher's own choice."""
-    arr = (ctypes.c_int32 * (3 * max_out))()
+    """The launch configurations (bn, bm, operand path, channels per k-step) of one fp32 conv layer (host only); [0] is the launcher's own choice."""
+    arr = (ctypes.c_int32 * (4 * max_out))()
     n = lib().trtx_op_conv2d_tactics_f32(N, H, W, Cin, ld_in or Cin, Cout, ld_out or Cout, k, k, stride, stride, pad, pad, 1 if residual else 0,
                                          (ld_res or Cout) if residual else 0, arr, max_out)
-    return [(arr[3 * i], arr[3 * i + 1], arr[3 * i + 2]) for i in range(n)]
+    return [(arr[4 * i], arr[4 * i + 1], arr[4 * i + 2], arr[4 * i + 3]) for i in range(n)]
 
 
 # ---------------------------------------------------------------------------------------------------- fused conv chains (tests / tools)

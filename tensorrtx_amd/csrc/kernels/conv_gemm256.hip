@@ -318,7 +318,9 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
 }  // namespace
 
 // fp16 plain GEMM (1x1, stride 1, unpadded, Cin == CinK), K a whole number of 64-wide tiles and at least 4 of them, Cout a whole number of 256-wide
-// tiles (the packed weights have exactly Cout_pad rows), 16-byte rows everywhere, the addressed slices below 2 GB, and enough tiles to matter
+// tiles (the packed weights have exactly Cout_pad rows), 16-byte rows everywhere, the addressed slices below 2 GB.  This is the LAUNCH-time predicate: it holds
+// at every batch up to the one the engine was built for (it used to contain the profitability rule below, which depends on the runtime batch - a
+// layer the tuner had put on this tile at max_batch was then refused at a smaller batch and the whole enqueue failed).
 bool conv_gemm256_possible(const ConvArgs& a) {
     if (a.in_i8 || a.out_i8 || a.res_i8 || a.up_C || a.scalar_out || a.groups != 1) return false;
     const bool plain = a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K;
@@ -330,8 +332,14 @@ bool conv_gemm256_possible(const ConvArgs& a) {
     if (a.Kpad % 64 || a.Kpad < 256 || a.Cout_pad % 256 || a.Cout % 8 || a.ld_in % 8 || a.ld_out % 8 || (a.residual && a.ld_res % 8)) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     if ((double)M * a.ld_in * 2.0 >= 2.0e9 || (double)a.Cout_pad * a.Kpad * 2.0 >= 2.0e9) return false;
-    // a candidate from 96 tiles on (one tile per CU on a third of the chip): whether it beats the 128-row tiles there is the tactic timing's call
-    return ((M + 255) / 256) * (a.Cout_pad / 256) >= 96;
+    return true;
+}
+
+// ... and the rule that makes it a CANDIDATE of the tactic timing (conv_tactics(), at the batch the engine is built for): from 96 tiles on - one tile per CU on a
+// third of the chip; whether it beats the 128-row tiles there is the timing's call
+bool conv_gemm256_worthwhile(const ConvArgs& a) {
+    const long M = (long)a.N * a.Ho * a.Wo;
+    return conv_gemm256_possible(a) && ((M + 255) / 256) * (a.Cout_pad / 256) >= 96;
 }
 
 int32_t conv_gemm256_f16(const ConvArgs& a0, hipStream_t s) {

@@ -963,7 +963,7 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
     else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only) ? 2 : 1, 1);
     // the 256 x 256 x 64 role-alternating tile for large plain GEMMs (conv_gemm256.hip): more work-efficient than any 128-row tile
     static const bool no_g256 = getenv("TRTX_GEMM256") != nullptr && atoi(getenv("TRTX_GEMM256")) == 0;
-    if (fp16 && !no_g256 && conv_gemm256_possible(a)) push(256, 64, 256, 1, 1);
+    if (fp16 && !no_g256 && conv_gemm256_worthwhile(a)) push(256, 64, 256, 1, 1);
     const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
     static const int bns[5] = {128, 80, 64, 32, 16};
     for (int bi = 0; bi < 5; ++bi) {

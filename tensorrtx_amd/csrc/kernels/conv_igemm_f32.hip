@@ -26,7 +26,7 @@ ConvArgs kernel_units(const ConvArgs& a) {
     ConvArgs k = a;
     k.Cin = 2 * a.Cin; k.ld_in = 2 * a.ld_in; k.CinK = 2 * a.CinK; k.K = 2 * a.K; k.Kpad = 2 * a.Kpad;
     k.up_C = 2 * a.up_C; k.up_ld = 2 * a.up_ld;
-    k.bk = 32;
+    k.bk = 2 * a.bk;
     return k;
 }
 
@@ -38,12 +38,28 @@ bool plain_gemm_f32(const ConvArgs& a) {
 // the 64- and 128-row tiles of the general and the plain-GEMM walk
 bool rs_exists(const ConvArgs& a, int bn, int bm) { return a.CinK != 8 && a.up_C == 0 && bm <= 128 && bn >= 32; }
 
+// 32-channel k-steps (ConvArgs::bk == 32: 128-byte LDS rows = whole cache lines per row, two LDS stages): layers whose channels per tap are a multiple of 32;
+// the same packed weights and the same bits as the 16-channel step.  Instantiated for the 64- and 128-row tiles, 32..128 columns wide, of the general and the
+// plain-GEMM walk and of the folded upsample
+bool wide_exists(const ConvArgs& a, int bn, int bm) { return a.CinK % 32 == 0 && a.Kpad % 32 == 0 && bm <= 128 && bn >= 32 && (a.up_C % 32) == 0; }
+
 template <int NFRAG, int MI>
 void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
     const int BN = 16 * NFRAG, BMT = 64 * MI;
     const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.Cout_pad / BN;
     const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
     const dim3 grid(chunk * 8), block(256);
+    if constexpr (MI <= 2 && NFRAG >= 2) {
+        if (a.bk == 32) {
+            if (a.up_C > 0)
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 64, 1, false, MI, 1, 0, false, 4, false, true, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            else if (plain_gemm_f32(a))
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 64, 1, false, MI, 1, 0, false, 4, false, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            else
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 64, 1, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            return;
+        }
+    }
 #ifdef TRTX_CONV_ABLATE   // timing experiments only (tools/f32_ablation.sh): TRTX_CONV_DBG as in the fp16 kernel, TRTX_F32_NST = 4 / 6 LDS stages (128 x 64 tile)
     static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
     static const int nst = getenv("TRTX_F32_NST") ? atoi(getenv("TRTX_F32_NST")) : 0;
@@ -69,7 +85,7 @@ void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigne
         if constexpr (MI == 2 && NFRAG <= 4)
             TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 2, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
     } else if (a.up_C > 0) {
-        if constexpr (MI <= 2 && NFRAG >= 2)
+        if constexpr (MI <= 2)
             TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, true, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
     } else if (plain_gemm_f32(a)) {
         TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
@@ -84,7 +100,7 @@ bool tile_exists(const ConvArgs& a, int bn, int bm) {
     if (bm != 64 && bm != 128 && bm != 256) return false;
     if (bm == 256 && bn == 128) return false;               // 128 accumulator registers + 48 of fragments: no
     if (a.CinK == 8) return bm == 128 && bn <= 64;
-    if (a.up_C > 0) return bm <= 128 && bn >= 32;
+    if (a.up_C > 0) return bm <= 128;
     return true;
 }
 
@@ -103,30 +119,25 @@ int32_t launch_f32_bn(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, u
     return TRTX_OK;
 }
 
-// The untuned tile of a layer.  The kernel is bound by the matrix pipe, so what a tile shape decides is how evenly the 256 CUs are loaded
-// (tiles per CU: the last round of a launch with 1.2 tiles per CU runs at 20 % occupancy) against what a smaller tile re-reads (the weight tile
-// per row tile, the A tile per column tile - L2 traffic that stays far below the fill rate here): the largest tile that still leaves >= 4 tiles
-// per CU, otherwise the smallest instantiated one.
+// The untuned tile of a layer (measured, profiles/r05_f32_shape_ab.txt: every shape lands within a few per cent of every other - the kernel's k-loop sustains
+// ~0.6 of the matrix pipe whatever the tile - so the rule only has to avoid the bad corners): the widest column tile that divides the padded Cout (a narrower one
+// re-reads the A tile Cout_pad / bn times; 64 instead of 128 when 128 would leave fewer than four tiles per CU), 64-row tiles (six workgroups per CU instead of
+// four, half the tail) unless the map is so large that even 128-row tiles give sixteen tiles per CU.
 void default_tile(const ConvArgs& a, int* bn_out, int* bm_out) {
     static const int bns[5] = {128, 80, 64, 32, 16};
-    static const int bms[3] = {256, 128, 64};
-    int best_bn = 0, best_bm = 0;
-    long best_area = 0;
-    int small_bn = 0, small_bm = 0;
-    long small_tiles = -1;
+    *bn_out = *bm_out = 0;
     for (int bn : bns) {
         if (a.Cout_pad % bn) continue;
-        if (bn <= 32 && a.Cout_pad > 2 * bn && a.Cout_pad % 64 == 0) continue;   // narrow tiles only where the layer is narrow
-        for (int bm : bms) {
-            if (!tile_exists(a, bn, bm)) continue;
-            const long tiles = ((long)a.M + bm - 1) / bm * (a.Cout_pad / bn);
-            const long area = (long)bn * bm;
-            if (tiles >= 4 * 256 && area > best_area) { best_area = area; best_bn = bn; best_bm = bm; }
-            if (tiles > small_tiles) { small_tiles = tiles; small_bn = bn; small_bm = bm; }
-        }
+        int bm = 64;
+        if (!tile_exists(a, bn, bm)) bm = 128;
+        if (!tile_exists(a, bn, bm)) continue;
+        const long tiles64 = ((long)a.M + 63) / 64 * (a.Cout_pad / bn);
+        if (bn == 128 && tiles64 < 4 * 256 && tile_exists(a, 64, bm)) continue;   // take the 64-wide tile
+        if (tiles64 >= 32 * 256 && tile_exists(a, bn, 128)) bm = 128;
+        *bn_out = bn;
+        *bm_out = bm;
+        return;
     }
-    *bn_out = best_bn ? best_bn : small_bn;
-    *bm_out = best_bn ? best_bm : small_bm;
 }
 
 }  // namespace
@@ -134,7 +145,8 @@ void default_tile(const ConvArgs& a, int* bn_out, int* bm_out) {
 int conv_igemm_f32_pick_cink(int cin) { return cin <= 8 ? 8 : (cin + 15) / 16 * 16; }
 
 bool conv_igemm_f32_supported(const ConvArgs& a) {
-    if (!a.f32 || a.in_i8 || a.out_i8 || a.res_i8) return false;
+    if (!a.f32 || a.in_i8 || a.out_i8 || a.res_i8 || (a.bk != 16 && a.bk != 32)) return false;
+    if (a.bk == 32 && !(a.bn && a.bm)) return false;   // the wide step is a named tactic (conv_tactics_f32), never the launcher's own choice
     if (a.groups != 1 || a.dil_h != 1 || a.dil_w != 1) return false;
     if (a.Cin % 4 || a.ld_in % 4) return false;                      // 16-byte channel chunks
     if (a.CinK != conv_igemm_f32_pick_cink(a.Cin) || a.K != a.kh * a.kw * a.CinK || a.Kpad != (a.K + 15) / 16 * 16) return false;
@@ -149,7 +161,12 @@ bool conv_igemm_f32_supported(const ConvArgs& a) {
     if (a.bn || a.bm) {   // a tactic was named
         const int bm = a.bm ? a.bm : 128;
         if (!a.bn || a.Cout_pad % a.bn || !tile_exists(a, a.bn, bm)) return false;
-        if (a.t_ws == 5 && !rs_exists(a, a.bn, bm)) return false;
+        if (a.t_ws == 5 && (!rs_exists(a, a.bn, bm) || a.bk != 16)) return false;
+        if (a.bk == 32 && !wide_exists(a, a.bn, bm)) return false;
+    } else {   // the launcher's own choice must exist (a folded upsample into 16 output channels has no instantiation)
+        int bn = 0, bm = 0;
+        default_tile(a, &bn, &bm);
+        if (!bn) return false;
     }
     return true;
 }
@@ -159,10 +176,10 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
     a.bn = 0; a.bm = 0;
     if (!conv_igemm_f32_supported(a)) return 0;
     int n = 0;
-    auto push = [&](int bn, int bm, int ws = 1) {
+    auto push = [&](int bn, int bm, int ws = 1, int bk = 16) {
         for (int i = 0; i < n; ++i)
-            if (out[i].bn == bn && out[i].bm == bm && out[i].ws == ws) return;
-        if (n < max_out) out[n++] = ConvTactic{bn, 16, bm, 1, ws, 0};
+            if (out[i].bn == bn && out[i].bm == bm && out[i].ws == ws && out[i].bk == bk) return;
+        if (n < max_out) out[n++] = ConvTactic{bn, bk, bm, 1, ws, 0};
     };
     int bn0, bm0;
     default_tile(a, &bn0, &bm0);
@@ -175,6 +192,7 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
         for (int bm : bms)
             if (tile_exists(a, bn, bm)) {
                 push(bn, bm);
+                if (wide_exists(a, bn, bm)) push(bn, bm, 1, 32);
                 if (rs_exists(a, bn, bm)) push(bn, bm, 5);
             }
     }

@@ -337,7 +337,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx4 (&acc)[
 
 // ---- epilogue of the fp32 kernels (conv_igemm_f32.hip).  The accumulator fragment of a lane is already what an NHWC fp32 store wants: four consecutive
 // channels (16j + 4 (lane >> 4) + [0, 4)) of one pixel = 16 bytes, the four lane groups of a pixel cover 64 contiguous bytes.  No staging through LDS, no
-// barrier: bias / activation / shortcut / store straight from the registers.  SiLU / sigmoid are v * rcp(1 + exp2(-v log2 e)) on the hardware's v_exp_f32 /
+// barrier: activation / shortcut / store straight from the registers (the bias is where the sums started).  SiLU / sigmoid are v * rcp(1 + exp2(-v log2 e)) on the hardware's v_exp_f32 /
 // v_rcp_f32 (1 ulp each): 5 instructions per element where expf + an IEEE division are ~30.  Measured on the first build (round 5): with the accurate
 // forms a 128 x 80 tile's epilogue was ~7k cycles of VALU issue per wave - 12 % of a 45-step 3x3 and MORE than the whole k-loop of a 4-step 1x1 - for an
 // error 60x below what 63 layers of fp32 summation leave on a logit (7e-5 at 640 x 640, against BASELINE's 1e-4).  The row slabs are walked by a rolled
@@ -365,14 +365,7 @@ __device__ __forceinline__ void conv_epilogue_f32(const ConvArgs& p, floatx4 (&a
     const float* __restrict__ res = static_cast<const float*>(p.residual);
     const int px_in = lane & 15;
     const int ch_in = (lane >> 4) * 4;
-    const bool vec = !p.scalar_out;
-    floatx4 bias[NFRAG];
-#pragma unroll
-    for (int j = 0; j < NFRAG; ++j) bias[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {   // wave-uniform; [Cout_pad] values, n0 + 16 NFRAG <= Cout_pad
-#pragma unroll
-        for (int j = 0; j < NFRAG; ++j) bias[j] = *reinterpret_cast<const floatx4*>(p.bias + n0 + j * 16 + ch_in);
-    }
+    const bool vec = !p.scalar_out;   // (the bias is already in the accumulators: conv_igemm_tile starts the sums at it)
 #pragma nounroll
     for (int i = 0; i < MI; ++i) {
         floatx4 v[NFRAG];
@@ -387,7 +380,7 @@ __device__ __forceinline__ void conv_epilogue_f32(const ConvArgs& p, floatx4 (&a
         for (int j = 0; j < NFRAG; ++j) {
             const int co = n0 + j * 16 + ch_in;
             if (m < 0 || co >= p.Cout) continue;
-            floatx4 x = v[j] + bias[j];
+            floatx4 x = v[j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = act_f32(x[e], p.act1, p.alpha1);
             if (res) {
@@ -665,13 +658,27 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 
     floatx4 acc[MI][NFW];
     intx4 acci[MI][NFW];
+    floatx4 part[F32 ? MI : 1][F32 ? NFW : 1];   // fp32: the running k-step's partial sum (two-level sum, see compute())
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NFW; ++j) {
             acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
             acci[i][j] = intx4{0, 0, 0, 0};
+            if constexpr (F32) part[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
+    if constexpr (F32) {
+        // fp32: the running total STARTS at the bias (a lane's fragment is four consecutive channels of one pixel, the same four for every row slab), so
+        // the fetch passes under the first tiles' round trip to memory instead of standing, a full L2 latency, in front of the epilogue's first store
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) {
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(p.bias + n0 + (WN == 1 ? 0 : (wave & 1)) * NFW * 16 + j * 16 + (lane >> 4) * 4);   // [Cout_pad] values
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = b4;
+            }
+        }
+    }
 
     // fragment read offsets inside a stage: row (lane & 15), logical chunk (lane >> 4) [+ 4 for the second k-slice]
     const int frow = lane & 15;
@@ -696,23 +703,37 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
             // BASELINE's 1e-4, twice what the blocked sums of a CPU library leave.  So a k-step's 16 products are summed from zero (srcC = 0) and the
             // step's partial is then added to the running total by the vector ALU: chains of 16 and K / 16 instead of one of K (K = 576: ~4 + 6 ulp).
             // Four v_add_f32 per fragment and step in the shadow of 128 cycles of MFMA; costs a second set of accumulator registers.
-            static_assert(!F32 || (BKT == 32 && !I8 && !PRE), "fp32: 16-float k-steps");
-            floatx4 af[MI], bf[NFW], part[MI][NFW];
+            // The partial of step kt is added while step kt+1 runs: each fragment's add stands right in front of the MFMA that restarts its partial from
+            // zero, in the shadow of the MFMA issued before it (adds at the END of a step would wait for the step's last MFMAs and hold the wave's issue
+            // port for ~32 VALU instructions with the matrix pipe idle: measured -6 %).  `part` lives across steps; the last one is added after the loop.
+            // BKT == 64: a 32-channel step = 128-byte rows, whole cache lines per row (half the line requests per byte of the fill path - what bounds this
+            // kernel, DESIGN 5 "round 5"); computed as its two 16-channel halves one after the other, each with its own partial: the arithmetic of two
+            // 16-channel steps, so both step widths return the same bits.
+            static_assert(!F32 || (!I8 && !PRE), "fp32 operands");
+            __builtin_amdgcn_s_setprio(1);   // a wave in its MFMA phase goes first: the matrix pipe is what this kernel is priced on, and co-resident waves in
+                                             // their set-up / epilogue (VALU, transcendentals on the same issue port) otherwise open bubbles in it
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const floatx4*>(sb + a_frag + i * 16 * ROW_B + f_off[0]);
+            for (int h = 0; h < KSUB; ++h) {
+                floatx4 af[MI], bf[NFW];
 #pragma unroll
-            for (int j = 0; j < NFW; ++j) bf[j] = *reinterpret_cast<const floatx4*>(sb + b_frag + j * 16 * ROW_B + f_off[0]);
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const floatx4*>(sb + a_frag + i * 16 * ROW_B + f_off[h]);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
+                for (int j = 0; j < NFW; ++j) bf[j] = *reinterpret_cast<const floatx4*>(sb + b_frag + j * 16 * ROW_B + f_off[h]);
 #pragma unroll
                 for (int j = 0; j < NFW; ++j)
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s4], af[i][s4], s4 == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : part[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i) {
+                        acc[i][j] += part[i][j];
+                        part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][0], af[i][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    }
 #pragma unroll
-            for (int j = 0; j < NFW; ++j)
+                for (int s4 = 1; s4 < 4; ++s4)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] += part[i][j];
+                    for (int j = 0; j < NFW; ++j)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s4], af[i][s4], part[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
             return;
         }
 #pragma unroll
@@ -824,6 +845,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 
     if (dbg & 8) return;
     if constexpr (F32) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) acc[i][j] += part[i][j];   // the last step's partial
         conv_epilogue_f32<NFW, MI>(p, acc, lane, n0 + wave_n * NFW * 16, [&](int t) {
             const int m = m0 + t;
             return m < p.M ? m : -1;

@@ -103,7 +103,8 @@ bool conv_igemm_group_supported(const ConvArgs* a, int n);
 int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s);
 // Large plain-GEMM convolutions on the 256 x 256 x 64 role-alternating tile (conv_gemm256.hip): the tactic ConvArgs::bn == 256 of the
 // implicit-GEMM family (same packed weights, same bits); conv_igemm_f16 dispatches to it
-bool conv_gemm256_possible(const ConvArgs& a);
+bool conv_gemm256_possible(const ConvArgs& a);     // may run (any batch up to the build batch)
+bool conv_gemm256_worthwhile(const ConvArgs& a);   // is a candidate of the tactic timing at this batch
 int32_t conv_gemm256_f16(const ConvArgs& a, hipStream_t s);
 // fp32 engines: the same skeleton on v_mfma_f32_16x16x4_f32 (conv_igemm_f32.hip).  ConvArgs::f32 = 1, bn / bm = 0: the launcher's own tile choice
 int conv_igemm_f32_pick_cink(int cin);

@@ -165,16 +165,17 @@ extern "C" int32_t trtx_conv_pack_weights_f32(const float* w_kcrs, int cout, int
 }
 
 extern "C" int32_t trtx_op_conv2d_tactics_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph,
-                                              int pw, int has_residual, int ld_res, int32_t* out2, int32_t max_out) {   // (3 ints per entry)
+                                              int pw, int has_residual, int ld_res, int32_t* out2, int32_t max_out) {   // (4 ints per entry)
     if (!out2 || max_out < 1 || N < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1) return 0;
     ConvArgs a = op_conv_args_f32(N, H, W, Cin, ld_in, Cout, ld_out, kh, kw, sh, sw, ph, pw, 0, has_residual, ld_res, 0);
     a.residual = has_residual ? reinterpret_cast<const void*>(1) : nullptr;
     std::vector<ConvTactic> t(max_out);
     const int n = conv_tactics_f32(a, t.data(), max_out);
     for (int i = 0; i < n; ++i) {
-        out2[3 * i + 0] = t[i].bn;
-        out2[3 * i + 1] = t[i].bm;
-        out2[3 * i + 2] = t[i].ws;
+        out2[4 * i + 0] = t[i].bn;
+        out2[4 * i + 1] = t[i].bm;
+        out2[4 * i + 2] = t[i].ws;
+        out2[4 * i + 3] = t[i].bk;
     }
     return n;
 }
@@ -193,6 +194,7 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, 
         a.bn = tile2[0];
         a.bm = tile2[1];
         a.t_ws = tile2[2];
+        a.bk = tile2[3];
     }
     static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;   // timing tools only
     int32_t st = TRTX_OK;

@@ -1303,8 +1303,9 @@ struct Lowerer {
     // exactly as its own launch computes it: bit-identical outputs.  TRTX_GROUP_CONVS=0 keeps one launch per convolution (A/B, tests).
     void group_convs() {
         if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
+        bool mark_only = false;   // TRTX_GROUP_CONVS=0: one launch per convolution, but the would-be members keep the group's K order (t_wsk = 1): same bits
         if (const char* e = getenv("TRTX_GROUP_CONVS"))
-            if (atoi(e) == 0) return;
+            if (atoi(e) == 0) mark_only = true;
         const int n = (int)plan.ops.size();
         if (n < 2 || n > 4096) return;
         // all dependencies (RAW, WAR, WAW at storage / channel-range granularity, as finalize step 5 computes them) in the current order
@@ -1415,13 +1416,14 @@ struct Lowerer {
                 if (!indep) continue;
                 margs.push_back(args_at_max_batch(plan.ops[j]));
                 // the operand path (t_rs: registers or LDS-DMA, the same bits either way) is a per-layer heuristic; a group runs on the
-                // path of its member with the most rows
+                // path of its member with the most rows.  Checked on a COPY (a rejected candidate used to leave its t_rs on the others)
+                std::vector<ConvArgs> trial = margs;
                 int big = 0;
-                for (size_t q = 1; q < margs.size(); ++q)
-                    if (margs[q].M > margs[big].M) big = (int)q;
-                const int rs = margs[big].t_rs;
-                for (ConvArgs& ma : margs) ma.t_rs = rs;
-                if (!conv_igemm_group_supported(margs.data(), (int)margs.size())) {
+                for (size_t q = 1; q < trial.size(); ++q)
+                    if (trial[q].M > trial[big].M) big = (int)q;
+                const int rs = trial[big].t_rs;
+                for (ConvArgs& ma : trial) ma.t_rs = rs;
+                if (!conv_igemm_group_supported(trial.data(), (int)trial.size())) {
                     margs.pop_back();
                     continue;
                 }
@@ -1437,6 +1439,11 @@ struct Lowerer {
             }
         }
         if (groups.empty()) return;
+        if (mark_only) {
+            for (const auto& mem : groups)
+                for (int m : mem) plan.ops[m].conv.t_wsk = 1;
+            return;
+        }
         // new order: Kahn over the contracted graph, ready nodes taken in the order of their first member's old position
         std::vector<int> node(n);
         int nn = 0;
@@ -1485,6 +1492,10 @@ struct Lowerer {
             for (int m : groups[group_of[k0]]) {
                 POp mo = plan.ops[m];
                 mo.conv.t_rs = plan.ops[big].conv.t_rs;
+                // ONE summation order per member, grouped or not: the grouped kernel walks K as the main kernel does, so the member's own launch -
+                // the fallback the executor takes at a batch where the members no longer share an instantiation, and TRTX_GROUP_CONVS=0 - must not pick
+                // the wave-split-K variant (different K order: the same engine rounded differently depending on batch size and on the switch)
+                mo.conv.t_wsk = 1;
                 g.group.push_back(mo);
                 g.name += (g.name.empty() ? "" : " + ") + mo.name;
                 for (int t : mo.in)

@@ -46,6 +46,64 @@ def gather_counts(local_counts, dist):
     return out
 
 
+def gpu_numa_cpus(device_index):
+    """CPUs of the NUMA node the GPU `device_index` hangs off: PCI bus id of the HIP device (hipDeviceGetPCIBusId, through torch's device
+    properties) -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist.  Returns (sorted cpu list, note); the
+    list is empty when the node cannot be determined (single-node hosts report numa_node = -1, containers may hide sysfs) - the caller then
+    leaves the affinity alone."""
+    import os
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception as e:  # noqa: BLE001
+        return [], f"no PCI bus id ({e})"
+    try:
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read().strip())
+    except Exception as e:  # noqa: BLE001
+        return [], f"{bus}: numa_node unreadable ({type(e).__name__})"
+    if node < 0:
+        return [], f"{bus}: numa_node = {node} (single-node host)"
+    try:
+        cpus = parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except Exception as e:  # noqa: BLE001
+        return [], f"{bus}: node {node}, cpulist unreadable ({type(e).__name__})"
+    allowed = os.sched_getaffinity(0)
+    cpus = [c for c in cpus if c in allowed]
+    return cpus, f"{bus}: NUMA node {node}, {len(cpus)} cpus"
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]  (the kernel's cpulist format)"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return sorted(set(out))
+
+
+def pin_to_gpu_numa_node(device_index, local_rank=0, local_world=1):
+    """Pin the calling process (and the threads it starts afterwards) to the cores of its GPU's NUMA node - VERDICT r4 item 8: with eight ranks on one host
+    a rank whose launch thread or pinned-buffer copies run on the far socket pays cross-socket latency on every enqueue and on the host-fed path's H2D
+    staging.  When several local ranks share a node, each takes its own contiguous slice of that node's cores.  Returns a note for the bench line; never
+    raises (an affinity the host refuses is reported, not fatal)."""
+    import os
+    cpus, note = gpu_numa_cpus(device_index)
+    if not cpus:
+        return "affinity unchanged - " + note
+    try:
+        # ranks sharing the node: split its cores evenly by local rank (no knowledge of the other ranks' nodes needed when ranks are dealt round-robin)
+        share = max(1, min(local_world, len(cpus)))
+        per = len(cpus) // share
+        mine = cpus[(local_rank % share) * per:(local_rank % share + 1) * per] if per >= 2 else cpus
+        os.sched_setaffinity(0, mine)
+        return f"pinned to {len(mine)} cpus [{mine[0]}..{mine[-1]}] - {note}"
+    except Exception as e:  # noqa: BLE001
+        return f"affinity unchanged ({type(e).__name__}: {e}) - {note}"
+
+
 class DeviceReplicas:
     """One process driving several GPUs: a replica (engine + context + stream + bindings) per device, images dealt to the
     replicas by `partition`, no cross-device traffic (the reference's own recipe, tutorials/multi_GPU_processing.md:13-30:

@@ -70,6 +70,32 @@ def test_bench_control_flow_c4_strong_split_builds_small_batch_engines():
     assert engine.describe_plan(plan, lowered=True)["max_batch"] == 1
 
 
+def test_bench_control_flow_c4_eight_ranks_one_image_each():
+    """the driver's 8-GPU line for C4 - `--gpus 8 --config retinaface_r50`, strong scaling by default: rank k gets image k of the global
+    batch of 8 - rehearsed with eight gloo ranks: plan broadcast of a batch-1 engine, per-rank partition, barriers, max over ranks, one JSON line."""
+    d = _run(8, ("--config", "retinaface_r50"))
+    assert d["scaling"] == "strong" and d["n_gpus"] == 8 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_numa_pinning_helpers_without_a_gpu():
+    """replicas.pin_to_gpu_numa_node: cpulist parsing, and no GPU / no sysfs entry leaves the affinity alone and says why (never raises)."""
+    from tensorrtx_amd import replicas
+    assert replicas.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and replicas.parse_cpulist("5") == [5]
+    before = os.sched_getaffinity(0)
+    note = replicas.pin_to_gpu_numa_node(0, 0, 1)
+    assert note.startswith("affinity unchanged") and os.sched_getaffinity(0) == before
+
+
+def test_bench_prints_the_tolerance_engine_leg():
+    """the default line (yolov8n, fp16) carries `tolerance_engine` - the fp32 build timed like `value` - with its own legs, dtype and
+    roofline against the fp32 MFMA peak; --no-tolerance-engine drops it."""
+    d = _run(1)
+    t = d["tolerance_engine"]
+    assert t["dtype"] == "f32" and t["value"] > 0 and len(t["legs_ms"]) >= 3 and t["roofline"]["peak"] == 157.3 and t["roofline"]["launches_per_step"] >= 60
+    assert "tolerance_engine" not in _run(1, ("--no-tolerance-engine",))
+
+
 def test_bench_in_process_replicas_control_flow():
     """--replicas in-process: one process, N devices through DeviceReplicas (the reference's tutorials/multi_GPU_processing.md recipe); dry run
     with three stand-in devices: every device gets a batch per step, value = all devices' images over the host clock."""

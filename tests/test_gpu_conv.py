@@ -134,6 +134,31 @@ TACTIC_CASES = [
 ]
 
 
+def test_the_256x256_tile_chosen_at_the_build_batch_runs_at_a_smaller_batch(gpu):
+    """conv_gemm256_possible() held the '>= 96 tiles' profitability rule, which depends on the RUNTIME batch - a layer the tuner had put on the
+    256 x 256 x 64 tile at max_batch was refused at a smaller batch and the whole enqueue failed (R-CNN res4 at 800 x 1344: 132 tiles at batch 2, 68 at batch 1).
+    The rule now only decides candidacy; the tile itself launches at any batch and returns the 128-row tiles' bits."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    Cin, Cout, H, W = 256, 256, 50, 84      # batch 8: 132 tiles (a candidate), batch 1: 17 tiles
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+    packed, cout_pad, kpad, bn = capi.pack_conv_weights_f16(w.numpy(), cin_pad=Cin)
+    wg, bg = torch.from_numpy(packed.view(np.int16)).to(gpu), torch.zeros(cout_pad, device=gpu)
+    t256 = (256, 64, 256, 1, 1, 0)
+    assert t256 in capi.conv2d_tactics(8, H, W, Cin, Cout, 1, 1, 0) and t256 not in capi.conv2d_tactics(1, H, W, Cin, Cout, 1, 1, 0)
+    for n in (8, 1):
+        x = torch.randn(n, H, W, Cin, generator=g).half().to(gpu)
+        try:
+            capi.conv_force_tactic(t256)
+            y = capi.conv2d_nhwc_f16(x, wg, bg, Cout, 1, 1, 1, 0, "relu")
+            capi.conv_force_tactic((128, 32, 128, 1, 1, 0))
+            y0 = capi.conv2d_nhwc_f16(x, wg, bg, Cout, 1, 1, 1, 0, "relu")
+        finally:
+            capi.conv_force_tactic(None)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y0), f"batch {n}"
+
+
 @pytest.mark.parametrize("case", TACTIC_CASES)
 def test_every_conv_tactic_is_the_same_convolution(gpu, case):
     import torch

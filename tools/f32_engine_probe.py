@@ -117,7 +117,12 @@ def main():
         for i, h in enumerate(heads):
             got = b2[e2.names.index(f"head{i}")].reshape(nb, *h.shape[1:]).cpu()
             worst = max(worst, (got - h).abs().max().item())
-        print(f"head tensors vs fp32 oracle ({nb} images): max abs err {worst:.3g}")
+        with torch.inference_mode():
+            heads64, _ = mt.yolov8_det(mt.Params64(owts.load_wts(path)), torch.from_numpy(x[:nb]).double())
+        worst64 = max((b2[e2.names.index(f"head{i}")].reshape(nb, *h.shape[1:]).cpu().double() - h).abs().max().item() for i, h in enumerate(heads64))
+        o64 = max((h.double() - g).abs().max().item() for h, g in zip(heads, heads64))
+        print(f"head tensors ({nb} images, logits up to {max(h.abs().max().item() for h in heads64):.1f}): max abs err {worst:.3g} vs the fp32 oracle, {worst64:.3g} vs the graph in double "
+              f"(the fp32 oracle itself: {o64:.3g})")
         # boxes: the TIMED engine's decode buffer (fused detect tail) against the oracle's decode of its own heads
         dec = bufs[e.names.index("output")].reshape(B, -1)[:nb].cpu().numpy()
         ref = yp.decode_c([h.numpy() for h in heads], 80, S, S, strides)
