@@ -755,7 +755,7 @@ def main():
         rows = []
         for _ in range(prof_runs):
             rows = e.profile(batch, bindings)
-            conv = [r for r, o in zip(rows, low["ops"]) if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] in ("conv_chain", "conv_group")]
+            conv = [r for r, o in zip(rows, low["ops"]) if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] == "conv_group"]
             n = len(conv)
             c_ms += sum(r["ms"] for r in conv)
             t_ms += sum(r["ms"] for r in rows)
@@ -791,22 +791,16 @@ def main():
     # YOLOv8n layers sit below the MFMA/HBM ridge (arithmetic intensity 16..290 FLOP/B against 312) -> bound "hbm";
     # ResNet-50 / RetinaFace / R-CNN are dominated by layers above it -> bound "mfma".  Both views are always printed.
     # (a grouped launch - 2..4 independent sibling convolutions in one dispatch, round 4 - is ONE launch priced on the bytes of all its members)
-    launch_ops = [o for o in low["ops"] if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] in ("conv_chain", "conv_group")]
+    launch_ops = [o for o in low["ops"] if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] == "conv_group"]
     n_group = sum(1 for o in launch_ops if o["kind"] == "conv_group")
     convs_in_groups = sum(len(o["members"]) for o in launch_ops if o["kind"] == "conv_group")
     igemm_ops = [m for o in launch_ops for m in (o["members"] if o["kind"] == "conv_group" else [dict(o)])]
     for m in igemm_ops:
         m.setdefault("kind", "conv")
-    n_chain = sum(1 for o in igemm_ops if o["kind"] == "conv_chain")
-    convs_in_chains = sum(len(o["stages"]) for o in igemm_ops if o["kind"] == "conv_chain")
     alg_bytes = 0.0
     flop_per_step = 0.0
     for o in igemm_ops:
         nb = o.get("nfix") or batch              # images per launch = nb * nmul (nmul: RoIs per image in the R-CNN head)
-        if o["kind"] == "conv_chain":            # a fused chain: its input and its output once, the intermediates never reach memory
-            alg_bytes += 2.0 * o["hw_in"][0] * o["hw_in"][1] * (o["cin"] + o["cout"]) * nb * o.get("nmul", 1) + o["weight_bytes"]
-            flop_per_step += o["flops"] * nb
-            continue
         i8 = o.get("i8", [0, 0, 0])
         es_in, es_out, es_res = (1.0 if i8[0] else 2.0), (1.0 if i8[1] else 2.0), (1.0 if i8[2] else 2.0)
         up_c = o.get("up_c", 0)   # folded upsample: those input channels are read from a tensor a quarter the size
@@ -824,9 +818,9 @@ def main():
     bound = "hbm" if intensity < MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS else "mfma"
     traffic, traffic_src = _traffic_from_profile(args.config)
     prof_us, prof_src = _kernel_duration_from_profile(args.config) if args.precision == "fp16" else (None, None)
-    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_chain_f16 / conv_igemm_f16 / conv_ws_f16 / conv_igemm_wsk_f16, all instantiations)",
-                "launches_per_step": n_conv, "grouped_launches": n_group, "convolutions_inside_groups": convs_in_groups, "fused_chain_launches": n_chain, "convolutions_inside_chains": convs_in_chains,
-                "bytes_priced": "algorithmic: fp16 activations in + out (+ residual) of every launch + its weights once; a fused chain is priced on its input and output only", "avg_launch_us": avg_launch_s * 1e6,
+    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_igemm_f16 / conv_igemm_group_f16 / conv_ws_f16 / conv_patch_f16 / conv_gemm256_f16 / conv_igemm_wsk_f16, all instantiations)",
+                "launches_per_step": n_conv, "grouped_launches": n_group, "convolutions_inside_groups": convs_in_groups,
+                "bytes_priced": "algorithmic: fp16 activations in + out (+ residual) of every launch + its weights once", "avg_launch_us": avg_launch_s * 1e6,
                 "timing": ("dispatch begin -> end of every conv launch (HIP events attached to the launch, hipExtLaunchKernelGGL), mean of 5 serialized profile passes"
                            if conv_ms_kernel else "interval between the HIP stream events around every conv op, mean of 5 serialized profile passes"),
                 "avg_launch_us_between_stream_events": conv_ms_events * 1e3 / max(n_conv, 1),

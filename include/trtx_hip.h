@@ -268,20 +268,7 @@ int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, int Cin, in
                                 const int32_t* tile4, trtx_stream_t stream);
 int32_t trtx_op_conv2d_tactics_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
                                    int has_residual, int ld_res, int32_t* out4, int32_t max_out);
-/* Fused convolution chain, one launch: up to three stride-1 convolutions (3x3 pad 1 or 1x1, the same Cout in {16,32,64,80,128})
- * whose intermediate tensors stay in LDS - the C2f bottleneck 3x3 -> 3x3 (+ shortcut) of yolov8/src/block.cpp:98-110 and the
- * detect-head arms 3x3 -> 3x3 -> 1x1 of yolov8/src/model.cpp:188-251.  residual[s] != 0 adds the chain input to stage s (needs
- * Cin == Cout).  Weights: trtx_conv_chain_pack_weights_f16 images (device pointers), bias fp32 [Cout] per stage.  tile_h / tile_w
- * 0 = chosen by the launcher.  trtx_op_conv_chain_plan (host only) reports the tile, LDS bytes and weight-ring depth it would use. */
-size_t trtx_conv_chain_packed_halfs(int cin, int cout, int k);
-int32_t trtx_conv_chain_pack_weights_f16(const float* w_kcrs, int cout, int cin, int k, const float* ch_scale, uint16_t* packed);
-int32_t trtx_op_conv_chain_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, void* out, int ld_out, int nstages,
-                                    const int32_t* k, const int32_t* cout, const int32_t* act, const int32_t* residual,
-                                    const void* const* wpacked, const float* const* bias, int tile_h, int tile_w, trtx_stream_t stream);
 int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream); /* test support: NaN patterns into every CU's LDS */
-int32_t trtx_op_conv_chain_set_stamps(void* device_buffer_512x16_u64); /* timing experiments: per-workgroup phase stamps; NULL = off */
-int32_t trtx_op_conv_chain_plan(int N, int H, int W, int Cin, int nstages, const int32_t* k, const int32_t* cout, const int32_t* residual,
-                                int tile_h, int tile_w, int32_t* out4);
 int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad, int ld_out,
                                      trtx_stream_t stream);
 int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ld_in,

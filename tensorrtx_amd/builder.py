@@ -115,6 +115,12 @@ class Network:
         check(self.L.trtx_layer_set_floats(self.n, l, 12, sc, 3), "trtx_layer_set_floats(resize scales)")   # TRTX_P_RESIZE_SCALES
         return l
 
+    def slice_channels(self, x, start, size, chw):
+        """ISliceLayer over the channel axis of a (C, H, W) tensor: channels [start, start + size) (block.cpp:134-149, the C2f split)"""
+        c, h, w = chw
+        st, sz, sp = _dims((start, 0, 0)), _dims((size, h, w)), _dims((1, 1, 1))
+        return self._layer(self.L.trtx_add_slice(self.n, x, ctypes.byref(st), ctypes.byref(sz), ctypes.byref(sp)), "add_slice")
+
     def concat(self, tensors):
         arr = (ctypes.c_int32 * len(tensors))(*tensors)
         return self._layer(self.L.trtx_add_concatenation(self.n, arr, len(tensors)), "add_concatenation")
@@ -122,6 +128,11 @@ class Network:
     def mark_output(self, tensor, name):
         check(self.L.trtx_tensor_set_name(self.n, tensor, name.encode()), "set_name")
         check(self.L.trtx_mark_output(self.n, tensor), "mark_output")
+
+    def set_int8_calibrator(self, cal):
+        """IBuilderConfig::setInt8Calibrator: cal is a tensorrtx_amd.calibrator.Calibrator (kept alive by this object)"""
+        self._keep.append(cal)
+        check(self.L.trtx_builder_set_int8_calibrator(self.b, ctypes.byref(cal.vtbl)), "trtx_builder_set_int8_calibrator")
 
     def build(self):
         hm = ctypes.c_void_p()

@@ -291,24 +291,7 @@ def conv2d_tactics_f32(N, H, W, Cin, Cout, k, stride, pad, residual=False, ld_in
     return [(arr[4 * i], arr[4 * i + 1], arr[4 * i + 2], arr[4 * i + 3]) for i in range(n)]
 
 
-# ---------------------------------------------------------------------------------------------------- fused conv chains (tests / tools)
-def pack_chain_weights_f16(w_kcrs, ch_scale=None):
-    """Host: KCRS fp32 numpy [Cout, Cin, k, k] -> packed uint16 [Cout, k*k*ceil(Cin/32)*32] for trtx_op_conv_chain_nhwc_f16."""
-    import numpy as np
-    L = lib()
-    L.trtx_conv_chain_packed_halfs.restype = ctypes.c_size_t
-    w = np.ascontiguousarray(w_kcrs, dtype=np.float32)
-    cout, cin, k, k2 = w.shape
-    assert k == k2
-    n = L.trtx_conv_chain_packed_halfs(cin, cout, k)
-    packed = np.zeros((cout, n // cout), dtype=np.uint16)
-    sc = np.ascontiguousarray(ch_scale, dtype=np.float32) if ch_scale is not None else None
-    check(L.trtx_conv_chain_pack_weights_f16(w.ctypes.data_as(ctypes.c_void_p), cout, cin, k,
-                                             sc.ctypes.data_as(ctypes.c_void_p) if sc is not None else None,
-                                             packed.ctypes.data_as(ctypes.c_void_p)), "trtx_conv_chain_pack_weights_f16")
-    return packed
-
-
+# ---------------------------------------------------------------------------------------------------- test support
 def poison_lds(sync=True):
     """Test support: fill every CU's LDS with fp16 NaN patterns (LDS is not cleared between kernels).  sync=False: only enqueued, on the
     current stream - the poisoning workgroups then run BESIDE whatever the other streams have in flight."""
@@ -317,35 +300,6 @@ def poison_lds(sync=True):
     check(lib().trtx_op_poison_lds(_p(w), _stream()), "trtx_op_poison_lds")
     if sync:
         torch.cuda.synchronize()
-
-
-def conv_chain_plan(N, H, W, Cin, ks, couts, residuals=None, tile=(0, 0)):
-    """(tile_h, tile_w, LDS bytes, k-steps per weight-ring slot; 0 = weights resident) the chain launcher would use, or None when the chain is unsupported. Host only."""
-    n = len(ks)
-    arr = ctypes.c_int32 * n
-    out = (ctypes.c_int32 * 4)()
-    st = lib().trtx_op_conv_chain_plan(N, H, W, Cin, n, arr(*ks), arr(*couts), arr(*(residuals or [0] * n)), tile[0], tile[1], out)
-    return tuple(out) if st == 0 else None
-
-
-def conv_chain_nhwc_f16(x, stages, out=None, tile=(0, 0)):
-    """One fused launch of a chain of stride-1 convolutions on an NHWC fp16 tensor (x: [N,H,W,Cin] CUDA half, channel stride x.stride(2)).
-    stages: list of dicts {k, cout, act, residual, w (packed, CUDA int16), bias (CUDA fp32 [cout])}."""
-    import torch
-    L = lib()
-    N, H, W, Cin = x.shape
-    n = len(stages)
-    cout = stages[-1]["cout"]
-    if out is None:
-        out = torch.empty((N, H, W, cout), dtype=torch.float16, device=x.device)
-    iarr = ctypes.c_int32 * n
-    parr = ctypes.c_void_p * n
-    check(L.trtx_op_conv_chain_nhwc_f16(_p(x), N, H, W, Cin, x.stride(2), _p(out), out.stride(2), n,
-                                        iarr(*[s["k"] for s in stages]), iarr(*[s["cout"] for s in stages]),
-                                        iarr(*[ACT[s.get("act", "none")] for s in stages]), iarr(*[1 if s.get("residual") else 0 for s in stages]),
-                                        parr(*[s["w"].data_ptr() for s in stages]), parr(*[s["bias"].data_ptr() for s in stages]),
-                                        tile[0], tile[1], _stream()), "trtx_op_conv_chain_nhwc_f16")
-    return out
 
 
 def conv2d_tactics(N, H, W, Cin, Cout, k, stride, pad, residual=False, ld_in=None, ld_out=None, ld_res=None, max_out=32):

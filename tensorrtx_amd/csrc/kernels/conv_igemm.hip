@@ -1,241 +1,14 @@
 // Host side of the implicit-GEMM convolution family (fp16 / int8): launchers, tactic lists, the grouped launch, the wave-split-K kernel.
 // The tile function, its epilogues and the two kernel entry points live in igemm_tile.h (shared with conv_igemm_f32.hip).
+#include "../options.h"
 #include "igemm_tile.h"
 
 namespace trtx {
 namespace {
 
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 stride-1 pad-1 variant with ROW REUSE ("r3").  In the kernel above the three taps (r, 0), (r, 1), (r, 2) of a filter row
-// fetch three A tiles that are the same pixels shifted by one: every input pixel crosses the L1 -> LDS path 9 times.  Here the
-// GEMM's M axis runs over the image with its two padding COLUMNS made explicit (pitch Wp = W + 2, position t <-> (n, h, wp),
-// input column wp - 1), so that "one pixel to the right" is always t + 1: ONE A tile per (filter row, channel slice) is loaded
-// and the three taps read it at row offsets 0, 1, 2.  A tile of BM rows therefore finishes BM - 2 positions (the last two rows
-// lack their right neighbours and are recomputed by the next tile); positions in the padding columns are computed and thrown
-// away (2 / Wp of the work).  A traffic through L1 -> LDS drops 3x; the weights of the three taps arrive as three B tiles per
-// step.  Same packed weights, so it is one more exchangeable tactic (ConvArgs::t_r3); K is walked (filter row, channel slice,
-// tap) instead of (tap, channel slice), so fp16 results may differ from the kernel above in the last place.
-// NSTAGES: LDS pipeline depth.  A step here carries three taps of MFMA work, so two stages already hide what three hide in the
-// kernel above - and 40 KB instead of 60 KB of LDS (64-wide column tile) lets four workgroups share a CU instead of two
-// (SQ counters of the 64 -> 64 3x3 80x80 layer, profiles/r02_sq_counters_64x64_3x3_80.txt: at two workgroups per CU this kernel
-// already matches the kernel above at four, with half the wave-cycles and a third of the wait cycles).
-// ROUND 4: NOT PART OF THE PRODUCT LIBRARY YET.  Round 3 found engines that had chosen this kernel returning results that differed between
-// execution contexts running side by side (tests/test_gpu_multi_context.py: 4 of 6 runs with it among the tactics, 0 of 12 without).  Root cause
-// (round 4, profiles/r04_r3_bisect.txt): in the THREE-stage instantiations the compiler placed the last 1-7 fragment reads of a k-step, and the
-// MFMAs that consume them, BELOW the next step's `s_waitcnt vmcnt` + `s_barrier` - nothing in the source forbade it - so a wave passed the barrier
-// that frees a stage with reads of that stage still queued.  The DMA pieces that refill the stage are, for this kernel's padding columns and
-// border rows, range-checked away: zero fill without a memory round trip, a few hundred cycles; with two 60 KB workgroups of this kernel and
-// another context's workgroups contending for the CU's LDS, those beat the queued reads.  Forced onto every layer it can take, three contexts in
-// flight: 64- and 32-wide three-stage tiles differ from the lone-context run in every run (whole XCD chunks of an early layer, errors O(1), no
-// NaN with poisoned LDS: stale-but-plausible data); two stages, and two stages with the three-stage LDS allocation, never; a second barrier after
-// the MFMAs or waiting for all loads does not help; `s_waitcnt lgkmcnt(0)` before the barrier does (identical in every run) - and is what the step
-// macro below now does.  The ISA scan tools/isa_barrier_reads.py finds the four three-stage instantiations of the round-3 kernel and nothing
-// else in the library.  The kernel stays compiled out (-DTRTX_EXPERIMENTAL_R3) until the fixed build has been through the full GPU suite and the
-// tuner's A/B again; without the define r3_possible() is false, no tactic names it and ConvArgs::t_r3 != 0 is refused.
-#ifdef TRTX_EXPERIMENTAL_R3
-template <int NFRAG, int BKT, int MI, int NSTAGES>
-__global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n, int total_tiles,
-                                                                int xcd_chunk) {
-    constexpr int BN = 16 * NFRAG;
-    constexpr int BM = 64 * MI;
-    constexpr int BME = BM - 2;                    // positions finished per tile
-    constexpr int WR = 16 * MI;
-    constexpr int ROW_B = BKT * 2;
-    constexpr int CH = BKT / 8;
-    constexpr int RPI = 64 / CH;
-    constexpr int A_LOADS = BM / (4 * RPI);
-    constexpr int B_PASSES = (BN + 4 * RPI - 1) / (4 * RPI);
-    constexpr int B_ROWS = B_PASSES * 4 * RPI;
-    constexpr int A_BYTES = BM * ROW_B;
-    constexpr int BT_BYTES = B_ROWS * ROW_B;       // weight tile of one tap
-    constexpr int STAGE_BYTES = A_BYTES + 3 * BT_BYTES;
-    constexpr int LOADS_PER_TILE = A_LOADS + 3 * B_PASSES;
-    constexpr int KSUB = BKT / 32;
-    constexpr int NST = NSTAGES;
-    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
-#if defined(R3_VARIANT) && R3_VARIANT == 8   // bisecting: the two-stage kernel with the LDS ALLOCATION of the three-stage one (the extra stage is never touched)
-    __shared__ __attribute__((aligned(16))) char smem[(NST + (BKT == 32 ? 1 : 0)) * STAGE_BYTES];
-#else
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
-#endif
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
-#if defined(R3_VARIANT) && R3_VARIANT == 16
-    if (tile >= total_tiles) return;
-#else
-    if (xcd_chunk) {
-        tile = (tile & 7) * xcd_chunk + (tile >> 3);
-        if (tile >= total_tiles) return;
-    }
-#endif
-    const int t0 = (tile / tiles_n) * BME;         // first position of the tile in the padded-column index space
-    const int n0 = (tile % tiles_n) * BN;
-    const int Wp = p.W + 2;
-    const int HWp = p.H * Wp;
-    const int Mp = p.N * HWp;
-
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
-
-    // exact position -> (image, row, padded column) with float reciprocals fixed up by one step (quotients are small)
-    const float inv_hwp = __builtin_amdgcn_rcpf((float)HWp), inv_wp = __builtin_amdgcn_rcpf((float)Wp);
-    auto split = [&](int t, int& n, int& h, int& wp) {
-        n = (int)((float)t * inv_hwp);
-        int rem = t - n * HWp;
-        if (rem < 0) { --n; rem += HWp; }
-        if (rem >= HWp) { ++n; rem -= HWp; }
-        h = (int)((float)rem * inv_wp);
-        wp = rem - h * Wp;
-        if (wp < 0) { --h; wp += Wp; }
-        if (wp >= Wp) { ++h; wp -= Wp; }
-    };
-
-    // ---- per-lane A source: LDS row rho holds position t0 - 1 + rho (the left neighbour of the tile's first position comes first)
-    const int lrow = lane / CH;
-    const int lswz = BKT == 32 ? swz<32>(lrow) : ((lrow >> 1) | ((wave & 1) << 2));
-    const int lchunk = (lane % CH) ^ lswz;
-    unsigned a_base[A_LOADS];   // byte offset of (n, h - 1, wp - 1, channel lchunk * 8): filter row 0; wraps for border pixels (masked)
-    unsigned a_rows[A_LOADS];   // bit r: filter row r of this position lies inside the image (0: padding column / outside the tensor)
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        const int t = t0 - 1 + (4 * i + wave) * RPI + lrow;
-        const bool in = t >= 0 && t < Mp;
-        int n, h, wp;
-        split(in ? t : 0, n, h, wp);
-        const bool col = wp >= 1 && wp <= p.W;
-        a_base[i] = (unsigned)(((n * p.H + h - 1) * p.W + wp - 1) * p.ld_in + lchunk * 8) * 2u;
-        a_rows[i] = (in && col) ? tap_range_mask(h - 1, 3, p.H) : 0u;
-    }
-    const int cmax = p.Cin - lchunk * 8;  // this lane's chunk holds real channels while uc < cmax
-    unsigned b_off[B_PASSES];
-#pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) {
-        const int row = (4 * j + wave) * RPI + lrow;
-        b_off[j] = row < BN ? (unsigned)(((n0 + row) * p.Kpad + lchunk * 8) * 2) : kOOB;
-    }
-
-    // wave-uniform walk: step e = (filter row r, channel slice uc)
-    const int spt = p.CinK / BKT;
-    const int nk = 3 * spt;
-    int s_kt = 0, s_r = 0, s_uc = 0;
-    const unsigned row_bytes = (unsigned)(p.W * p.ld_in) * 2u;   // one image row down
-    const unsigned tap_bytes = (unsigned)p.CinK * 2u;            // one tap along the packed K axis
-
-    auto issue_tile = [&](int stage) {
-        char* sbase = smem + stage * STAGE_BYTES;
-        const bool live = s_kt < nk;
-        const unsigned add = (unsigned)s_r * row_bytes + (unsigned)s_uc * 2u;
-        const bool chunk_ok = s_uc < cmax;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const bool ok = ((a_rows[i] >> s_r) & 1u) && chunk_ok && live;
-            const unsigned voff = ok ? a_base[i] + add : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sbase + (4 * i + wave) * RPI * ROW_B), 16, voff, 0, 0, 0);
-        }
-        const unsigned kadd = (unsigned)(s_r * 3) * tap_bytes + (unsigned)s_uc * 2u;   // tap (r, 0) of this channel slice
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int j = 0; j < B_PASSES; ++j) {
-                const unsigned voff = (live && b_off[j] != kOOB) ? b_off[j] + kadd + (unsigned)q * tap_bytes : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + A_BYTES + q * BT_BYTES + (4 * j + wave) * RPI * ROW_B), 16, voff,
-                                                         0, 0, 0);
-            }
-        ++s_kt;
-        s_uc += BKT;
-        const int wrap = s_uc >= p.CinK;
-        s_uc = wrap ? 0 : s_uc;
-        s_r += wrap;
-    };
-
-    floatx4 acc[MI][NFRAG];
-    intx4 acci[MI][NFRAG];  // unused (the shared epilogue's int8 leg)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NFRAG; ++j) {
-            acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-            acci[i][j] = intx4{0, 0, 0, 0};
-        }
-
-    // fragment read offsets: B rows (lane & 15) as in the kernel above; A rows (lane & 15) + q for tap q.  The swizzle is keyed by
-    // the LDS row, and tile / fragment bases are multiples of 16 rows, so it is the swizzle of (lane & 15) + q.
-    const int frow = lane & 15;
-    int fb_off[KSUB], fa_off[3][KSUB];
-#pragma unroll
-    for (int h = 0; h < KSUB; ++h) {
-        fb_off[h] = frow * ROW_B + ((((lane >> 4) + 4 * h) ^ swz<BKT>(frow)) * 16);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) fa_off[q][h] = (frow + q) * ROW_B + ((((lane >> 4) + 4 * h) ^ swz<BKT>(frow + q)) * 16);
-    }
-    const int a_frag = wave * WR * ROW_B;
-
-    auto compute = [&](int stage) {
-        const char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h = 0; h < KSUB; ++h) {
-                half8 af[MI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8*>(sb + a_frag + i * 16 * ROW_B + fa_off[q][h]);
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j) {
-                    const half8 bf = *reinterpret_cast<const half8*>(sb + A_BYTES + q * BT_BYTES + j * 16 * ROW_B + fb_off[h]);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
-                }
-            }
-    };
-
-    // R3_VARIANT (bisecting builds, profiles/r04_r3_bisect.txt): 0 = the kernel with its fix (fragment reads complete, lgkmcnt(0), before the
-    // barrier that frees their stage); 32 = the round-3 kernel (no such wait: reproduces the hazard; "variant 0" in the record, which predates
-    // the fix); on top of the round-3 kernel: 1 = a second barrier after the MFMAs of a step, 2 = every step waits for ALL of the wave's loads
-    // (neither helps), 7 = both plus the lgkmcnt(0); 8 = two stages with the three-stage LDS allocation; 16 = plain tile order (no XCD chunks)
-#ifndef R3_VARIANT
-#define R3_VARIANT 0
-#endif
-#define TRTX_R3STEP(S)                                                                        \
-    {                                                                                         \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R3_VARIANT & 2) ? 0 : LOADS_PER_TILE * (NST - 2)) : "memory");     \
-        if (R3_VARIANT == 0 || R3_VARIANT == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* THE FIX (see the kernel's header) */ \
-        __builtin_amdgcn_s_barrier();                                                         \
-        issue_tile(((S) + NST - 1) % NST);                                                    \
-        compute(S);                                                                           \
-        if (R3_VARIANT & 1) __builtin_amdgcn_s_barrier();                                     \
-    }
-    issue_tile(0);
-    if (NST == 3) issue_tile(1);
-    for (int kt = 0;;) {
-        TRTX_R3STEP(0);
-        if (++kt == nk) break;
-        TRTX_R3STEP(1);
-        if (++kt == nk) break;
-        if (NST == 3) {
-            TRTX_R3STEP(2);
-            if (++kt == nk) break;
-        }
-    }
-#undef TRTX_R3STEP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // row t of the tile is position t0 + t: a real output pixel unless it sits in a padding column, past the tensor, or in the
-    // two rows this tile leaves to the next one
-    conv_epilogue<NFRAG, MI, false, NST * STAGE_BYTES>(p, acc, acci, smem, wave, lane, n0, [&](int t) {
-        const int pos = t0 + t;
-        if (t >= BME || pos >= Mp) return -1;
-        int n, h, wp;
-        split(pos, n, h, wp);
-        return (wp >= 1 && wp <= p.W) ? (n * p.H + h) * p.W + wp - 1 : -1;
-    });
-}
-#endif  // TRTX_EXPERIMENTAL_R3
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3x3 stride-1 pad-1 variant with a RESIDENT INPUT PATCH ("patch"; experimental, -DTRTX_EXPERIMENTAL_PATCH).  The kernels
+// 3x3 stride-1 pad-1 variant with a RESIDENT INPUT PATCH ("patch", tactic ConvArgs::t_ws == 3; a product tactic since round 5).  The kernels
 // above bring an A tile from global memory to LDS for every (tile, tap, channel slice): a 3x3 layer's input crosses the global -> LDS path
 // nine times per column tile, and on YOLOv8n / ResNet-50 that path - not HBM, not the MFMA pipe - is the largest term of a step
 // (tools/lds_fill_model.py: 5.6 GB per b32 step for 2.3 GB of HBM bytes).  Here an output tile is a TH x 16 block of ONE image, its
@@ -245,8 +18,10 @@ __global__ __launch_bounds__(256) void conv_igemm_r3_f16_kernel(const ConvArgs p
 // K is walked (tap, channel slice) as in the main kernel and every output element accumulates in the same order with the same MFMA: results
 // are bit-identical to the main kernel's (tests/test_gpu_conv.py treats it as one more exchangeable tile shape, ConvArgs::t_ws == 3).
 // All index arithmetic lives in patch_index.h and is replayed lane by lane on the CPU (tests/test_patch_index_cpu.py).
-// NOT YET RUN ON A GPU (written at the end of round 4 without GPU minutes): compiled only with the define; without it no tactic names it.
-#ifdef TRTX_EXPERIMENTAL_PATCH
+// Written at the end of round 4 without GPU minutes (CPU replay of its index arithmetic, ISA scan); first run in round 5 (profiles/r05_patch_shape_ab.txt,
+// r05_patch_r3_first_run.txt): bit-identical to the main kernel on every shape on the first launch, 64 -> 64 @ 80x80 34 vs 39-44 us, 64 -> 80 42 vs 48-53,
+// 80 -> 80 54 vs 70, 128 -> 64 @ 40x40 20 vs 22-25 (input flushed from the caches); in the whole step, where a layer's input is still warm from its producer,
+// +0.3-1.3 % on the bench line.  A candidate of the tactic timing wherever patch_possible() holds, and the kernel of the grouped launches whose members all qualify.
 template <int NFRAG, int KC, int MI>
 constexpr int patch_lds_bytes() {
     return KC * (4 * MI + 2) * patchidx::kPitch * patchidx::kPixelBytes + 3 * ((16 * NFRAG + 63) / 64) * 64 * 64;
@@ -486,7 +261,6 @@ int32_t launch_patch_group(const ConvArgs* a, int n, hipStream_t s) {
 #undef TRTX_PG
     return TRTX_OK;
 }
-#endif  // TRTX_EXPERIMENTAL_PATCH
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small-M variant (20x20 maps at batch 32 give M = 12800: 100 tiles of 128 rows for 256 CUs, and a 3x3 conv over 256
@@ -740,11 +514,10 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     const int BN = 16 * NFRAG, BMT = 64 * MI;
     const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.Cout_pad / BN;
     const int total = tiles_m * tiles_n;
-    static const bool plain = getenv("TRTX_CONV_NOXCD") != nullptr;  // A/B switch for the micro-benchmarks
-    const int chunk = plain ? 0 : (total + 7) / 8;
-    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // A/B switch: 0 / 1 override ConvArgs::t_rs
-    const bool rs_on = rs_env >= 0 ? rs_env != 0 : a.t_rs != 0;
+    constexpr bool plain = false;   // (XCD-aware tile order always)
+    const int chunk = (total + 7) / 8;
+    const int dbg = options().conv_dbg;   // ablation builds only (the product kernels ignore it)
+    const bool rs_on = a.t_rs != 0;
     if constexpr (TPS == 1 && !I8) {
         if (a.up_C > 0) {   // folded upsample (conv_igemm_supported has checked the geometry)
             if (rs_on)
@@ -757,8 +530,7 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
         }
     }
     if constexpr (TPS == 1 && !I8) {
-        static const bool one_off = getenv("TRTX_CONV_NOONE") != nullptr;   // A/B switch
-        if (!one_off && a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K) {
+        if (a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K) {
             if (rs_on)
                 TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
                             in_bytes, w_bytes, tiles_n, total, chunk, dbg);
@@ -774,29 +546,6 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
     else
     TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a, in_bytes,
                        w_bytes, tiles_n, total, chunk, dbg);
-}
-
-// the large-GEMM configuration: 256 x 128 tile, 2 x 2 waves of 128 x 64, 64-wide k-steps, three stages = 144 KB of LDS
-int32_t launch_big(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
-    // TRTX_BIG_VARIANT (experiments): 0 = 256 x 128, fragment reads issued ahead; 1 = the same, reads next to their MFMAs;
-    // 2 / 3 = 128 x 128 with the 2 x 2 wave grid (64 x 64 wave tiles, two workgroups per CU), reads next to / ahead of their MFMAs
-    static const int variant = getenv("TRTX_BIG_VARIANT") ? atoi(getenv("TRTX_BIG_VARIANT")) : 0;
-    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;  // timing experiments only
-    const int bm = (variant >= 2 && variant <= 4) ? 128 : 256;   // 5 / 6 / 7 = 256 x 128 with EIGHT waves (4 x 2 grid of 64 x 64 wave tiles; 3 stages, 3 + reads ahead, 2 stages);   // 4 = the plain 128 x 128 tile (four waves stacked along M) with the reads issued ahead
-    const int tiles_m = (a.M + bm - 1) / bm, tiles_n = a.Cout_pad / 128;
-    const int total = tiles_m * tiles_n;
-    const int chunk = (total + 7) / 8;
-    switch (variant) {
-        case 1: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 8, 2, 3, false>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 2: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, false>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 3: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 5: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 6: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 3, true, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 7: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 4, 2, 2, false, 8>), dim3(chunk * 8), dim3(512), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        case 4: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 2, 1, 0, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-        default: TRTX_LAUNCH((conv_igemm_f16_kernel<8, 64, 1, false, 8, 2, 3, true>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk, dbg); break;
-    }
-    return TRTX_OK;
 }
 
 template <int BKT, int TPS, bool I8 = false, int MI = 2>
@@ -830,44 +579,11 @@ bool wsk_possible(const ConvArgs& a) {
 }
 // ... and is what the untuned dispatch picks for few tiles with a long k-chain
 bool wsk_default(const ConvArgs& a) {
-    static const bool no_wsk = getenv("TRTX_CONV_NOWSK") != nullptr;  // A/B switch for the micro-benchmarks
+    const bool no_wsk = !options().wsk;  // A/B switch (TRTX_CONV_NOWSK)
     const int tiles128 = ((a.M + 127) / 128) * (a.Cout_pad / a.bn);
     return !no_wsk && wsk_possible(a) && tiles128 <= 256 && a.Kpad / 32 >= 16;
 }
-// the row-reuse kernel: fp16 3x3 stride 1 pad 1 with 16-byte output stores, 128-row tiles, 32..128-wide column tiles
-bool r3_possible(const ConvArgs& a) {
-#ifndef TRTX_EXPERIMENTAL_R3
-    return false;   // compiled out of the product (see the kernel's header)
-#endif
-    return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
-           a.dil_h == 1 && a.dil_w == 1 && a.CinK % 32 == 0 && a.CinK != 16 && !a.scalar_out && a.Ho == a.H && a.Wo == a.W &&
-           (a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) && (a.bm == 0 || a.bm == 128) && (a.bk == 32 || a.CinK % 64 == 0) &&
-           (double)a.N * a.H * (a.W + 2) < 8.0e6;  // positions are split with float reciprocals
-}
-#ifdef TRTX_EXPERIMENTAL_R3
-static int r3_forced() {
-    static const int v = getenv("TRTX_FORCE_R3") ? atoi(getenv("TRTX_FORCE_R3")) : 0;
-    return v;
-}
-static int r3_forced_bn() {   // TRTX_FORCE_R3_BN=64|80|128: force only the layers of that column-tile width
-    static const int v = getenv("TRTX_FORCE_R3_BN") ? atoi(getenv("TRTX_FORCE_R3_BN")) : 0;
-    return v;
-}
-template <int BKT, int NSTAGES>
-int32_t launch_r3(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
-    const int tiles_m = (a.N * a.H * (a.W + 2) + 125) / 126, tiles_n = a.Cout_pad / a.bn;
-    const int total = tiles_m * tiles_n, chunk = (total + 7) / 8;
-    switch (a.bn) {
-        case 32: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<2, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 64: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<4, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 80: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<5, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        case 128: TRTX_LAUNCH((conv_igemm_r3_f16_kernel<8, BKT, 2, NSTAGES>), dim3(chunk * 8), dim3(256), 0, s, a, in_bytes, w_bytes, tiles_n, total, chunk); break;
-        default: return TRTX_ERR_UNSUPPORTED;
-    }
-    return TRTX_OK;
-}
-#endif
-#ifdef TRTX_EXPERIMENTAL_PATCH
+bool r3_possible(const ConvArgs&) { return false; }   // (the row-reuse kernel of rounds 2-4 left the library in round 5: tools/hip/experiments/README.md)
 // the resident-patch kernel: fp16 3x3 stride 1 pad 1 over at most 128 (or exactly 256) input channels, 16-byte output stores, 64 / 80 / 128-wide column tiles
 bool patch_possible(const ConvArgs& a) {
     return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
@@ -875,13 +591,10 @@ bool patch_possible(const ConvArgs& a) {
            !a.scalar_out && a.Ho == a.H && a.Wo == a.W && (a.bn == 64 || a.bn == 80 || a.bn == 128) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128) &&
            a.t_r3 == 0;
 }
-#endif
 // 64-row tiles are instantiated for the fp16 one-tap-per-step kernels (both k-step widths)
 bool bm64_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16; }
 // ... 256-row tiles too, for 32/64/80-wide column tiles
 bool bm256_possible(const ConvArgs& a) { return !a.in_i8 && a.CinK != 16 && (a.bn == 32 || a.bn == 64 || a.bn == 80); }
-// ... and, 128 columns wide with 64-wide k-steps, the large-GEMM configuration (launch_big)
-bool big_possible(const ConvArgs& a) { return !a.up_C && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.bn == 128 && a.bk == 64 && a.CinK % 64 == 0 && a.Kpad % 64 == 0 && a.Cout_pad % 128 == 0; }
 
 }  // namespace
 
@@ -906,8 +619,8 @@ int conv_igemm_pick_bk(int cin, int taps) {
     // 3x3 layers over Cin % 64 == 0 gain 5-12 %, 1x1 layers lose 15-20 %, and with 3x3-only selection the whole engine
     // step is still 4 % slower (1.61 vs 1.54 ms on the same box): not a static default; the tactic tuner (runtime/tune.cpp)
     // times it per layer (the packed weights of a Cin % 64 == 0 layer are the same for both widths).
-    static const bool allow64 = getenv("TRTX_CONV_BK64") != nullptr;
-    return (cin % 64 == 0 && taps >= 9 && allow64) ? 64 : 32;
+    (void)cin; (void)taps;
+    return 32;
 }
 
 int conv_igemm_pick_cink(int cin, int bk) {
@@ -928,7 +641,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
     const double img_bytes = (double)a.H * a.W * a.ld_in * 2.0, w_b = (double)a.Cout_pad * a.Kpad * 2.0;
     return a.Cin % 8 == 0 && a.ld_in % 8 == 0 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1 && a.kh * a.kw <= kMaxTaps && cink_ok && a.CinK >= a.Cin &&
            a.Kpad == (a.kh * a.kw * a.CinK + bk - 1) / bk * bk && (out_vec || a.scalar_out) && img_bytes < 2.0e9 && w_b < 2.0e9 &&
-           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && (bm256_possible(a) || big_possible(a)))) &&
+           valid_bn(a.bn) && a.Cout_pad % a.bn == 0 && (a.bm == 0 || a.bm == 128 || (a.bm == 64 && bm64_possible(a)) || (a.bm == 256 && bm256_possible(a))) &&
            (a.t_r3 == 0 || r3_possible(a));
 }
 
@@ -938,15 +651,7 @@ bool conv_igemm_supported(const ConvArgs& a) {
 // results may differ in the last place).
 int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_efficient_only) {
     int n = 0;
-    // TRTX_TACTICS_EXCLUDE=wsk,r3,ws,bk64,bm64,bm256: kernel families left out of the candidate lists (bisecting, A/B); entry 0 stays
-    static const char* excl = getenv("TRTX_TACTICS_EXCLUDE");
-    auto excluded = [&](int bk, int bm, int wsk, int ws, int r3) {
-        if (!excl || n == 0) return false;
-        return (wsk == 2 && strstr(excl, "wsk")) || (r3 && strstr(excl, "r3")) || (ws == 2 && strstr(excl, "ws,")) || (bk == 64 && strstr(excl, "bk64")) ||
-               (bm == 64 && strstr(excl, "bm64")) || (bm == 256 && strstr(excl, "bm256"));
-    };
     auto push = [&](int bn, int bk, int bm, int wsk, int ws, int r3 = 0) {
-        if (excluded(bk, bm, wsk, ws, r3)) return;
         for (int i = 0; i < n; ++i)
             if (out[i].bn == bn && out[i].bk == bk && out[i].bm == bm && out[i].wsk == wsk && out[i].ws == ws && out[i].r3 == r3) return;
         if (n < max_out) out[n++] = ConvTactic{bn, bk, bm, wsk, ws, r3};
@@ -962,8 +667,7 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
     if (ws_ok) push(a.bn, a.bk, 128, 1, 2);
     else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only) ? 2 : 1, 1);
     // the 256 x 256 x 64 role-alternating tile for large plain GEMMs (conv_gemm256.hip): more work-efficient than any 128-row tile
-    static const bool no_g256 = getenv("TRTX_GEMM256") != nullptr && atoi(getenv("TRTX_GEMM256")) == 0;
-    if (fp16 && !no_g256 && conv_gemm256_worthwhile(a)) push(256, 64, 256, 1, 1);
+    if (fp16 && options().gemm256 && conv_gemm256_worthwhile(a)) push(256, 64, 256, 1, 1);
     const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
     static const int bns[5] = {128, 80, 64, 32, 16};
     for (int bi = 0; bi < 5; ++bi) {
@@ -979,26 +683,9 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             push(bn, t.bk, 128, 1, 1);
             if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
             if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
-            // The large-GEMM tile (launch_big) is a candidate only on request (TRTX_BIG_VARIANT set): none of its variants beats the
-            // 128 x 128 tile on MI355X (profiles/r03_gemm_tiles.txt) - all of them stop at ~0.42 of the MFMA peak, bound by instruction
-            // issue (4.2 non-MFMA instructions per 16-cycle MFMA; SQ counters in profiles/r03_sq_counters_res5_3x3.txt).
-            static const bool big_on = getenv("TRTX_BIG_VARIANT") != nullptr;
-            if (big_on && big_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 256) push(bn, t.bk, 256, 1, 1);
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
-#ifdef TRTX_EXPERIMENTAL_PATCH
-            // the resident-patch kernel (ws == 3): a candidate only on request until it has been through the GPU suite (TRTX_CONV_PATCH=1)
-            static const bool allow_patch = getenv("TRTX_CONV_PATCH") != nullptr && atoi(getenv("TRTX_CONV_PATCH")) != 0;
-            if (allow_patch && fp16 && patch_possible(t)) push(bn, t.bk, 128, 1, 3);
-#endif
-            // The 3x3 row-reuse kernel is a candidate only on request (TRTX_TACTICS_R3=1).  Round 3 found engines that had chosen it
-            // returning results that differ in the last fp16 places between execution contexts running side by side (and only then:
-            // tests/test_gpu_multi_context.py failed in 4 of 6 runs with it among the candidates, 0 of 12 without) - an ordering hazard in
-            // that kernel that shows under co-scheduling and has not been found yet.  It won 2-10 us on a handful of 20x20 / 40x40 layers.
-            static const bool allow_r3 = getenv("TRTX_TACTICS_R3") != nullptr && atoi(getenv("TRTX_TACTICS_R3")) != 0;
-            if (allow_r3 && r3_possible(t)) {
-                push(bn, t.bk, 128, 1, 1, t.bk == 64 ? 2 : 1);   // 64-wide k-steps: always two LDS stages
-                if (t.bk == 32) push(bn, t.bk, 128, 1, 1, 2);    // 32-wide: three stages or two (more workgroups per CU)
-            }
+            // the resident-patch 3x3 kernel (ws == 3): the same bits, fewer bytes through the global -> LDS fill path (work-efficient: a candidate in every set)
+            if (fp16 && options().patch && patch_possible(t)) push(bn, t.bk, 128, 1, 3);
         }
     }
     return n;
@@ -1040,21 +727,11 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
         int32_t st = TRTX_OK;
         if (a.in_i8) {
             st = launch_bn<32, 1, true>(a, in_bytes, w_bytes, s);
-#ifdef TRTX_EXPERIMENTAL_R3
-        } else if ((a.t_r3 != 0 || (r3_forced() && (r3_forced_bn() == 0 || r3_forced_bn() == a.bn))) && r3_possible(a)) {   // TRTX_FORCE_R3=1|2 (bisecting): every layer the kernel can take, 3 | 2 stages
-            const int v = a.t_r3 ? a.t_r3 : r3_forced();
-            st = a.bk == 64 ? launch_r3<64, 2>(a, in_bytes, w_bytes, s)
-                            : (v == 2 ? launch_r3<32, 2>(a, in_bytes, w_bytes, s) : launch_r3<32, 3>(a, in_bytes, w_bytes, s));
-#endif
-#ifdef TRTX_EXPERIMENTAL_PATCH
         } else if (a.t_ws == 3 && patch_possible(a)) {
             st = launch_patch(a, in_bytes, w_bytes, s);
-#endif
         } else if (wsk) {
             if (a.bn == 64) launch_wsk<4>(a, in_bytes, w_bytes, s);
             else launch_wsk<5>(a, in_bytes, w_bytes, s);
-        } else if (bm256 && big_possible(a)) {
-            st = launch_big(a, in_bytes, w_bytes, s);
         } else if (a.bk == 64) {
             st = bm64 ? launch_bn<64, 1, false, 1>(a, in_bytes, w_bytes, s)
                       : (bm256 ? launch_bn<64, 1, false, 4>(a, in_bytes, w_bytes, s) : launch_bn<64, 1>(a, in_bytes, w_bytes, s));
@@ -1081,7 +758,7 @@ bool group_member_ok(const ConvArgs& a) {
 }
 template <int NFRAG, bool RS, bool ONE>
 void launch_group(const ConvGroupArgs& g, hipStream_t s) {
-    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
+    const int dbg = options().conv_dbg;
     TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g, dbg);
 }
 }  // namespace
@@ -1098,14 +775,12 @@ bool conv_igemm_group_supported(const ConvArgs* a, int n) {
 
 int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     if (!conv_igemm_group_supported(a, n)) return TRTX_ERR_UNSUPPORTED;
-#ifdef TRTX_EXPERIMENTAL_PATCH
-    // TRTX_CONV_PATCH=2: groups whose members are all resident-patch layers of one instantiation run on that kernel (groups are not tuned: an A/B switch)
-    static const bool patch_groups = getenv("TRTX_CONV_PATCH") != nullptr && atoi(getenv("TRTX_CONV_PATCH")) >= 2;
-    if (patch_groups && patch_group_possible(a, n)) {
+    // groups whose members are all resident-patch layers of one instantiation run on that kernel (round 5: +1 % on the bench line over the main kernel's
+    // groups, same bits - profiles/r05_patch_r3_first_run.txt; groups are not tuned, TRTX_CONV_PATCH=0 is the A/B switch)
+    if (options().patch && patch_group_possible(a, n)) {
         const int32_t st = launch_patch_group(a, n, s);
         return st != TRTX_OK ? st : check_launch("conv_patch_group_f16");
     }
-#endif
     ConvGroupArgs g{};
     g.n = n;
     int order[kMaxConvGroup];   // falling k-steps per tile (ties: more rows first)
@@ -1129,10 +804,8 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
         g.w_bytes[k] = (unsigned)((size_t)ak.Cout_pad * ak.Kpad * 2);
     }
     for (int k = n; k <= kMaxConvGroup; ++k) g.slot_start[k] = slots;
-    static const int rs_env = getenv("TRTX_CONV_RS") ? atoi(getenv("TRTX_CONV_RS")) : -1;   // the same A/B switch as the single launches
-    const bool rs = rs_env >= 0 ? rs_env != 0 : a[0].t_rs != 0;
-    static const bool one_off = getenv("TRTX_CONV_NOONE") != nullptr;
-    const bool one = !one_off && plain_gemm(a[0]);
+    const bool rs = a[0].t_rs != 0;
+    const bool one = plain_gemm(a[0]);
     const int nf = a[0].bn / 16;
     if (nf == 4) {
         if (one) rs ? launch_group<4, true, true>(g, s) : launch_group<4, false, true>(g, s);

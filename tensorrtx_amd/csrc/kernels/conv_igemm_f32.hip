@@ -16,6 +16,7 @@
 // The kernel is MFMA-bound by construction: a 128 x 64 tile issues 32 MFMAs = 1024 cycles per k-step and wave against ~150 other instructions,
 // 12 KB of LDS fill and 6 fragment reads; the 20 - 40 % of the fp16 kernels' time that is LDS fill, address arithmetic and barriers sits in the
 // shadow of the matrix pipe here.  Every tile shape sums K in the same order: all tactics return the same bits.
+#include "../options.h"
 #include "igemm_tile.h"
 
 namespace trtx {
@@ -61,8 +62,7 @@ void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigne
         }
     }
 #ifdef TRTX_CONV_ABLATE   // timing experiments only (tools/f32_ablation.sh): TRTX_CONV_DBG as in the fp16 kernel, TRTX_F32_NST = 4 / 6 LDS stages (128 x 64 tile)
-    static const int dbg = getenv("TRTX_CONV_DBG") ? atoi(getenv("TRTX_CONV_DBG")) : 0;
-    static const int nst = getenv("TRTX_F32_NST") ? atoi(getenv("TRTX_F32_NST")) : 0;
+    const int dbg = options().conv_dbg, nst = options().f32_stages;
     if constexpr (MI == 2 && NFRAG == 4) {
         if (a.CinK != 8 && !a.up_C && !plain_gemm_f32(a) && a.t_ws != 5) {
             if (nst == 4) TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 4, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, dbg);

@@ -442,9 +442,8 @@ bool conv_stem_supported(const ConvArgs& a) {
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s) {
     if (!conv_stem_supported(a) || a.ld_out % 8 || (reinterpret_cast<uintptr_t>(a.out) & 15)) return TRTX_ERR_UNSUPPORTED;
     const int K = a.kh * a.kw * a.Cin;
-    static const bool no_mfma = getenv("TRTX_STEM_FMA") != nullptr;  // A/B switch for the micro-benchmarks
     const size_t patch = (size_t)a.Cin * ((kStemTH - 1) * a.stride_h + a.kh) * ((kStemTW - 1) * a.stride_w + a.kw + 9) * 4;
-    if (!no_mfma && a.Cout % 16 == 0 && K <= 160 && patch <= 60 * 1024 &&
+    if (a.Cout % 16 == 0 && K <= 160 && patch <= 60 * 1024 &&
         (size_t)a.N * a.Cin * a.H * a.W * 4 < 2000000000u && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0) {
         const int ks = K <= 32 ? 1 : 5;
         bool done = true;

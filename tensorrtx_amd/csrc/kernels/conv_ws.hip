@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "../options.h"
 #include "kernels.h"
 #include "launch.h"
 
@@ -399,7 +400,7 @@ bool pick_config(const ConvArgs& a, WsConfig* c, WsGeom* g) {
     // The stationary weights are loaded once per WORKGROUP: that only pays when a workgroup then walks several tiles.  Measured
     // (tools/gpu_ws_probe.sh, batch 32): 80x80 and 160x160 maps (1600+ tiles) win 15-30 % over the implicit-GEMM kernel,
     // 40x40 / 20x20 maps (<= 450 tiles, about one per workgroup) lose 20-40 %.
-    static const int min_tiles = getenv("TRTX_WS_MIN_TILES") ? atoi(getenv("TRTX_WS_MIN_TILES")) : 1024;
+    constexpr int min_tiles = 1024;
     if (g->total_tiles < min_tiles) return false;
     const int tpi = g->tiles_x * g->tiles_y;
     g->inv_tw = 1.0f / (float)g->TW;
@@ -431,13 +432,12 @@ int32_t launch_ws(const ConvArgs& a, const WsGeom& g, unsigned in_bytes, hipStre
             (void)hipGetLastError();
             occ = 1;
         }
-        static const int occ_cap = getenv("TRTX_WS_OCC") ? atoi(getenv("TRTX_WS_OCC")) : 4;  // A/B switch
+        constexpr int occ_cap = 4;
         occ = std::min(occ, occ_cap);
         *occ_cache = occ;
     }
     WsGeom gg = g;
-    static const int dbg = getenv("TRTX_WS_DBG") ? atoi(getenv("TRTX_WS_DBG")) : 0;
-    gg.dbg = dbg;
+    gg.dbg = 0;
     gg.grid = (std::min(g.total_tiles, 256 * occ) + 7) / 8 * 8;
     TRTX_LAUNCH(kern, dim3(gg.grid), dim3(256), lds, s, a, gg, in_bytes);
     return TRTX_OK;
@@ -484,7 +484,7 @@ WsPlan* ws_plan(const ConvArgs& a) {
 }  // namespace
 
 bool conv_ws_supported(const ConvArgs& a) {
-    static const bool off = getenv("TRTX_CONV_NOWS") != nullptr;  // A/B switch for the micro-benchmarks
+    const bool off = !options().ws;  // A/B switch (TRTX_CONV_NOWS)
     return !off && a.up_C == 0 && ws_plan(a)->ok;   // a folded upsample is the implicit-GEMM main kernel's
 }
 

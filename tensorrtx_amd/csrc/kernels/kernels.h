@@ -116,34 +116,7 @@ void conv_pack_weights_igemm_f32(const float* w_kcrs, int cout, int cin, int kh,
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);
 int32_t conv_ws_f16(const ConvArgs& a, hipStream_t s);
-// --- fused convolution chains (conv_chain.hip): 3x3 -> 3x3 (+ shortcut), 3x3 -> 3x3 -> 1x1, or a lone 3x3, stride 1, one launch per
-// chain over spatial tiles with the intermediate tensors resident in LDS (C2f bottlenecks block.cpp:98-110, detect-head arms
-// model.cpp:188-251).  Every stage has the same Cout (16 / 32 / 64 / 80 / 128); NHWC fp16 in and out.
-struct ChainStageDesc {
-    int k;              // 3 (stride 1, pad 1) or 1
-    int cout;
-    int act;            // ACT_* after the bias
-    float alpha;
-    int residual;       // add the chain INPUT (same pixel and channel; needs Cin == cout) to the rounded activation (block.cpp:104-108)
-    const void* wgt;    // fp16 [cout][k*k * kc * 32], index ((r*k + q) * kc + c / 32) * 32 + c % 32 with kc = ceil(cin / 32)
-    const float* bias;  // [cout]: folded BN shift / conv bias
-};
-struct ChainDesc {
-    const void* in;
-    void* out;
-    int N, H, W, Cin, ld_in, ld_out;
-    int nstages;
-    ChainStageDesc st[3];
-    int tile_h, tile_w;  // 0: chosen by the launcher
-};
-bool conv_chain_supported(const ChainDesc& d);
-int32_t conv_chain_f16(const ChainDesc& d, hipStream_t s);
-// the tile, LDS bytes and weight-ring depth the launcher would use (host only)
-int32_t conv_chain_describe(const ChainDesc& d, int* th, int* tw, int* lds_bytes, int* nst);
-size_t conv_chain_weight_halfs(int cin, int cout, int k);
-int32_t conv_chain_poison_lds(unsigned* device_word, hipStream_t s);  // test support: NaN patterns into every CU's LDS
-void conv_chain_set_stamps(unsigned long long* device_buffer_512x16);  // timing experiments (tools/chain_stamps.py); nullptr = off
-void conv_chain_pack_weights(const float* w_kcrs, int cout, int cin, int k, const float* ch_scale, uint16_t* packed);
+int32_t poison_lds(unsigned* device_word, hipStream_t s);  // test support (test_support.hip): NaN patterns into every CU's LDS
 // first layer: fp32 NCHW input (1..4 channels) -> NHWC fp16, weights fp32 [kh*kw*Cin (c,r,q)][Cout]
 bool conv_stem_supported(const ConvArgs& a);
 int32_t conv_stem_nchw_f32(const ConvArgs& a, hipStream_t s);

@@ -1,4 +1,4 @@
-// Index arithmetic of the resident-patch 3x3 kernel (conv_igemm.hip, -DTRTX_EXPERIMENTAL_PATCH): which patch pixel and which
+// Index arithmetic of the resident-patch 3x3 kernel (conv_igemm.hip, tactic ConvArgs::t_ws == 3): which patch pixel and which
 // 8-channel chunk a DMA lane fetches, where it lands in LDS, where a fragment lane reads its 16 bytes, how the weight tile is laid out.
 // Plain integer functions, usable from host code: tests/test_patch_index_cpu.py compiles this header with g++ and replays the kernel's data
 // path lane by lane (DMA pieces -> LDS image -> ds_read_b128 fragments -> v_mfma_f32_16x16x32_f16 semantics) against a direct convolution, so
@@ -11,7 +11,7 @@
 // pixels x 64 bytes = 1 KiB, lane-linear: lane l writes bytes [16 l, 16 l + 16) of the piece.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TRTX_HD __host__ __device__ __forceinline__
 #else
 #define TRTX_HD inline

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 #include "kernels/kernels.h"
 #include "runtime/pack.h"
 
@@ -119,7 +120,7 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f16(const void* in, int N, int H, int W, 
     if (reinterpret_cast<uintptr_t>(out) & 15) a.scalar_out = 1;
     if (g_force_tactic) conv_apply_tactic(&a, g_forced);
     // TRTX_OP_REPS=n (timing tools only): n back-to-back launches per call, so that the device — not the Python caller — sets the pace
-    static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;
+    const int reps = options().op_reps;
     int32_t st = TRTX_OK;
     for (int r = 0; r < reps && st == TRTX_OK; ++r) st = conv_igemm_f16(a, stream);
     return st;
@@ -196,7 +197,7 @@ extern "C" int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, 
         a.t_ws = tile2[2];
         a.bk = tile2[3];
     }
-    static const int reps = getenv("TRTX_OP_REPS") ? atoi(getenv("TRTX_OP_REPS")) : 1;   // timing tools only
+    const int reps = options().op_reps;   // timing tools only
     int32_t st = TRTX_OK;
     for (int r = 0; r < reps && st == TRTX_OK; ++r) st = conv_igemm_f32(a, stream);
     return st;
@@ -255,77 +256,9 @@ extern "C" int32_t trtx_op_nhwc_f16_to_nchw_f32(const void* in, float* out, int 
     return nhwc_to_nchw_f32(in, DT_F16, out, N, C, H, W, ld_in, stream);
 }
 
-// ---- fused convolution chains (kernels/conv_chain.hip) ---------------------------------------------------------------------
-extern "C" size_t trtx_conv_chain_packed_halfs(int cin, int cout, int k) {
-    if (cin < 1 || cout < 1 || (k != 1 && k != 3)) return 0;
-    return conv_chain_weight_halfs(cin, cout, k);
-}
-
-extern "C" int32_t trtx_conv_chain_pack_weights_f16(const float* w_kcrs, int cout, int cin, int k, const float* ch_scale, uint16_t* packed) {
-    if (!w_kcrs || !packed || cin < 1 || cout < 1 || (k != 1 && k != 3)) return TRTX_ERR_INVALID;
-    conv_chain_pack_weights(w_kcrs, cout, cin, k, ch_scale, packed);
-    return TRTX_OK;
-}
-
-static bool chain_desc(ChainDesc* d, int N, int H, int W, int Cin, int ld_in, int ld_out, int nstages, const int32_t* k, const int32_t* cout,
-                       const int32_t* act, const int32_t* residual, int tile_h, int tile_w) {
-    if (!k || !cout || nstages < 1 || nstages > 3) return false;
-    *d = ChainDesc{};
-    d->N = N; d->H = H; d->W = W; d->Cin = Cin; d->ld_in = ld_in; d->ld_out = ld_out;
-    d->nstages = nstages;
-    d->tile_h = tile_h; d->tile_w = tile_w;
-    for (int s = 0; s < nstages; ++s) {
-        d->st[s].k = k[s];
-        d->st[s].cout = cout[s];
-        d->st[s].act = act ? act[s] : ACT_NONE;
-        d->st[s].alpha = 0.1f;
-        d->st[s].residual = residual ? residual[s] : 0;
-    }
-    return true;
-}
-
-extern "C" int32_t trtx_op_conv_chain_plan(int N, int H, int W, int Cin, int nstages, const int32_t* k, const int32_t* cout, const int32_t* residual,
-                                           int tile_h, int tile_w, int32_t* out4) {
-    ChainDesc d;
-    if (!out4 || !chain_desc(&d, N, H, W, Cin, (Cin + 7) / 8 * 8, 0, nstages, k, cout, nullptr, residual, tile_h, tile_w)) return TRTX_ERR_INVALID;
-    d.ld_out = d.st[nstages - 1].cout;
-    int th = 0, tw = 0, lds = 0, nst = 0;
-    const int32_t st = conv_chain_describe(d, &th, &tw, &lds, &nst);
-    if (st != TRTX_OK) return st;
-    out4[0] = th; out4[1] = tw; out4[2] = lds; out4[3] = nst;
-    return TRTX_OK;
-}
-
-extern "C" int32_t trtx_op_conv_chain_nhwc_f16(const void* in, int N, int H, int W, int Cin, int ld_in, void* out, int ld_out, int nstages,
-                                               const int32_t* k, const int32_t* cout, const int32_t* act, const int32_t* residual,
-                                               const void* const* wpacked, const float* const* bias, int tile_h, int tile_w, trtx_stream_t stream) {
-    ChainDesc d;
-    if (!in || !out || !wpacked || !bias || !chain_desc(&d, N, H, W, Cin, ld_in, ld_out, nstages, k, cout, act, residual, tile_h, tile_w)) return TRTX_ERR_INVALID;
-    d.in = in;
-    d.out = out;
-    for (int s = 0; s < nstages; ++s) {
-        if (!wpacked[s] || !bias[s]) return TRTX_ERR_INVALID;
-        d.st[s].wgt = wpacked[s];
-        d.st[s].bias = bias[s];
-    }
-    // micro-benchmarks (tools/chain_bench.py): TRTX_OP_REPEAT launches back to back from C, so that the host side of the Python binding
-    // does not pace the measurement
-    int repeat = 1;
-    if (const char* e = getenv("TRTX_OP_REPEAT")) repeat = atoi(e) > 0 ? atoi(e) : 1;
-    int32_t st = TRTX_OK;
-    for (int r = 0; r < repeat && st == TRTX_OK; ++r) st = conv_chain_f16(d, static_cast<hipStream_t>(stream));
-    return st;
-}
-
-// timing experiments: per-workgroup s_memtime stamps of the chain kernel into a caller-owned device buffer [512][16] u64 (nullptr: off)
-extern "C" int32_t trtx_op_conv_chain_set_stamps(void* device_buffer) {
-    conv_chain_set_stamps(static_cast<unsigned long long*>(device_buffer));
-    return TRTX_OK;
-}
-
-// test support: fill the LDS of every CU with fp16 NaN patterns (LDS survives kernel boundaries; see tests/test_gpu_conv_chain.py)
+// test support: fill the LDS of every CU with fp16 NaN patterns (LDS survives kernel boundaries; tests/test_gpu_multi_context.py)
 extern "C" int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream) {
     if (!device_word) return TRTX_ERR_INVALID;
-    return conv_chain_poison_lds(static_cast<unsigned*>(device_word), static_cast<hipStream_t>(stream));
+    return poison_lds(static_cast<unsigned*>(device_word), static_cast<hipStream_t>(stream));
 }
 

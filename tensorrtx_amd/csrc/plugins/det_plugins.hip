@@ -1167,15 +1167,14 @@ static int32_t sorted_nms(int mode, int batch, const float* scores, const float*
     a.thresh = thresh;
     a.mode = mode;
     a.stop_after = (mode == NMS_RPN || mode == NMS_HARD0) ? n_out : 0;
-    static const bool no_mask = getenv("TRTX_NMS_NOMASK") != nullptr;  // A/B switch for the micro-benchmarks
-    if (mode == NMS_RPN && n <= kMaskMaxN && !no_mask) {
+    if (mode == NMS_RPN && n <= kMaskMaxN) {
         const int n_blk = (n + 63) / 64;
         uint64_t* mask_t = c.take<uint64_t>((size_t)batch * n_blk * n_blk * 64);
         if (!c.ok) return TRTX_ERR_WORKSPACE;
         hipLaunchKernelGGL(hard_mask_kernel, dim3(n_blk, n_blk, batch), dim3(64), 0, stream, boxes, (long)n * 4, order, n, n_blk,
                            thresh, mask_t);
         hipLaunchKernelGGL(hard_scan_kernel, dim3(batch), dim3(1024), 0, stream, mask_t, sorted, n, n_blk, a.stop_after);
-    } else if ((mode == NMS_HARD0 || mode == NMS_SOFT_LINEAR || mode == NMS_SOFT_GAUSS) && classes && n <= 1024 && !no_mask) {
+    } else if ((mode == NMS_HARD0 || mode == NMS_SOFT_LINEAR || mode == NMS_SOFT_GAUSS) && classes && n <= 1024) {
         const int n_blk = (n + 63) / 64;
         float* f_t = c.take<float>((size_t)batch * n_blk * 64 * n_blk * 64);
         if (!c.ok) return TRTX_ERR_WORKSPACE;

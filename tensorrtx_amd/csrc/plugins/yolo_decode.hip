@@ -344,13 +344,29 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, x[i]);
             float sum = 0.f, acc = 0.f;
+            if constexpr (sizeof(T) == 4) {
+                // fp32 engines: the arithmetic of the un-fused chain to the bit - softmax_kernel (linear_ops.hip: p_i = expf(x_i - max) * (1 / sum)) followed by the
+                // DFL 1x1 convolution (conv_direct_kernel: an fmaf chain over the 16 bins from 0) - so that a user YoloLayer plugin behind the un-fused graph and
+                // the built-in fused tail return the same boxes (tests/test_ref_pinning.py::test_reference_yololayer_plugin_runs_inside_a_full_engine)
+                float ex[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float ex = expf(x[i] - mx);
-                sum += ex;
-                acc = fmaf(ex, w[i], acc);
+                for (int i = 0; i < 16; ++i) {
+                    ex[i] = expf(x[i] - mx);
+                    sum += ex[i];
+                }
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = fmaf(ex[i] * inv, w[i], acc);
+                side[s] = acc;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float ex = expf(x[i] - mx);
+                    sum += ex;
+                    acc = fmaf(ex, w[i], acc);
+                }
+                side[s] = acc / sum;
             }
-            side[s] = acc / sum;
         }
         float best = 0.0f;
         int bcls = 0;

@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "../common.h"
+#include "../options.h"
 #include "engine.h"
 #include "graph.h"
 #include "int8.h"
@@ -409,9 +410,9 @@ extern "C" int32_t trtx_build_serialized(trtx_builder* b, trtx_network* n, trtx_
     // of this plan times the launch configurations of its convolutions (runtime/tune.cpp) and the choices are stored IN the plan, so
     // that every deserialize of it runs the same kernels.  Without a GPU (or with TRTX_TUNE=0) the plan carries no choices and
     // engines made from it run the static defaults.
-    const char* tune_env = getenv("TRTX_TUNE");
+    const int tune_opt = read_options().tune;
     // (fp32 engines too since round 5: their convolutions have tile shapes to choose from - kernels/conv_igemm_f32.hip - all of them the same bits)
-    if (!(tune_env && atoi(tune_env) == 0) && trtx_device_count() > 0) {
+    if (tune_opt != 0 && trtx_device_count() > 0) {
         trtx_engine* e = nullptr;
         if (engine_from_plan(blob.data(), blob.size(), true, &e) == TRTX_OK && e) {
             n->net.tactics = e->net->tactics;

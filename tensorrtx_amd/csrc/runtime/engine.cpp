@@ -6,6 +6,7 @@
 #include <sstream>
 
 #include "../common.h"
+#include "../options.h"
 #include "int8.h"
 #include "plugin.h"
 
@@ -94,14 +95,14 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
     char* W = static_cast<char*>(e->d_weights);
     std::vector<hipEvent_t> evs;
     std::vector<LaunchProbe> probes;  // profiling: per convolution, the dispatch's own begin / end timestamps
-    static const bool no_probe = getenv("TRTX_PROFILE_NO_KERNEL_EVENTS") != nullptr;
+    const bool no_probe = !options().profile_kernel_events;
     if (prof) {
         evs.resize(plan.ops.size() + 1);
         for (auto& ev : evs) TRTX_HIP_TRY(hipEventCreate(&ev));
         probes.resize(plan.ops.size());
         if (!no_probe && !c->tuning)  // the tactic timing keeps its own clock (the interval between the stream events)
             for (size_t k = 0; k < plan.ops.size(); ++k)
-                if ((plan.ops[k].kind == OP_CONV && plan.ops[k].igemm) || plan.ops[k].kind == OP_CONV_CHAIN || plan.ops[k].kind == OP_CONV_GROUP)
+                if ((plan.ops[k].kind == OP_CONV && plan.ops[k].igemm) || plan.ops[k].kind == OP_CONV_GROUP)
                     if (hipEventCreate(&probes[k].start) != hipSuccess || hipEventCreate(&probes[k].stop) != hipSuccess) (void)hipGetLastError();
         TRTX_HIP_TRY(hipEventRecord(evs[0], stream));
     }
@@ -203,28 +204,6 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     st = TRTX_OK;
                     for (int m = 0; m < gn && st == TRTX_OK; ++m) st = conv_igemm_f16(ga[m], stream);
                 }
-                break;
-            }
-            case OP_CONV_CHAIN: {
-                ChainDesc d{};
-                d.in = R.ptr(op.in[0]);
-                d.out = R.ptr(op.out[0]);
-                d.N = nb(t0);
-                d.H = op.conv.H; d.W = op.conv.W; d.Cin = op.conv.Cin; d.ld_in = t0.ld; d.ld_out = to.ld;
-                d.nstages = (int)op.chain.size();
-                for (size_t s = 0; s < op.chain.size(); ++s) {
-                    const POp::ChainStage& cs = op.chain[s];
-                    d.st[s].k = cs.k;
-                    d.st[s].cout = cs.cout;
-                    d.st[s].act = cs.act;
-                    d.st[s].alpha = cs.alpha;
-                    d.st[s].residual = cs.residual ? 1 : 0;
-                    d.st[s].wgt = W + cs.w_off;
-                    d.st[s].bias = reinterpret_cast<const float*>(W + cs.b_off);
-                }
-                if (prof && probes[k].start && probes[k].stop) conv_set_launch_probe(&probes[k]);
-                st = conv_chain_f16(d, stream);
-                conv_set_launch_probe(nullptr);
                 break;
             }
             case OP_POOL:
@@ -537,8 +516,7 @@ int32_t trtx::engine_from_plan(const void* plan_data, size_t size, bool time_tac
     // kernel tactics: the plan's own (chosen by timing when it was built on a GPU machine); a plan built without a GPU has none and
     // is timed here only on request (TRTX_TUNE=1) - by default it runs the static defaults, reproducibly
     if (!time_tactics && !e->net->tactics_timed) {
-        const char* env = getenv("TRTX_TUNE");
-        time_tactics = env && atoi(env) == 1;
+        time_tactics = read_options().tune == 1;
     }
     if (const int32_t st = tune_engine(e.get(), time_tactics)) return st;
     *out = e.release();
@@ -629,7 +607,7 @@ namespace {
 int32_t enqueue_maybe_graph(trtx_context* c, int batch, void* const* bindings, hipStream_t stream) {
     const trtx::Plan& plan = c->engine->plan;
     if (c->graph_state == 0) {
-        static const bool on = getenv("TRTX_GRAPH") && atoi(getenv("TRTX_GRAPH")) != 0;
+        static const bool on = options().graph;
         bool ok = on;
         for (const auto& op : plan.ops)
             if (op.kind == trtx::OP_PLUGIN && !trtx::builtin_plugin_capturable(op.plugin->v)) ok = false;

@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "../common.h"
+#include "../options.h"
 #include "engine.h"
 
 namespace trtx {
@@ -267,7 +268,7 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
         // TRTX_CALIB_REPORT=<file>: per calibrated tensor the largest |x| seen, the threshold chosen, the share of elements beyond it
         // (what the int8 engine clips) and the share in bin 0 - the evidence behind a detection-level int8 figure
         FILE* report = nullptr;
-        if (const char* rp = getenv("TRTX_CALIB_REPORT")) report = fopen(rp, "a");
+        if (const std::string rp = read_options().calib_report; !rp.empty()) report = fopen(rp.c_str(), "a");
         if (report) fprintf(report, "# %s calibration, %d batch(es) of %d; tensor\tabsmax\tthreshold\tclipped_share\tbin0_share\telements\n", minmax ? "min-max" : "entropy", n_batches, batch);
         for (const PTensor& t : plan.tensors) {
             if (t.parent >= 0 || t.layout != LAY_NHWC || t.net_tensor < 0 || t.storage < 0) continue;

@@ -7,6 +7,7 @@
 #include <functional>
 #include <sstream>
 
+#include "../options.h"
 #include "pack.h"
 #include "plan.h"
 
@@ -67,6 +68,7 @@ struct YoloHeadFuse {
 struct Lowerer {
     const Network& net;
     Plan& plan;
+    const Options opt = read_options();   // the environment's A/B switches as of THIS lowering (tests flip them inside one process)
     int dt;  // dtype of NHWC tensors
     std::vector<std::vector<int>> consumers;
     std::vector<int> pt_of, pt_lin, pt_nhwc;
@@ -477,8 +479,7 @@ struct Lowerer {
                    (l.nb_out == 8 || l.nb_out == 16 || l.nb_out == 32 || l.nb_out == 64) &&
                    (size_t)l.kernel[0] * l.kernel[1] * cin * l.nb_out * 4 <= 48 * 1024;
             // fp32 engines (round 5): kernels/conv_stem_f32.hip, the same idea on the vector ALU - the layer is HBM-bound and 3x padding on the MFMA path
-            static const bool no_stem32 = getenv("TRTX_F32_DIRECT") != nullptr;
-            if (dt == DT_F32 && !no_stem32)
+            if (dt == DT_F32 && opt.f32_mfma)
                 stem = l.kind == L_CONV && di.nb == (net.explicit_batch ? 4 : 3) && src.layout == LAY_LINEAR && pt_nhwc[l.inputs[0]] < 0 && cin <= 4 && g.residual < 0 &&
                        g.act2 == ACT_NONE && l.groups == 1 && l.dilation[0] == 1 && l.dilation[1] == 1 && l.nb_out % 16 == 0 && l.nb_out <= 256;
         }
@@ -791,7 +792,7 @@ struct Lowerer {
                 // (803 MB fp32 written, re-read and re-written as fp16 per image at C5).  Same detectron2 ROIAlign(aligned=True)
                 // arithmetic as the plugin (pinned on the reference's kernel in tests/test_ref_pinning.py); fp32 engines and
                 // TRTX_ROIALIGN_PLUGIN=1 keep the plugin route.
-                static const bool keep_plugin = getenv("TRTX_ROIALIGN_PLUGIN") != nullptr;
+                const bool keep_plugin = !opt.roialign_fused;
                 if (!keep_plugin && dt == DT_F16 && !net.explicit_batch && l.plugin && l.plugin->type() == "RoiAlign" && l.plugin->version() == "1" &&
                     l.inputs.size() == 2 && l.outputs.size() == 1 && plan.tensors[pt_of[l.inputs[1]]].layout == LAY_NHWC) {
                     const std::vector<uint8_t> blob = l.plugin->serialize();
@@ -812,7 +813,7 @@ struct Lowerer {
                             // convolutions read contiguous pixels.  Mask R-CNN's mask-head RoIAlign feeds a stride-1 reader and keeps
                             // the full grid (rcnn/rcnn.cpp:204-233).  TRTX_ROIALIGN_FOLD_STRIDE=0 keeps the full grid (A/B, tests).
                             int step = 0;
-                            const bool no_fold = getenv("TRTX_ROIALIGN_FOLD_STRIDE") && atoi(getenv("TRTX_ROIALIGN_FOLD_STRIDE")) == 0;   // read at every lowering
+                            const bool no_fold = !opt.roialign_fold_stride;
                             if (!no_fold && !net.tensors[l.outputs[0]].is_output && !consumers[l.outputs[0]].empty()) {
                                 step = -1;
                                 for (int c : consumers[l.outputs[0]]) {
@@ -1164,134 +1165,6 @@ struct Lowerer {
         }
     }
 
-    // Convolution chains -> one launch (kernels/conv_chain.hip).  A chain is 3x3 -> 3x3 [-> 1x1] or 3x3 -> 1x1, all stride 1 with the
-    // same Cout, every intermediate tensor read by the next stage only: the C2f bottleneck (block.cpp:98-110; its shortcut adds the
-    // chain's own input) and the three-convolution arms of the detect head (model.cpp:188-251).  The fused op takes the first stage's
-    // place in the schedule (its only activation input is that stage's input) and the intermediate tensors lose their storage.
-    // OPT-IN (TRTX_FUSE_CHAINS=1): on MI355X the fused kernel is correct (bit-identical to the layer-by-layer kernels) and cuts YOLOv8n
-    // b32 from 67 to 45 launches and the arena from 277 to 197 MB, but in round 3 it is SLOWER than the implicit-GEMM launches it
-    // replaces (one context 1.73 vs 1.41 ms, three contexts 1.16 vs 0.94 ms on one box; DESIGN.md section 5 has the per-chain table and
-    // the phase stamps): at the one or two workgroups per CU its LDS plan allows, prologue, k-loop bookkeeping and the SiLU epilogues
-    // run back to back instead of under another workgroup's MFMAs.
-    void fuse_conv_chains() {
-        if (dt != DT_F16 || CalibrationLowering::active()) return;
-        const char* fe = getenv("TRTX_FUSE_CHAINS");
-        if (!fe || atoi(fe) == 0) return;
-        std::vector<int> readers(plan.tensors.size(), 0);
-        auto top_of = [&](int t) {
-            while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
-            return t;
-        };
-        std::vector<int> views_of(plan.tensors.size(), 0);  // tensors (other than itself) that alias an owner's storage
-        for (const PTensor& t : plan.tensors)
-            if (t.parent >= 0) ++views_of[top_of(t.id)];
-        for (const POp& op : plan.ops) {
-            for (int t : op.in) ++readers[t];
-            for (int t : op.extra_in) ++readers[t];
-        }
-        auto plain = [&](const POp& op, int k) {
-            const ConvArgs& a = op.conv;
-            return op.kind == OP_CONV && op.igemm && !op.stem && !op.from_deconv && !a.in_i8 && !a.out_i8 && !a.res_i8 && a.kh == k && a.kw == k &&
-                   a.stride_h == 1 && a.stride_w == 1 && a.pad_h == k / 2 && a.pad_w == k / 2 && a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 &&
-                   a.act2 == ACT_NONE && !a.scalar_out && a.Ho == a.H && a.Wo == a.W && plan.tensors[op.in[0]].nmul == 1;
-        };
-        // an intermediate: written by `op`, read exactly once (by the next stage, as its convolution input), owns its storage, no view
-        // of it exists and it is not a binding
-        auto private_out = [&](const POp& op) {
-            const int t = op.out[0];
-            const PTensor& pt = plan.tensors[t];
-            return readers[t] == 1 && pt.parent < 0 && views_of[t] == 0 && !is_binding_tensor(t) && pt.dtype == DT_F16;
-        };
-        auto consumer_of = [&](int tensor, size_t from) -> int {
-            for (size_t k = from; k < plan.ops.size(); ++k)
-                if (!plan.ops[k].in.empty() && plan.ops[k].in[0] == tensor) return (int)k;
-            return -1;
-        };
-        auto same_tensor = [&](int a, int b) {
-            const PTensor &x = plan.tensors[a], &y = plan.tensors[b];
-            return a == b || (x.storage == y.storage && x.rcoff == y.rcoff && x.C == y.C && x.layout == y.layout);
-        };
-        // TRTX_FUSE_CHAINS_MASK: bit i set = fuse the i-th candidate chain (bisecting / per-chain A/B); default all
-        unsigned long long mask = ~0ull;
-        if (const char* e = getenv("TRTX_FUSE_CHAINS_MASK")) mask = strtoull(e, nullptr, 0);
-        int cand_index = 0;
-        for (size_t k = 0; k < plan.ops.size(); ++k) {
-            POp& first = plan.ops[k];
-            if (!plain(first, 3) || first.in.size() != 1) continue;
-            std::vector<int> members = {(int)k};
-            const int cout = first.conv.Cout;
-            // second stage: 3x3 (optionally + the chain input as shortcut) or 1x1
-            if (!private_out(first)) continue;
-            int nx = consumer_of(first.out[0], k + 1);
-            if (nx < 0) continue;
-            auto stage_ok = [&](const POp& op, int kk, bool allow_res) {
-                if (!plain(op, kk) || op.conv.Cout != cout || op.conv.Cin != cout) return false;
-                if (op.in.size() > 1) return allow_res && same_tensor(op.in[1], first.in[0]) && first.conv.Cin == cout;
-                return true;
-            };
-            if (stage_ok(plan.ops[nx], 3, true)) {
-                members.push_back(nx);
-                if (private_out(plan.ops[nx])) {
-                    const int n3 = consumer_of(plan.ops[nx].out[0], nx + 1);
-                    if (n3 >= 0 && stage_ok(plan.ops[n3], 1, false)) members.push_back(n3);
-                }
-            } else if (stage_ok(plan.ops[nx], 1, false)) {
-                members.push_back(nx);
-            } else {
-                continue;
-            }
-            // does the kernel take it (tile / LDS plan at the largest batch)?
-            ChainDesc d{};
-            const PTensor& tin = plan.tensors[first.in[0]];
-            const PTensor& tout = plan.tensors[plan.ops[members.back()].out[0]];
-            d.N = (tin.nfix ? tin.nfix : plan.max_batch) * tin.nmul;
-            d.H = first.conv.H; d.W = first.conv.W; d.Cin = first.conv.Cin; d.ld_in = tin.ld; d.ld_out = tout.ld;
-            d.nstages = (int)members.size();
-            if (tin.rcoff % 8 || tout.rcoff % 8 || tin.dtype != DT_F16 || tout.dtype != DT_F16) continue;
-            for (size_t s = 0; s < members.size(); ++s) {
-                const POp& m = plan.ops[members[s]];
-                d.st[s].k = m.conv.kh;
-                d.st[s].cout = m.conv.Cout;
-                d.st[s].act = m.conv.act1;
-                d.st[s].alpha = m.conv.alpha1;
-                d.st[s].residual = m.in.size() > 1 ? 1 : 0;
-            }
-            if (!conv_chain_supported(d)) continue;
-            if (!((mask >> (cand_index++ & 63)) & 1ull)) continue;
-            POp fused = first;
-            fused.kind = OP_CONV_CHAIN;
-            fused.igemm = false;
-            fused.in = {first.in[0]};
-            fused.out = {plan.ops[members.back()].out[0]};
-            fused.flops = 0;
-            fused.bytes = 0;
-            fused.name = "";
-            for (size_t s = 0; s < members.size(); ++s) {
-                const POp& m = plan.ops[members[s]];
-                POp::ChainStage st;
-                st.src_layer = m.src_layer;
-                st.scale_layer = m.scale_layer;
-                st.k = m.conv.kh;
-                st.cin = m.conv.Cin;
-                st.cout = m.conv.Cout;
-                st.act = m.conv.act1;
-                st.alpha = m.conv.alpha1;
-                st.residual = m.in.size() > 1;
-                fused.chain.push_back(st);
-                fused.flops += m.flops;
-                fused.name += (s ? " + " : "") + m.name;
-            }
-            fused.name += " [fused chain]";
-            fused.conv.Cout = cout;
-            fused.conv.ld_out = tout.ld;
-            // algorithmic bytes per sample: the chain's input and output once (the intermediates never exist in memory)
-            fused.bytes = 2.0 * first.conv.H * first.conv.W * (first.conv.Cin + cout);
-            plan.ops[k] = fused;
-            for (size_t s = members.size() - 1; s >= 1; --s) plan.ops.erase(plan.ops.begin() + members[s]);
-            // reader counts of the erased ops' inputs no longer matter: their tensors are gone from the schedule
-        }
-    }
-
     // Independent convolutions of one kernel instantiation -> one launch (OP_CONV_GROUP; kernels/conv_igemm.hip conv_igemm_group_f16_kernel).
     // The YOLOv8 detect head is six chains of depth three over three pyramid levels (yolov8/src/model.cpp:188-251): cv2.{0,1,2}.0 are three
     // independent 3x3 convolutions to 64 channels, cv3.{0,1,2}.0 three to 80, and so on down the chains - 18 launches, of which the 20x20 and
@@ -1304,8 +1177,7 @@ struct Lowerer {
     void group_convs() {
         if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
         bool mark_only = false;   // TRTX_GROUP_CONVS=0: one launch per convolution, but the would-be members keep the group's K order (t_wsk = 1): same bits
-        if (const char* e = getenv("TRTX_GROUP_CONVS"))
-            if (atoi(e) == 0) mark_only = true;
+        if (!opt.group_convs) mark_only = true;
         const int n = (int)plan.ops.size();
         if (n < 2 || n > 4096) return;
         // all dependencies (RAW, WAR, WAW at storage / channel-range granularity, as finalize step 5 computes them) in the current order
@@ -1518,8 +1390,7 @@ struct Lowerer {
     // TRTX_FOLD_UPSAMPLE=0 keeps the resize (A/B, tests).  Not with kINT8 (the int8 resize requantises between two scales).
     void fold_upsample() {
         if (net.int8 || CalibrationLowering::active()) return;   // (fp16 and fp32 engines: both MFMA kernels fetch the slice from the half-resolution tensor)
-        if (const char* e = getenv("TRTX_FOLD_UPSAMPLE"))
-            if (atoi(e) == 0) return;
+        if (!opt.fold_upsample) return;
         auto top = [&](int t) {
             while (plan.tensors[t].parent >= 0) t = plan.tensors[t].parent;
             return t;
@@ -1644,9 +1515,7 @@ struct Lowerer {
                 {
                     const double flop_px = 2.0 * a.Cout * (double)a.kh * a.kw * a.Cin;
                     const double byte_px = 2.0 * ((double)a.Cin * a.stride_h * a.stride_w + (double)a.Cout * (op.in.size() > 1 ? 2 : 1));
-                    // TRTX_RS_RIDGE=<FLOP per byte> (A/B at build time): the 80 -> 80 3x3 arms of the detect head sit at 360 FLOP/B, just above the
-                    // default, at 14 % of the MFMA peak - whether they belong on the register path too is an open measurement
-                    static const double ridge = getenv("TRTX_RS_RIDGE") ? atof(getenv("TRTX_RS_RIDGE")) : 312.0;
+                    constexpr double ridge = 312.0;   // the MFMA / HBM ridge, FLOP per byte
                     t.t_rs = (net.max_aux_streams == 0 && flop_px / byte_px < ridge) ? 1 : 0;
                 }
                 if (conv_igemm_supported(t)) {
@@ -1657,9 +1526,8 @@ struct Lowerer {
         }
         // fp32 engines: the same skeleton on the fp32 MFMA (kernels/conv_igemm_f32.hip), 16-channel k-steps; the tile shape is the launcher's
         if (op.kind == OP_CONV && !op.stem && dt == DT_F32 && ti.dtype == DT_F32 && to.dtype == DT_F32 && a.groups == 1 && a.dil_h == 1 && a.dil_w == 1) {
-            static const bool off = getenv("TRTX_F32_DIRECT") != nullptr;   // A/B: the scalar direct kernel of rounds 1-4
             int cin_eff = a.Cin;
-            bool ok = !off;
+            bool ok = opt.f32_mfma;   // (TRTX_F32_DIRECT=1: the scalar direct kernel of rounds 1-4, an A/B switch)
             if (cin_eff % 4) {
                 const PTensor& own = plan.tensors[ti.parent >= 0 ? ti.parent : ti.id];
                 ok = ok && ti.parent < 0 && own.pad_zeroed;
@@ -1815,7 +1683,6 @@ struct Lowerer {
             a.out = {a.out[0], b.out[0], c3.out[0]};
             plan.ops.erase(plan.ops.begin() + k + 1, plan.ops.begin() + k + 3);
         }
-        fuse_conv_chains();
         group_convs();
         // 5. op dependencies at (storage, channel/element range) granularity: RAW, WAR and WAW
         const int nops = (int)plan.ops.size();
@@ -1859,7 +1726,7 @@ struct Lowerer {
         // 6 lanes 1.335-1.353 ms vs 4 lanes 1.354-1.360 with resident inputs, but 2.56-2.74 vs 1.67-1.71 ms once a host-fed pipeline
         // adds an H2D stream; ResNet-50 / RetinaFace / R-CNN are 0.5-1.3 % faster with 4.  (8 or 16 hardware queues: 2.2x slower.)
         int max_lanes = net.max_aux_streams >= 0 ? 1 + net.max_aux_streams : 4;  // IBuilderConfig::setMaxAuxStreams
-        if (const char* e = getenv("TRTX_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));  // A/B override
+        if (opt.lanes > 0) max_lanes = std::max(1, std::min(16, opt.lanes));  // A/B override (TRTX_LANES)
         std::vector<int> tail(max_lanes, -1);
         plan.num_lanes = 1;
         for (int k = 0; k < nops; ++k) {
@@ -2093,32 +1960,6 @@ bool pack_weights(const Network& net, Plan* plan) {
             op.b_off = reserve(bias.size() * 4);
             memcpy(blob.data() + op.b_off, bias.data(), bias.size() * 4);
             op.bytes += (double)(op.igemm ? (size_t)a.Cout_pad * a.Kpad * (a.f32 ? 4 : 2) : (size_t)cout * a.K * 4);
-        } else if (op.kind == OP_CONV_CHAIN) {
-            for (POp::ChainStage& st : op.chain) {
-                const LayerDef& l = net.layers[st.src_layer];
-                std::vector<float> sc(st.cout, 1.f), bias(st.cout, 0.f);
-                for (int c = 0; c < st.cout && c < (int)l.w1.size(); ++c) bias[c] = l.w1[c];
-                if (st.scale_layer >= 0) {
-                    const LayerDef& sl = net.layers[st.scale_layer];
-                    for (int c = 0; c < st.cout; ++c) {
-                        const float scale = sl.w1.empty() ? 1.f : (sl.w1.size() == 1 ? sl.w1[0] : sl.w1[c]);
-                        const float shift = sl.w0.empty() ? 0.f : (sl.w0.size() == 1 ? sl.w0[0] : sl.w0[c]);
-                        sc[c] = scale;
-                        bias[c] = bias[c] * scale + shift;
-                    }
-                }
-                const TensorDef& tin = net.tensors[l.inputs[0]];
-                const int cin_logical = (int)tin.dims.d[tin.dims.nb - 3];
-                const size_t halfs = conv_chain_weight_halfs(st.cin, st.cout, st.k);
-                st.w_off = reserve(halfs * 2);
-                conv_chain_pack_weights(l.w0.data(), st.cout, cin_logical, st.k, sc.data(), reinterpret_cast<uint16_t*>(blob.data() + st.w_off));
-                st.b_off = reserve(bias.size() * 4);
-                memcpy(blob.data() + st.b_off, bias.data(), bias.size() * 4);
-                op.bytes += (double)halfs * 2;
-            }
-        } else if (op.kind == OP_CONV_GROUP) {   // members were packed just before (they precede their group in `every`)
-            op.bytes = 0;
-            for (const POp& m : op.group) op.bytes += m.bytes;
         } else if (op.kind == OP_YOLO_HEAD) {
             const LayerDef& l = net.layers[op.src_layer];
             op.w_off = reserve(16 * 4);
@@ -2141,6 +1982,11 @@ bool pack_weights(const Network& net, Plan* plan) {
             memcpy(blob.data() + op.w_off, power.data(), C * 4);
         }
     }
+    for (auto& op : plan->ops)   // a grouped launch moves what its members move (their packed weights were priced just above)
+        if (op.kind == OP_CONV_GROUP) {
+            op.bytes = 0;
+            for (const POp& m : op.group) op.bytes += m.bytes;
+        }
     plan->weight_bytes = align256(blob.size());
     blob.resize(plan->weight_bytes, 0);
     return true;
@@ -2175,7 +2021,7 @@ std::string Plan::describe_json() const {
             o << ",\"igemm\":" << (op.igemm ? "true" : "false") << ",\"stem\":" << (op.stem ? "true" : "false") << ",\"cin\":" << (a.in_i8 ? 2 * a.Cin : a.Cin) << ",\"cout\":" << a.Cout
               << ",\"k\":[" << a.kh << "," << a.kw << "],\"stride\":[" << a.stride_h << "," << a.stride_w << "],\"hw_in\":["
               << a.H << "," << a.W << "],\"hw_out\":[" << a.Ho << "," << a.Wo << "],\"act1\":" << a.act1
-              << ",\"act2\":" << a.act2 << ",\"up_c\":" << a.up_C << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
+              << ",\"act2\":" << a.act2 << ",\"alpha1\":" << a.alpha1 << ",\"alpha2\":" << a.alpha2 << ",\"up_c\":" << a.up_C << ",\"residual\":" << (op.in.size() > 1 ? "true" : "false")
               << ",\"bn_folded\":" << (op.scale_layer >= 0 ? "true" : "false") << ",\"ld_in\":" << a.ld_in
               << ",\"ld_out\":" << a.ld_out << ",\"i8\":[" << a.in_i8 << "," << a.out_i8 << "," << a.res_i8 << "],\"nmul\":" << (op.stem ? 1 : tensors[op.in[0]].nmul) << ",\"nfix\":"
               << (op.stem ? 0 : tensors[op.in[0]].nfix);
@@ -2192,21 +2038,6 @@ std::string Plan::describe_json() const {
                 o << ",\"in\":[";
                 for (size_t q = 0; q < m.in.size(); ++q) o << (q ? "," : "") << m.in[q];
                 o << "],\"out\":[" << m.out[0] << "]}";
-            }
-            o << "]";
-        }
-        if (op.kind == OP_CONV_CHAIN) {
-            const ConvArgs& a = op.conv;
-            o << ",\"cin\":" << a.Cin << ",\"cout\":" << a.Cout << ",\"hw_in\":[" << a.H << "," << a.W << "],\"hw_out\":[" << a.H << "," << a.W
-              << "],\"ld_in\":" << a.ld_in << ",\"ld_out\":" << a.ld_out << ",\"nmul\":" << tensors[op.in[0]].nmul << ",\"nfix\":" << tensors[op.in[0]].nfix
-              << ",\"weight_bytes\":";
-            double wb = 0;
-            for (const auto& st : op.chain) wb += 2.0 * (double)conv_chain_weight_halfs(st.cin, st.cout, st.k);
-            o << wb << ",\"stages\":[";
-            for (size_t j = 0; j < op.chain.size(); ++j) {
-                const auto& st = op.chain[j];
-                o << (j ? "," : "") << "{\"k\":" << st.k << ",\"cin\":" << st.cin << ",\"cout\":" << st.cout << ",\"act\":" << st.act << ",\"residual\":"
-                  << (st.residual ? "true" : "false") << "}";
             }
             o << "]";
         }

@@ -44,7 +44,7 @@ enum OpKind : int {
     OP_POOL_CHAIN,    // three chained k x k stride-1 'same' max-pools (SPPF) in one launch, three outputs
     OP_D2S,           // depth-to-space: [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c] (second half of a kernel == stride deconvolution)
     OP_ROI_ALIGN,     // detectron2 ROIAlign on the NHWC feature map, NHWC [P][res][res][C] out (fused form of the "RoiAlign" plugin)
-    OP_CONV_CHAIN,    // two or three stride-1 convolutions in one launch, intermediates in LDS (kernels/conv_chain.hip)
+    OP_RESERVED_47,   // (rounds 3-4: OP_CONV_CHAIN, the fused convolution chains - tools/hip/experiments/)
     OP_CONV_GROUP,    // 2..4 INDEPENDENT implicit-GEMM convolutions of one kernel instantiation in one launch (POp::group; round 4)
 };
 const char* op_kind_name(int k);
@@ -94,15 +94,6 @@ struct POp {
     bool igemm = false;
     bool stem = false;         // conv_stem kernel: reads the LINEAR fp32 input directly
     bool from_deconv = false;  // 1x1 conv standing in for a kernel == stride deconvolution (weights re-laid from CKRS)
-    // OP_CONV_CHAIN: the fused stages in order (stage 0 reads in[0]; the last one writes out[0]); `conv` keeps stage 0's geometry
-    struct ChainStage {
-        int src_layer = -1, scale_layer = -1;
-        int k = 3, cin = 0, cout = 0, act = ACT_NONE;
-        float alpha = 0.f;
-        bool residual = false;  // adds the chain input (C2f shortcut)
-        size_t w_off = 0, b_off = 0;
-    };
-    std::vector<ChainStage> chain;
     // OP_CONV_GROUP: the member convolutions, each a complete OP_CONV record (its own in / out tensors, ConvArgs, weights); the group's
     // in / out are the unions, so dependencies, lanes and buffer lifetimes see one op
     std::vector<POp> group;
@@ -148,7 +139,7 @@ struct Plan {
 // Lower a network into a plan (pure host work; no device needed).  Returns false and sets plan.error.
 bool lower_network(const Network& net, Plan* plan);
 // While > 0 on the calling thread, lower_network keeps every tensor of the definition that a kINT8 engine of it would keep: the passes
-// that make a tensor disappear from an fp16 plan but not from the int8 plan (fold_upsample, fuse_conv_chains) are off.  Set by
+// that make a tensor disappear from an fp16 plan but not from the int8 plan (fold_upsample) are off.  Set by
 // run_int8_calibration around the statistics engine: the observer sees a tensor only where an op writes it, and the upsampled slice of
 // a concat buffer must reach that buffer's histogram (the int8 engine requantises the upsampled feature into the shared
 // scale and would clip it if the scale came from the skip slice alone).

@@ -32,6 +32,7 @@
 #include <sstream>
 
 #include "../common.h"
+#include "../options.h"
 #include "engine.h"
 
 using namespace trtx;
@@ -70,9 +71,9 @@ void cache_load_locked() {
     static bool done = false;
     if (done) return;
     done = true;
-    const char* path = getenv("TRTX_TACTIC_CACHE");
-    if (!path || !*path) return;
-    FILE* f = fopen(path, "r");
+    const std::string path = read_options().tactic_cache;
+    if (path.empty()) return;
+    FILE* f = fopen(path.c_str(), "r");
     if (!f) return;
     char head[64] = {0};
     if (!fgets(head, sizeof head, f) || strncmp(head, kCacheHeader, strlen(kCacheHeader)) != 0) {  // another format: ignored
@@ -91,9 +92,9 @@ void cache_load_locked() {
     fclose(f);
 }
 void cache_append_locked(const SigKey& k, const Choice& c) {
-    const char* path = getenv("TRTX_TACTIC_CACHE");
-    if (!path || !*path) return;
-    FILE* f = fopen(path, "a");
+    const std::string path = read_options().tactic_cache;
+    if (path.empty()) return;
+    FILE* f = fopen(path.c_str(), "a");
     if (!f) return;
     if (ftell(f) == 0) fprintf(f, "%s\n", kCacheHeader);
     for (int i = 0; i < 28; ++i) fprintf(f, "%d ", k.v[i]);
@@ -123,9 +124,9 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
     // TRTX_TUNE=0 (read at every build / deserialize) keeps every layer on its static default, whatever the plan carries.  Measured
     // on YOLOv8n b32 (profiles/r02_tactics.txt, same box, alternating runs): one context 1.309-1.310 ms against 1.413-1.421 untuned
     // (conv launches 19.9 against 21.6 us); three contexts in flight 0.936-0.945 against 0.945-0.950 ms.  Timing costs 0.1-2 s.
-    const char* env = getenv("TRTX_TUNE");
-    const bool off = env && atoi(env) == 0;
-    const bool verbose = getenv("TRTX_TUNE_VERBOSE") != nullptr;
+    const Options opt = read_options();
+    const bool off = opt.tune == 0;
+    const bool verbose = opt.tune_verbose;
     Plan& plan = e->plan;
     e->tactics.clear();
     // setMaxAuxStreams(0) is how a caller says "I keep several execution contexts in flight": whole batches overlap, the chip is

@@ -57,6 +57,11 @@ SPEC = {
     ("retinaface_r50_int8", "vs_fp32_oracle"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
     ("retinaface_r50_int8", "vs_fp16_engine"): {"matched_iou50": ("min",), "mean_iou": ("min",), "mean_conf_err": ("max",)},
     ("retinaface_r50_int8", "minmax_vs_fp32_oracle"): {"matched_iou50": ("min", 1 / 3830), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    # int8 KERNEL parity: the engine against its own plan interpreted on the CPU at the plan's scales (oracle/lowered_int8.py) - no calibrator in the comparison
+    ("yolov8n_int8_640", "entropy2_engine_vs_plan_interpreter"): {"matched_iou90": ("min", 1 / 900), "matched_iou90_reverse": ("min", 1 / 900), "mean_conf_err": ("max",)},
+    ("yolov8n_int8_640", "minmax_engine_vs_plan_interpreter"): {"matched_iou90": ("min", 1 / 900), "matched_iou90_reverse": ("min", 1 / 900), "mean_conf_err": ("max",)},
+    ("retinaface_r50_int8", "int8_engine_vs_plan_interpreter"): {"matched_iou50": ("min", 1 / 3830), "mean_iou": ("min",), "mean_conf_err": ("max",)},
+    ("retinaface_r50_int8", "int8_minmax_engine_vs_plan_interpreter"): {"matched_iou50": ("min", 1 / 3830), "mean_iou": ("min",), "mean_conf_err": ("max",)},
 }
 
 # The numbers: written by `python tools/parity_bounds_from_record.py --write profiles/rNN_parity_metrics.jsonl` at 1.4x the worst value of the
@@ -146,6 +151,17 @@ CEILINGS = {
     ("retinaface_r50_int8", "vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
     ("retinaface_r50_int8", "vs_fp16_engine"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
     ("retinaface_r50_int8", "minmax_vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.85, "mean_conf_err": 0.10},
+    # Kernel parity at MODEL level.  Construct by construct the int8 engine equals its plan interpreted on the CPU bit for bit
+    # (tests/test_gpu_int8.py::test_int8_engine_equals_its_plan_interpreted_on_the_cpu - that is the assertion of kernel parity).  Through the 60 requantisations of
+    # a whole detector that exactness does not survive: an fp16-ulp difference anywhere (summation order of an fp16 layer chosen by the tactic timing, the stem's
+    # v_exp against torch.sigmoid) moves one value across an int8 rounding boundary, one int8 step is 1/254 of a tensor's range, and from there the two evaluations
+    # are two samples of the same quantisation noise.  What the model-level rows assert is that the engine is an order of magnitude closer to ITS PLAN than to the
+    # fp32 oracle (entropy calibration, same images: 83 % at IoU 0.5 / conf err 0.25 against the oracle; 94 % at IoU 0.9 / 0.03 against the plan): the gap to
+    # fp32 is the calibrator's clipping, not the kernels.
+    ("yolov8n_int8_640", "entropy2_engine_vs_plan_interpreter"): {"matched_iou90": 0.90, "matched_iou90_reverse": 0.90, "mean_conf_err": 0.06},
+    ("yolov8n_int8_640", "minmax_engine_vs_plan_interpreter"): {"matched_iou90": 0.90, "matched_iou90_reverse": 0.90, "mean_conf_err": 0.08},
+    ("retinaface_r50_int8", "int8_engine_vs_plan_interpreter"): {"matched_iou50": 0.95, "mean_iou": 0.88, "mean_conf_err": 0.06},
+    ("retinaface_r50_int8", "int8_minmax_engine_vs_plan_interpreter"): {"matched_iou50": 0.95, "mean_iou": 0.88, "mean_conf_err": 0.06},
 }
 SPEC[("yolov8n_int8_320", None)]["head_max_err_over_span_int8"] = ("max",)   # the worst head element was reported and unbounded.  Bounded
 # relative to the span of the logits: under entropy calibration a clipped activation moves single logits by a third of the span (measured

@@ -232,6 +232,18 @@ def test_yolov8n_int8_detections_at_640(gpu):
     parity.check("yolov8n_int8_640", "vs_fp32_oracle", **vs32)
     parity.check("yolov8n_int8_640", "vs_fp16_engine", **vs16)
     parity.check("yolov8n_int8_640", "minmax_vs_fp32_oracle", **mm32)
+    # KERNEL parity, independent of the calibrator (VERDICT r4 "missing 3"): the same two plans interpreted on the CPU at the scales they carry
+    # (oracle/lowered_int8.py: int8 storage, per-channel int8 weights, exact integer sums, the epilogue's fp32 / fp16 steps) - whatever the calibrator
+    # clipped is clipped on both sides, so what is left is what the int8 KERNELS do differently from their own specification
+    from oracle import lowered_int8 as li
+    for tag, algo in (("int8", "entropy2"), ("int8_minmax", "minmax")):
+        plan = plans[algo]
+        emu = li.run(plan, engine.describe_plan(plan), engine.describe_plan(plan, lowered=True), {"images": x}, B)["output"].reshape(B, -1)
+        st = _yolo_detection_stats(dec[tag], emu)
+        back = _yolo_detection_stats(emu, dec[tag])
+        parity.check("yolov8n_int8_640", f"{algo}_engine_vs_plan_interpreter", candidates=st["candidates"], matched_iou90=st["matched_iou90"], mean_iou=st["mean_iou"],
+                     mean_conf_err=st["mean_conf_err"], matched_iou90_reverse=back["matched_iou90"],
+                     count_ratio=float(dec[tag][:, 0].sum() / max(emu[:, 0].sum(), 1.0)))
 
 
 def _retina_loose_match(dec, ref, conf_floor=0.1):
@@ -305,3 +317,39 @@ def test_retinaface_r50_int8_engine(gpu):
     parity.check("retinaface_r50_int8", "vs_fp32_oracle", **vs32)
     parity.check("retinaface_r50_int8", "vs_fp16_engine", **vs16)
     parity.check("retinaface_r50_int8", "minmax_vs_fp32_oracle", **_retina_loose_match(out["int8_minmax"], ref))
+    # kernel parity at the plan's own scales (see test_yolov8n_int8_detections_at_640)
+    from oracle import lowered_int8 as li
+    for tag, plan in (("int8", plan8), ("int8_minmax", plan8mm)):
+        emu = li.run(plan, engine.describe_plan(plan), engine.describe_plan(plan, lowered=True), {"data": x.numpy()}, B)["prob"].reshape(B, -1)
+        st = _retina_loose_match(out[tag], emu)
+        parity.check("retinaface_r50_int8", f"{tag}_engine_vs_plan_interpreter", candidates=st["candidates"], matched_iou50=st["matched_iou50"], min_iou=st["min_iou"],
+                     mean_iou=st["mean_iou"], mean_conf_err=st["mean_conf_err"], count_ratio=float(out[tag][:, 0].sum() / max(emu[:, 0].sum(), 1.0)))
+
+
+# ------------------------------------------------------------------------------------------------ int8 kernel parity, construct by construct
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+
+EXACT_CONSTRUCTS = ["plain_chain", "shortcut", "relu_shortcut", "upsample_concat", "maxpool_between", "c2f_int8", "stem3", "head_arms"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", EXACT_CONSTRUCTS + ["sppf", "slice_then_chain"])
+def test_int8_engine_equals_its_plan_interpreted_on_the_cpu(gpu, name):
+    """VERDICT r4 "missing 3" / item 6: int8 KERNEL parity with no calibrator anywhere.  Small kINT8 networks built from the constructs of the YOLOv8n /
+    RetinaFace graphs (tools/int8_interp_probe.py: Conv-BN-SiLU chains fp16 -> int8 -> int8 -> fp16, int8 and fp16 shortcuts, ReLU after the add, the C2f
+    split / bottleneck / concat with an int8 buffer, SPPF's pool chain, upsample + concat with per-tensor scales - the int8 resize requantises -, a max-pool
+    between int8 layers, the 3-channel stem in front of an int8 layer, two detect arms off one int8 tensor), scales FABRICATED (a cache with a different
+    value per tensor), run on the GPU and through oracle/lowered_int8.py - the lowered plan evaluated with the arithmetic the kernels state.  Every construct
+    on the MFMA path must agree BIT FOR BIT; SPPF may differ by one fp16 ulp in a few values (max-pool of an fp16 tensor feeding an fp16 1x1), and the chain
+    behind a K = 16 convolution (the scalar direct kernel: accurate expf where the MFMA epilogue uses v_exp / v_rcp) in < 1 % of the values."""
+    import int8_interp_probe as probe
+    worst, frac = probe.run(name)
+    if name in EXACT_CONSTRUCTS:
+        assert worst == 0.0, f"{name}: engine and plan interpreter differ by up to {worst}"
+    elif name == "sppf":
+        assert worst <= 0.0079 and frac < 1e-3, (worst, frac)      # one fp16 ulp at |y| < 16
+    else:
+        assert frac < 0.01, (worst, frac)

@@ -1,6 +1,7 @@
 """The LDS-pipelined kernels may not pass a barrier with fragment reads in flight (the barrier frees the buffer those reads come from): checked on the
 COMPILED ISA of every MFMA convolution kernel, because nothing in the language makes the compiler keep the property - round 3's row-reuse kernel lost it in
-its three-stage instantiations and returned different results under co-scheduling (profiles/r04_r3_bisect.txt, tools/isa_barrier_reads.py).
+its three-stage instantiations and returned different results under co-scheduling (profiles/r04_r3_bisect.txt, tools/isa_barrier_reads.py); that kernel left
+the tree in round 5, the property stays under test for everything that ships.
 hipcc cross-compiles gfx950 without a GPU; the five translation units compile side by side (the big one takes about a minute)."""
 import os
 import subprocess
@@ -16,7 +17,7 @@ import isa_barrier_reads as scan  # noqa: E402
 
 CSRC = os.path.join(ROOT, "tensorrtx_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-UNITS = ["conv_igemm", "conv_gemm256", "conv_ws", "conv_chain", "conv_stem"]
+UNITS = ["conv_igemm", "conv_igemm_f32", "conv_gemm256", "conv_ws", "conv_stem"]
 
 SNIPPET = """
 	.amdhsa_kernel k_%s
@@ -75,19 +76,13 @@ k:
 def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
     with tempfile.TemporaryDirectory() as tmp:
         def compile_unit(u):
-            # "conv_igemm+experimental": the same file with the two experimental kernels compiled in (the row-reuse kernel with its fix, the resident-patch
-            # kernel) - they are not in the product library, and they must not lose the property while they wait for their GPU checks
             name, defs = u, []
-            if u.endswith("+experimental"):
-                name, defs = u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DTRTX_EXPERIMENTAL_PATCH"]
-            elif u.endswith("+round3_r3"):   # the row-reuse kernel as round 3 shipped it (no lgkmcnt(0) before the barrier): the scan must FIND its hazard
-                name, defs = u.split("+")[0], ["-DTRTX_EXPERIMENTAL_R3", "-DR3_VARIANT=32"]
             out = os.path.join(tmp, u + ".s")
             subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", "-mllvm",
                                    "-amdgpu-mfma-vgpr-form", *defs, "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels", name + ".hip")],
                                   stderr=subprocess.DEVNULL)
             return out
-        units = UNITS + ["conv_igemm+experimental", "conv_igemm+round3_r3"]
+        units = list(UNITS)
         with ThreadPoolExecutor(len(units)) as ex:
             outs = list(ex.map(compile_unit, units))
         counts = {}
@@ -95,11 +90,7 @@ def test_no_product_kernel_passes_a_barrier_with_lds_reads_in_flight():
             n, bad = scan.scan(path)
             counts[u] = n
             assert n > 0, f"{u}: no kernel found in the listing"
-            if u.endswith("+round3_r3"):
-                # fails-before-the-fix: exactly the three-stage instantiations of the row-reuse kernel (<NFRAG, 32, 2, 3>), nothing else
-                names = sorted(name for name, _ in bad)
-                assert len(names) == 4 and all("conv_igemm_r3_f16_kernel" in x and x.endswith("ELi32ELi2ELi3EEEvNS_8ConvArgsEjjiii") for x in names), names
-                continue
             assert not bad, f"{u}: barrier reached with LDS reads in flight in {bad}"
-        assert sum(counts[u] for u in UNITS) >= 250   # conv_igemm alone instantiates 218
-        assert counts["conv_igemm+experimental"] >= counts["conv_igemm"] + 12 + 40   # + the row-reuse and the resident-patch instantiations
+        # (the fails-before-the-fix case of round 4 - the row-reuse kernel as round 3 shipped it - left the tree with that kernel; the scanner's own
+        # behaviour is pinned by the two synthetic listings above)
+        assert sum(counts.values()) >= 300   # conv_igemm (incl. the resident-patch kernel) + conv_igemm_f32 + conv_ws + conv_gemm256 + conv_stem

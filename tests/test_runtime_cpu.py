@@ -126,7 +126,6 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     plan = engine.build_plan("yolov8n", path, batch=32, h=640, w=640, fp16=1)
     # layer by layer (the default): Appendix C.1's 63 convolutions = 1 stem (fp32 NCHW in) + 62 MFMA implicit-GEMM; the DFL
     # 1x1 convs are absorbed by the fused head kernel
-    monkeypatch.delenv("TRTX_FUSE_CHAINS", raising=False)
     # round 4: the detect head's 18 convolutions - six chains of depth three over three levels (model.cpp:188-251) - go out as 6 grouped
     # launches of 3 sibling layers each (lower.cpp group_convs): 65 -> 53 ops, 62 -> 50 MFMA conv launches
     grouped = engine.describe_plan(plan, lowered=True)
@@ -158,18 +157,6 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
     assert sum(o["residual"] for o in convs) == 6  # bottleneck shortcuts of model.2/4/6/8
     assert low["arena_bytes"] < 450e6
-    # TRTX_FUSE_CHAINS=1 (opt-in): the 10 C2f bottleneck pairs (block.cpp:98-110) and the 6 three-convolution arms of the detect head
-    # (model.cpp:188-251) run as fused chains: 38 of the 63 convolutions in 16 launches, 45 launches per step
-    monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
-    fused = engine.describe_plan(plan, lowered=True)
-    chains = [o for o in fused["ops"] if o["kind"] == "conv_chain"]
-    assert len(fused["ops"]) == 43 and len(chains) == 16
-    assert sorted(len(c["stages"]) for c in chains) == [2] * 10 + [3] * 6
-    assert sum(c["stages"][1]["residual"] for c in chains) == 6 and all(not c["stages"][0]["residual"] for c in chains)
-    assert sum(len(c["stages"]) for c in chains) + sum(o["kind"] == "conv" for o in fused["ops"]) == 63
-    assert abs(fused["flops_per_sample"] - low["flops_per_sample"]) < 1.0        # the same algorithmic work ...
-    assert fused["bytes_per_sample"] < 0.8 * low["bytes_per_sample"]             # ... over fewer bytes: intermediates never reach memory
-    assert fused["arena_bytes"] < low["arena_bytes"]
 
 
 def test_plan_roundtrip_is_byte_stable():
@@ -213,16 +200,13 @@ def test_retinaface_builder_matches_pytorch_restatement():
 
 
 def test_retinaface_lowering_at_config4_size(monkeypatch):
-    monkeypatch.setenv("TRTX_FUSE_CHAINS", "1")
     monkeypatch.setenv("TRTX_GROUP_CONVS", "0")
     path, _ = synth_wts("retinaface_r50")
     plan = engine.build_plan("retinaface_r50", path, batch=1, fp16=1, h=1280, w=1280)
     low = engine.describe_plan(plan, lowered=True)
     kinds = [o["kind"] for o in low["ops"]]
     convs = [o for o in low["ops"] if o["kind"] == "conv"]
-    chains = [o for o in low["ops"] if o["kind"] == "conv_chain"]   # SSH conv7X7_2 -> conv7x7_3 per level (retina_r50.cpp:87-98)
-    assert len(chains) == 3 and all([s["k"] for s in c["stages"]] == [3, 3] for c in chains)
-    assert len(convs) + 2 * len(chains) == 82 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == len(convs) - 1
+    assert len(convs) == 82 and convs[0]["stem"] and sum(o["igemm"] for o in convs) == len(convs) - 1
     assert abs(low["flops_per_sample"] / 1e9 - 354.0) < 1.0          # 354 GFLOP @1280^2
     assert "copy_nhwc" not in kinds and "act_nhwc" not in kinds      # SSH ReLU pushed into the conv epilogues, heads aliased
     # the FPN's two all-ones depthwise 2x2/2 deconvolutions (retina_r50.cpp:156-172) are what they compute: nearest upsamples
@@ -470,28 +454,6 @@ def test_conv_tactics_are_enumerated_on_the_host():
     assert capi.conv2d_tactics(32, 160, 160, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1, 0)]   # two taps per k-step: one configuration
     assert not any(x[5] for x in capi.conv2d_tactics(32, 40, 40, 64, 64, 3, 2, 1))        # stride 2: no row reuse
     assert not any(x[5] for x in capi.conv2d_tactics(32, 40, 40, 128, 128, 1, 1, 0))
-
-
-def test_conv_chain_plans_for_the_yolov8n_chains():
-    """host side of kernels/conv_chain.hip: every C2f bottleneck pair and detect-head arm of YOLOv8n b32 gets a tile whose LDS plan fits
-    the CU (160 KB) and enough workgroups to fill the chip; unsupported shapes are refused"""
-    from tensorrtx_amd import capi
-    chains = [(160, 16, [3, 3], [16, 16], [0, 1]), (80, 32, [3, 3], [32, 32], [0, 1]), (40, 64, [3, 3], [64, 64], [0, 1]),
-              (20, 128, [3, 3], [128, 128], [0, 1]), (40, 64, [3, 3], [64, 64], [0, 0]), (80, 32, [3, 3], [32, 32], [0, 0]),
-              (80, 64, [3, 3, 1], [64, 64, 64], None), (80, 64, [3, 3, 1], [80, 80, 80], None),
-              (40, 128, [3, 3, 1], [64, 64, 64], None), (40, 128, [3, 3, 1], [80, 80, 80], None),
-              (20, 256, [3, 3, 1], [64, 64, 64], None), (20, 256, [3, 3, 1], [80, 80, 80], None)]
-    for hw, cin, ks, couts, res in chains:
-        plan = capi.conv_chain_plan(32, hw, hw, cin, ks, couts, res)
-        assert plan is not None, (hw, cin, ks, couts)
-        th, tw, lds, nst = plan
-        assert lds <= 160 * 1024 and nst in (0, 1, 2, 4)   # weights resident in LDS (0) or streamed, that many k-steps per ring slot
-        tiles = 32 * ((hw + th - 1) // th) * ((hw + tw - 1) // tw)
-        assert tiles >= 256, (hw, cin, plan, tiles)
-    assert capi.conv_chain_plan(1, 20, 20, 64, [3, 3], [64, 48], None) is None      # stages must share Cout
-    assert capi.conv_chain_plan(1, 20, 20, 64, [3, 3], [96, 96], None) is None      # Cout not instantiated
-    assert capi.conv_chain_plan(1, 20, 20, 32, [3, 3], [64, 64], [0, 1]) is None    # shortcut needs Cin == Cout
-    assert capi.conv_chain_plan(1, 20, 20, 64, [5, 3], [64, 64], None) is None
 
 
 def test_int8_tensor_on_a_convolution_without_the_mfma_path_falls_back_to_fp16():

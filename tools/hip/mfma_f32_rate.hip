@@ -16,6 +16,8 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+__device__ int g_random_data;   // 1: the LDS tiles hold pseudo-random floats in [-1, 1) instead of small integers (data-dependent power -> clock?)
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const float* src, unsigned src_bytes, float* out, long long* clk, int steps) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 12288];
@@ -27,7 +29,11 @@ __global__ __launch_bounds__(256) void k(const float* src, unsigned src_bytes, f
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = floatx4{(float)lane, 1.f, 2.f, (float)j};
     if (MODE >= 1) {
-        for (int i = threadIdx.x; i < 3 * 12288 / 4; i += 256) reinterpret_cast<float*>(smem)[i] = (float)(i & 7);
+        for (int i = threadIdx.x; i < 3 * 12288 / 4; i += 256) {
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            reinterpret_cast<float*>(smem)[i] = g_random_data ? ((float)(h & 0xffffff) / 8388608.0f - 1.0f) : (float)(i & 7);
+        }
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
@@ -107,14 +113,18 @@ int main() {
     CHECK(hipMemset(src, 0, src_bytes));
     CHECK(hipMalloc(&out, 4096));
     CHECK(hipMalloc(&clk, 64));
-    for (int steps : {36, 400, 4000}) {
-        for (int w : {1, 2, 4}) {
+    for (int rnd : {0, 1}) {
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_random_data), &rnd, 4));
+    printf("## LDS operand tiles hold %s\n", rnd ? "pseudo-random floats in [-1, 1)" : "small integers (0..7)");
+    for (int steps : {400, 4000}) {
+        for (int w : {1, 4}) {
             run<0>("A bare MFMA loop", w, steps, src, src_bytes, out, clk);
             run<1>("B + 6 ds_read_b128 per step", w, steps, src, src_bytes, out, clk);
             run<2>("C + s_barrier per step", w, steps, src, src_bytes, out, clk);
             run<3>("D + 3 LDS-DMA pieces per step, range-checked", w, steps, src, src_bytes, out, clk);
             run<4>("E + 3 LDS-DMA pieces per step, from L2", w, steps, src, src_bytes, out, clk);
         }
+    }
     }
     return 0;
 }

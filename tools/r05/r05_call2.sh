@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, second GPU call: the fp32 MFMA convolution (unit tests, the fp32 engines' parity tests) and the fp32 YOLOv8n engine at C3 against the scalar path.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32; mkdir -p $O; cd $R
 timeout 300 python -m pytest tests/test_gpu_conv_f32.py -m gpu -q -x 2>&1 | tail -15 | tee $O/pytest_conv_f32.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, third GPU call: fp32 engine with the fp32 stem kernel, fast epilogue, fused fp32 detect tail, folded upsamples; per-shape A/B of the fp32 conv.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32b; mkdir -p $O; cd $R
 timeout 300 python -m pytest tests/test_gpu_conv_f32.py -m gpu -q -x 2>&1 | tail -5 | tee $O/pytest_conv_f32.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32c; mkdir -p $O; cd $R
 timeout 120 tools/hip/bin/mfma_f32_rate 2>&1 | tee $O/mfma_f32_rate.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32d; mkdir -p $O; cd $R
 timeout 300 python -m pytest tests/test_gpu_conv_f32.py -m gpu -q -x 2>&1 | tail -5 | tee $O/pytest_conv_f32.txt

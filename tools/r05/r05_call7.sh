@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32e; mkdir -p $O; cd $R
 timeout 600 python -m pytest tests/test_gpu_conv_f32.py tests/test_gpu_engine.py -m gpu -q -k "f32 or fp32 or folded_upsample_small" 2>&1 | tail -8 | tee $O/pytest.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_f32f; mkdir -p $O; cd $R
 # tile-count quantisation: 64->64 3x3 with 256 / 512 / 1024 / 2048 / 4096 tiles of 128 x 64 (1, 2, 4, 8, 16 per CU)

@@ -2,7 +2,7 @@
 # Round 5, first GPU call: the two operand-reuse kernels written in rounds 2-4 run at last, trimmed to fit ~15 GPU minutes:
 # resident-patch (tools/scratch/patch) and row-reuse (tools/scratch/r3) builds against the product library on ONE box.  Results under gpurun_out/r05_first/.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 export TMPDIR=/tmp
 O=$R/gpurun_out/r05_first; mkdir -p $O; cd $R
 LP=$R/tools/scratch/patch LR=$R/tools/scratch/r3
