@@ -5,6 +5,8 @@
 //   C  B + s_barrier per 32 MFMAs                                                                  -> + the workgroup barrier
 //   D  C + 3 buffer_load ... lds pieces per 32 MFMAs, range-checked away (no memory access)         -> + DMA issue
 //   E  D with the loads real (an L2-resident 4 MB source)                                           -> + the fill
+//   F  E with ROLES: 8 waves, waves 4-7 only fetch (issue, counted wait, barrier), waves 0-3 only multiply (barrier, fragment reads, MFMAs)
+//   G  E with the three pieces pinned between the MFMAs (after the 4th, 14th, 24th) instead of wherever the compiler puts them
 // clock64() counts shader cycles, wall_clock64() a constant 100 MHz: their ratio is the clock the kernel actually ran at.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/hip/mfma_f32_rate.hip -o tools/hip/bin/mfma_f32_rate
 #include <hip/hip_runtime.h>
@@ -19,7 +21,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ int g_random_data;   // 1: the LDS tiles hold pseudo-random floats in [-1, 1) instead of small integers (data-dependent power -> clock?)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(const float* src, unsigned src_bytes, float* out, long long* clk, int steps) {
+__global__ __launch_bounds__(MODE == 5 ? 512 : 256) void k(const float* src, unsigned src_bytes, float* out, long long* clk, int steps) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 12288];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     floatx4 acc[8];
@@ -38,14 +40,35 @@ __global__ __launch_bounds__(256) void k(const float* src, unsigned src_bytes, f
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     const long long c0 = clock64(), w0 = wall_clock64();
-    unsigned off = (unsigned)((blockIdx.x * 256 + threadIdx.x) * 16) % (src_bytes - 65536);
+    unsigned off = (unsigned)((blockIdx.x * 256 + (threadIdx.x & 255)) * 16) % (src_bytes - 65536);
+    if (MODE == 5 && wave >= 4) {   // the fetching role: nothing but issue, counted wait, barrier
+        for (int s = 0; s < steps; ++s) {
+            __builtin_amdgcn_s_barrier();
+            const int nst = (s + 2) % 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + nst * 12288 + (4 * p + wave - 4) * 1024), 16, off + p * 16384, 0, 0, 0);
+            off = (off + 49152) % (src_bytes - 65536);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     for (int s = 0; s < steps; ++s) {
         const int st = s % 3;
-        if (MODE >= 2) {
+        if (MODE == 5) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (MODE == 6) {
             asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (MODE >= 3) {
+        if (MODE >= 2 && MODE <= 4) {
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (MODE == 3 || MODE == 4) {
             const int nst = (s + 2) % 3;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -66,7 +89,17 @@ __global__ __launch_bounds__(256) void k(const float* src, unsigned src_bytes, f
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][s4], a[i][s4], acc[i * 4 + j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][s4], a[i][s4], acc[i * 4 + j], 0, 0, 0);
+                    const int n = s4 * 8 + j * 2 + i;
+                    if (MODE == 6 && (n == 3 || n == 13 || n == 23)) {
+                        const int p = n / 10;
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + ((s + 2) % 3) * 12288 + (4 * p + wave) * 1024), 16, off + p * 16384, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        if (MODE == 6) off = (off + 49152) % (src_bytes - 65536);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long c1 = clock64(), w1 = wall_clock64();
@@ -90,7 +123,7 @@ static void run(const char* what, int wg_per_cu, int steps, const float* src, un
     long long h[2] = {0, 0};
     for (int r = 0; r < 4; ++r) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, src, src_bytes, out, clk, steps);
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(MODE == 5 ? 512 : 256), 0, 0, src, src_bytes, out, clk, steps);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -113,16 +146,18 @@ int main() {
     CHECK(hipMemset(src, 0, src_bytes));
     CHECK(hipMalloc(&out, 4096));
     CHECK(hipMalloc(&clk, 64));
-    for (int rnd : {0, 1}) {
+    for (int rnd : {1}) {
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_random_data), &rnd, 4));
     printf("## LDS operand tiles hold %s\n", rnd ? "pseudo-random floats in [-1, 1)" : "small integers (0..7)");
-    for (int steps : {400, 4000}) {
-        for (int w : {1, 4}) {
+    for (int steps : {2000}) {
+        for (int w : {1, 2, 3, 4}) {
             run<0>("A bare MFMA loop", w, steps, src, src_bytes, out, clk);
             run<1>("B + 6 ds_read_b128 per step", w, steps, src, src_bytes, out, clk);
             run<2>("C + s_barrier per step", w, steps, src, src_bytes, out, clk);
             run<3>("D + 3 LDS-DMA pieces per step, range-checked", w, steps, src, src_bytes, out, clk);
             run<4>("E + 3 LDS-DMA pieces per step, from L2", w, steps, src, src_bytes, out, clk);
+            run<5>("F = E with roles (4 fetching + 4 multiplying waves)", w, steps, src, src_bytes, out, clk);
+            run<6>("G = E, pieces pinned between the MFMAs", w, steps, src, src_bytes, out, clk);
         }
     }
     }
