@@ -18,6 +18,7 @@
 // shadow of the matrix pipe here.  Every tile shape sums K in the same order: all tactics return the same bits.
 #include "../options.h"
 #include "igemm_tile.h"
+#include "patch_tile.h"
 
 namespace trtx {
 namespace {
@@ -43,6 +44,10 @@ bool rs_exists(const ConvArgs& a, int bn, int bm) { return a.CinK != 8 && a.up_C
 // the same packed weights and the same bits as the 16-channel step.  Instantiated for the 64- and 128-row tiles, 32..128 columns wide, of the general and the
 // plain-GEMM walk and of the folded upsample
 bool wide_exists(const ConvArgs& a, int bn, int bm) { return a.CinK % 32 == 0 && a.Kpad % 32 == 0 && bm <= 128 && bn >= 32 && (a.up_C % 32) == 0; }
+
+// roles (ConvArgs::t_ws == 6; igemm_tile.h ROLES): four fetching + four multiplying waves per workgroup, 16-channel steps through LDS-DMA, same bits.
+// Instantiated for the 64- and 128-row tiles, 32..128 columns wide, of the general walk, the plain-GEMM walk and the folded upsample
+bool roles_exist(const ConvArgs& a, int bn, int bm) { return a.CinK != 8 && bm <= 128 && bn >= 32; }
 
 template <int NFRAG, int MI>
 void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
@@ -73,6 +78,16 @@ void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigne
     }
 #endif
     if constexpr (MI <= 2 && NFRAG >= 2) {
+        if (a.t_ws == 6 && roles_exist(a, BN, BMT)) {
+            const dim3 block2(512);
+            if (a.up_C > 0)
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, true, false, true, true>), grid, block2, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            else if (plain_gemm_f32(a))
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, true, true, true>), grid, block2, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            else
+                TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, false, true, true>), grid, block2, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+            return;
+        }
         if (a.t_ws == 5 && rs_exists(a, BN, BMT)) {
             if (plain_gemm_f32(a))
                 TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, true, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
@@ -91,6 +106,53 @@ void launch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigne
         TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, true, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
     } else {
         TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, 32, 1, false, MI, 1, 0, false, 4, false, false, false, true>), grid, block, 0, s, k, in_bytes, w_bytes, tiles_n, total, chunk, 0);
+    }
+}
+
+// ---- the resident-patch kernel with fp32 operands (ConvArgs::t_ws == 3; patch_tile.h): 3x3 stride 1 pad 1, the input of a TH x 16 output block lies in LDS
+// once as Cin / 16 planes, only the weight tile streams per k-step.  Planes: 16 / 32 / 48 / 64 / 80 / 128 input channels (1 .. 8 planes of an 8-row patch:
+// 15 KB each; 16-row patches up to two planes), column tiles 16 .. 80 wide.  Same K order, same two-level sum: the implicit-GEMM kernel's bits.
+bool patch_possible_f32(const ConvArgs& a, int bn) {
+    const int kc = a.CinK / 16;
+    return !a.up_C && a.kh == 3 && a.kw == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 && a.CinK % 16 == 0 &&
+           (kc <= 5 || kc == 8) && a.Kpad == 9 * a.CinK && !a.scalar_out && a.Ho == a.H && a.Wo == a.W &&
+           (bn == 16 || bn == 32 || bn == 64 || bn == 80) && a.Cout_pad % bn == 0;   // (128 columns: 2 x 64 accumulator registers + 40 of fragments - no)
+}
+int patch_rows_f32(const ConvArgs& a) { return (a.CinK <= 32 && a.H >= 16) ? 16 : 8; }
+
+template <int NFRAG, int KC>
+void launch_patch_f32_mi(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    const int th = patch_rows_f32(a);
+    const int tiles_n = a.Cout_pad / (16 * NFRAG), tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th;
+    const int total = a.N * tiles_y * tiles_x * tiles_n, chunk = (total + 7) / 8;
+    if constexpr (KC <= 2) {
+        if (th == 16) {
+            TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 4, true>), dim3(chunk * 8), dim3(256), 0, s, k, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+            return;
+        }
+    }
+    TRTX_LAUNCH((conv_patch_f16_kernel<NFRAG, KC, 2, true>), dim3(chunk * 8), dim3(256), 0, s, k, in_bytes, w_bytes, tiles_n, tiles_x, tiles_y, total, chunk);
+}
+template <int NFRAG>
+int32_t launch_patch_f32_kc(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    switch (a.CinK / 16) {
+        case 1: launch_patch_f32_mi<NFRAG, 1>(a, k, in_bytes, w_bytes, s); break;
+        case 2: launch_patch_f32_mi<NFRAG, 2>(a, k, in_bytes, w_bytes, s); break;
+        case 3: launch_patch_f32_mi<NFRAG, 3>(a, k, in_bytes, w_bytes, s); break;
+        case 4: launch_patch_f32_mi<NFRAG, 4>(a, k, in_bytes, w_bytes, s); break;
+        case 5: launch_patch_f32_mi<NFRAG, 5>(a, k, in_bytes, w_bytes, s); break;
+        case 8: launch_patch_f32_mi<NFRAG, 8>(a, k, in_bytes, w_bytes, s); break;
+        default: return TRTX_ERR_UNSUPPORTED;
+    }
+    return TRTX_OK;
+}
+int32_t launch_patch_f32(const ConvArgs& a, const ConvArgs& k, unsigned in_bytes, unsigned w_bytes, hipStream_t s) {
+    switch (a.bn) {
+        case 16: return launch_patch_f32_kc<1>(a, k, in_bytes, w_bytes, s);
+        case 32: return launch_patch_f32_kc<2>(a, k, in_bytes, w_bytes, s);
+        case 64: return launch_patch_f32_kc<4>(a, k, in_bytes, w_bytes, s);
+        case 80: return launch_patch_f32_kc<5>(a, k, in_bytes, w_bytes, s);
+        default: return TRTX_ERR_UNSUPPORTED;
     }
 }
 
@@ -162,6 +224,8 @@ bool conv_igemm_f32_supported(const ConvArgs& a) {
         const int bm = a.bm ? a.bm : 128;
         if (!a.bn || a.Cout_pad % a.bn || !tile_exists(a, a.bn, bm)) return false;
         if (a.t_ws == 5 && (!rs_exists(a, a.bn, bm) || a.bk != 16)) return false;
+        if (a.t_ws == 6 && (!roles_exist(a, a.bn, bm) || a.bk != 16)) return false;
+        if (a.t_ws == 3 && (!patch_possible_f32(a, a.bn) || a.bk != 16)) return false;
         if (a.bk == 32 && !wide_exists(a, a.bn, bm)) return false;
     } else {   // the launcher's own choice must exist (a folded upsample into 16 output channels has no instantiation)
         int bn = 0, bm = 0;
@@ -186,6 +250,11 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
     push(bn0, bm0);
     static const int bns[5] = {128, 80, 64, 32, 16};
     static const int bms[3] = {128, 64, 256};
+    for (int bn : bns)   // the resident-patch kernel at the widest column tile
+        if (patch_possible_f32(a, bn)) {
+            push(bn, 128, 3);
+            break;
+        }
     for (int bn : bns) {
         if (a.Cout_pad % bn) continue;
         if (bn <= 32 && a.Cout_pad > 2 * bn) continue;
@@ -194,6 +263,7 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
                 push(bn, bm);
                 if (wide_exists(a, bn, bm)) push(bn, bm, 1, 32);
                 if (rs_exists(a, bn, bm)) push(bn, bm, 5);
+                if (options().roles && roles_exist(a, bn, bm)) push(bn, bm, 6);
             }
     }
     return n;
@@ -217,7 +287,8 @@ int32_t conv_igemm_f32(const ConvArgs& a0, hipStream_t s) {
         const ConvArgs k = kernel_units(a);
         const unsigned in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * 4);
         int32_t st;
-        if (a.bm == 64) st = launch_f32_bn<1>(a, k, in_bytes, w_bytes, s);
+        if (a.t_ws == 3) st = launch_patch_f32(a, k, in_bytes, w_bytes, s);
+        else if (a.bm == 64) st = launch_f32_bn<1>(a, k, in_bytes, w_bytes, s);
         else if (a.bm == 256) st = launch_f32_bn<4>(a, k, in_bytes, w_bytes, s);
         else st = launch_f32_bn<2>(a, k, in_bytes, w_bytes, s);
         if (st != TRTX_OK) return st;

@@ -449,8 +449,14 @@ constexpr int igemm_lds_bytes() {
 
 // One (BM x BN) output tile at (m0, n0) of the convolution `p`: the whole kernel but for the blockIdx -> tile mapping, which the two
 // entry points below do differently (one problem per launch / several problems per launch, round 4).
+// ROLES (round 5): the workgroup is 2 * NW waves; waves NW .. 2NW-1 only FETCH (address arithmetic, the LDS-DMA pieces, the counted wait, the barrier) and
+// waves 0 .. NW-1 only MULTIPLY (barrier, fragment reads, MFMAs, epilogue).  A DMA piece holds its wave's issue port for 60-200 cycles and the tap / address
+// arithmetic in front of it for a few dozen more; in the one-role kernel that is time the same wave's MFMAs are not being issued (a wave issues in order), and
+// with 3-4 waves per SIMD the others cover it only partly: tools/hip/mfma_f32_rate.hip measures the bare skeleton at 0.66 / 0.77 / 0.82 of the fp32 MFMA peak
+// with 1 / 2 / 4 workgroups per CU, and the same skeleton with roles at 0.80 / 0.89 / 0.89 (profiles/r05_mfma_f32_rate_roles.txt).  Same tiles, same LDS
+// contents, same K order: the same bits as the one-role kernel.
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
-          bool ONE = false, bool F32 = false>
+          bool ONE = false, bool F32 = false, bool ROLES = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_bytes, unsigned w_bytes, const int m0, const int n0, int dbg_flags,
                                                 char* __restrict__ smem) {
     const int dbg = TRTX_DBG(dbg_flags);
@@ -478,7 +484,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool fetcher = ROLES && wave_all >= NW;            // wave-uniform
+    const int wave = ROLES ? (wave_all & (NW - 1)) : wave_all;   // a fetching wave fills the LDS rows the one-role kernel's wave of the same index fills
+    static_assert(!ROLES || (!RS && NW == 4), "roles: LDS-DMA operands, 4 + 4 waves");
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, w_bytes, 0x00020000);
@@ -805,7 +814,42 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
         TRTX_STAMP(4, kt);                                                    \
     }
 
-    if constexpr (RS) {
+    if constexpr (ROLES) {
+        if (fetcher) {
+#pragma unroll
+            for (int st = 0; st < NST - 1; ++st) issue_tile(st);
+            for (int kt = 0;;) {
+                bool done = false;
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    if (done) continue;
+                    // tile kt has landed (at most the NST - 2 younger tiles in flight) - said to the multiplying waves by the barrier
+                    if (B_PARTIAL && !b_last_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LOADS_PER_TILE - 1) * (NST - 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE * (NST - 2)) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue_tile((st + NST - 1) % NST);   // into the stage the multiplying waves finished with before this barrier
+                    if (++kt == nk) done = true;
+                }
+                if (done) break;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-out tiles' LDS writes (range-checked away) retire before the wave ends
+            if constexpr (!F32) __builtin_amdgcn_s_barrier();  // ... and before the multiplying waves' epilogue reuses the stages as staging tiles (below)
+            return;                                             // (an ended wave no longer counts at the workgroup's barriers)
+        }
+        for (int kt = 0;;) {
+            bool done = false;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (done) continue;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous step's fragment reads are COMPLETE before the stage is given back
+                __builtin_amdgcn_s_barrier();
+                compute(st);
+                if (++kt == nk) done = true;
+            }
+            if (done) break;
+        }
+        if constexpr (!F32) __builtin_amdgcn_s_barrier();   // the fetching waves' last LDS writes have retired (the fp32 epilogue does not touch LDS)
+    } else if constexpr (RS) {
         // registers <- tile 0; LDS stage 0 <- registers; registers <- tile 1.  Step kt: (writes of tile kt visible) barrier, MFMAs of
         // stage kt & 1, then tile kt+1 goes from the registers to the other stage - free since every wave passed this step's barrier
         // after its reads of step kt-1 - and tile kt+2 is fetched.  The compiler places the vmcnt / lgkmcnt waits of the register path.
@@ -863,8 +907,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_b
 }
 
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
-          bool ONE = false, bool F32 = false>
-__global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
+          bool ONE = false, bool F32 = false, bool ROLES = false>
+__global__ __launch_bounds__(NW * 64 * (ROLES ? 2 : 1)) void conv_igemm_f16_kernel(const ConvArgs p, unsigned in_bytes, unsigned w_bytes, int tiles_n,
                                                              int total_tiles, int xcd_chunk, int dbg_flags) {
     __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<NFRAG, BKT, MI, WN, NSTO, NW, RS>()];   // up to 144 KB of the CU's 160 KB
     int tile = blockIdx.x;
@@ -874,7 +918,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_f16_kernel(const ConvArgs 
     }
     const int m0 = (tile / tiles_n) * ((NW / WN) * 16 * MI);
     const int n0 = (tile % tiles_n) * (16 * NFRAG);
-    conv_igemm_tile<NFRAG, BKT, TPS, I8, MI, WN, NSTO, PRE, NW, RS, UP, ONE, F32>(p, in_bytes, w_bytes, m0, n0, dbg_flags, smem);
+    conv_igemm_tile<NFRAG, BKT, TPS, I8, MI, WN, NSTO, PRE, NW, RS, UP, ONE, F32, ROLES>(p, in_bytes, w_bytes, m0, n0, dbg_flags, smem);
 }
 
 // Several INDEPENDENT convolutions in one launch (round 4).  The YOLOv8 detect head is six chains of depth three over

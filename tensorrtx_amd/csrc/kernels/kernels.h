@@ -45,7 +45,7 @@ struct ConvArgs {
     // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
     int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
-    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 3 = the resident-patch 3x3
+    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 6 = (fp32 launches) fetching + multiplying wave roles; 3 = the resident-patch 3x3
                 // kernel instead (conv_igemm.hip, builds with -DTRTX_EXPERIMENTAL_PATCH only)
     int t_rs;   // implicit-GEMM operands through registers (global -> VGPR -> ds_write) instead of LDS-DMA: 0 = no, 1 = yes (same bits)
     int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two

@@ -46,6 +46,9 @@ CASES = [
     (2, 80, 80, 192, 64, 1, 1, 0, "silu", False, "none"),
     (7, 20, 20, 256, 256, 1, 1, 0, "silu", False, "none"),
     (1, 7, 9, 64, 64, 1, 1, 0, "none", True, "relu"),        # 63 pixels: a single ragged tile
+    (2, 40, 40, 32, 32, 3, 1, 1, "silu", False, "none"),     # resident patch: two planes of a 16-row patch
+    (1, 20, 20, 128, 64, 3, 1, 1, "silu", False, "none"),    # resident patch: eight planes (one workgroup per CU)
+    (1, 20, 20, 128, 128, 3, 1, 1, "silu", True, "none"),    # ... two 64-wide column tiles over one patch; wave roles at 128 columns
 ]
 
 
@@ -79,6 +82,11 @@ def test_conv_f32_mfma_vs_torch_and_every_tile_shape_is_the_same_bits(gpu, case)
     N, H, W, Cin, Cout, k, s, p, _, use_res, _ = case
     tiles = capi.conv2d_tactics_f32(N, H, W, Cin, Cout, k, s, p, residual=use_res)
     assert len(tiles) >= 1
+    kinds = {t[2] for t in tiles}
+    if k == 3 and s == 1 and p == 1 and Cin % 16 == 0 and Cin // 16 in (1, 2, 3, 4, 5, 8) and Cout % 4 == 0:
+        assert 3 in kinds, "the resident-patch kernel is a candidate for every 3x3 stride-1 layer it can take"
+    if Cin > 8 and ((Cout + 15) // 16 * 16) % 32 == 0:
+        assert 6 in kinds and 5 in kinds, "wave roles / register-staged operands are candidates wherever a 32-wide column tile exists"
     for t in tiles[1:]:
         other, _, _ = _run(case, gpu, tile=t)
         assert torch.equal(other, got), f"tile {t} differs from tile {tiles[0]}"

@@ -18,6 +18,7 @@ REPS = 10
 
 
 ONLY = None
+KINDS = None   # --kinds 1,6: only these operand paths (1 LDS-DMA, 5 registers, 6 roles), 16-channel steps
 
 
 def one(N, H, W, Cin, Cout, k, s, act):
@@ -37,6 +38,8 @@ def one(N, H, W, Cin, Cout, k, s, act):
     for t in capi.conv2d_tactics_f32(N, H, W, Cin, Cout, k, s, p):
         if ONLY and tuple(t) != ONLY:
             continue
+        if KINDS and (t[2] not in KINDS or t[3] != 16):
+            continue
         y = capi.conv2d_nhwc_f32(x, wg, bias, Cout, k, k, s, p, act, tile=t)
         torch.cuda.synchronize()
         ts = []
@@ -54,7 +57,7 @@ def one(N, H, W, Cin, Cout, k, s, act):
         same = "same bits" if torch.equal(got, first) else f"DIFFERS max {float((got - first).abs().max()):.3g}"
         med = sorted(ts)[len(ts) // 2]
         tiles = -(-N * Ho * Wo // t[1]) * (cout_pad // t[0])
-        print(f"   bn {t[0]:3d} bm {t[1]:3d} {'regs' if t[2] == 5 else 'dma '} bk {t[3]:2d}  {tiles:6d} tiles ({tiles / 256:5.1f}/CU)  median {med:7.1f} us  min {min(ts):7.1f}  = {gflop / med * 1e3:6.1f} TF/s ({gflop / med * 1e3 / 157.3:.2f})  {same}")
+        print(f"   bn {t[0]:3d} bm {t[1]:3d} { {3: 'ptch', 5: 'regs', 6: 'role'}.get(t[2], 'dma ')} bk {t[3]:2d}  {tiles:6d} tiles ({tiles / 256:5.1f}/CU)  median {med:7.1f} us  min {min(ts):7.1f}  = {gflop / med * 1e3:6.1f} TF/s ({gflop / med * 1e3 / 157.3:.2f})  {same}")
 
 
 if __name__ == "__main__":
@@ -67,6 +70,10 @@ if __name__ == "__main__":
     if "--only" in argv:
         i = argv.index("--only")
         ONLY = tuple(int(v) for v in argv[i + 1].split(","))
+        del argv[i:i + 2]
+    if "--kinds" in argv:
+        i = argv.index("--kinds")
+        KINDS = tuple(int(v) for v in argv[i + 1].split(","))
         del argv[i:i + 2]
     a = [int(v) for v in argv]
     shapes = [tuple(a[i:i + 7]) for i in range(0, len(a), 7)] if a else SHAPES
