@@ -412,6 +412,8 @@ def main():
                     help="int8: BuilderFlag::kINT8 engine (entropy calibration on 2 synthetic batches, int8 MFMA convs, fp16 fallback)")
     ap.add_argument("--contexts", type=int, default=3,
                     help="execution contexts kept in flight per GPU (each on its own stream; 1 = the reference's serial loop)")
+    ap.add_argument("--upload-buffers", type=int, default=0,
+                    help="host-fed leg: device frame buffers the uploads rotate through (0 = 2 x contexts + 2)")
     ap.add_argument("--repeats", type=int, default=7,
                     help="the W-warm-up + K-step timed leg is run this many times back to back; `value` is the MEDIAN leg (all legs are printed)")
     ap.add_argument("--replicas", default="processes", choices=["processes", "in-process"],
@@ -696,7 +698,7 @@ def main():
     dt_host = host_legs = None
     if cfg["nms"]:
         from tensorrtx_amd import preproc
-        n_up = n_ctx + 1
+        n_up = args.upload_buffers or (2 * n_ctx + 2)   # a frame buffer is held until its batch's last kernel (the event the caller can see): with n_ctx + 1 of them the uploads waited for whole batches
         # the same synthetic scenes as the resident-input legs, as camera frames: uint8, HWC, BGR
         def as_frames(x):
             return pin(torch.from_numpy(np.ascontiguousarray((np.clip(x, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8).transpose(0, 2, 3, 1)[..., ::-1])))
@@ -721,7 +723,7 @@ def main():
             slot.run(None if not dry else net_in[k % n_ctx], with_d2h=True, frames=list(raw[s]))
             consumed[s].record(slot.stream)
 
-        def host_timed(n_steps):
+        def host_timed(n_steps, uploads=True):
             for s in range(n_up):
                 consumed[s].record(tc.current_stream())
             tc.synchronize()
@@ -729,9 +731,10 @@ def main():
                 dist.barrier()
             tc.synchronize()
             t0 = time.perf_counter()
-            upload(0)
+            if uploads:
+                upload(0)
             for k in range(n_steps):
-                if k + 1 < n_steps:
+                if uploads and k + 1 < n_steps:
                     upload((k + 1) % n_up)               # prefetch the next batch while the earlier ones compute
                 host_step(k)
             tc.synchronize()
@@ -740,10 +743,26 @@ def main():
             tc.synchronize()
             return replicas.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
-        host_timed(min(2 * n_ctx, args.steps))           # warm the path (letterbox kernel, pinned copies)
-        host_all = [host_timed(args.steps) for _ in range(3)]
-        dt_host = sorted(host_all)[1]
+        def h2d_alone(n_steps):
+            # the uploads of the same frames with nothing else on the GPU: what the PCIe link itself sustains for this transfer size
+            tc.synchronize()
+            t0 = time.perf_counter()
+            with tc.stream(copy_stream):
+                for k in range(n_steps):
+                    raw[k % n_up].copy_(frames[k % n_up], non_blocking=True)
+            tc.synchronize()
+            return time.perf_counter() - t0
+
+        host_timed(args.steps)                           # warm the path: letterbox kernel, pinned copies, the link (round 5: the first leg after a 6-step warm-up ran 2x slow, legs 3-7 within 0.5 %)
+        host_all = [host_timed(args.steps) for _ in range(7)]   # seven legs like `value` (round 4 took three and one of them was a 2x outlier)
+        dt_host = sorted(host_all)[3]
         host_legs = [round(h / args.steps * 1e3, 4) for h in host_all]
+        # the same steps with the frames already on the device (the `uploaded` events of the last leg stay signalled): what the fused letterbox + stem
+        # costs against the resident fp32 input of `value` - the rest of the distance to `value` is the link
+        frames_resident_ms = sorted(host_timed(args.steps, uploads=False) for _ in range(3))[1] / args.steps * 1e3
+        h2d_alone(2)
+        h2d_ms = sorted(h2d_alone(args.steps) for _ in range(3))[1] / args.steps * 1e3
+        host_frame_bytes = int(frames[0].numel())
 
     # per-kernel timing with HIP events on the launch stream (IProfiler analogue): roofline of the dominant kernel
     prof_runs = 5
@@ -897,6 +916,9 @@ def main():
                                 "what": "same steps + async copy of the kept counts and the compacted detection buffer [B,1000,6] to pinned host memory each step (the reference's timer includes D2H, yolov8_det.cpp:97-104)"}
         res["host_fed"] = {"value": (global_batch if mode == "strong" else world * batch) * args.steps / dt_host, "unit": "images/sec",
                            "ms_per_step": dt_host / args.steps * 1e3, "legs_ms": host_legs,
+                           "pcie": {"h2d_bytes_per_step": host_frame_bytes, "h2d_alone_ms_per_step": h2d_ms, "h2d_alone_GBps": host_frame_bytes / (h2d_ms * 1e-3) / 1e9 if h2d_ms else None,
+                                    "h2d_share_of_step": h2d_ms / (dt_host / args.steps * 1e3) if dt_host else None, "frames_resident_ms_per_step": frames_resident_ms,
+                                    "what": "the uploads of the same pinned frames alone (no kernels): the link's own time per step - the host-fed rate is bounded by max(upload, compute)"},
                            "what": "PCIe-inclusive: uint8 HWC frames in pinned host memory -> H2D on a copy stream (double-buffered, overlapped) -> enqueue_frames (the letterbox is fused into the stem convolution: no fp32 input tensor) -> NMS -> D2H of the detections; never `value`"}
         res["detections"] = detections
     # internal consistency: a leg that does strictly MORE work per step (the D2H copies) or keeps fewer batches in flight (one

@@ -390,16 +390,20 @@ void launch_lds(const ConvArgs& a, hipStream_t s) {
     const unsigned in_bytes = (unsigned)((size_t)a.N * a.Cin * a.H * a.W * 4);
     const int total = a.N * g.tiles_x * g.tiles_y;
     // as many workgroups as are resident at once (registers and this LDS size decide), each walking total / grid tiles
-    static thread_local int resident[2] = {0, 0};   // [0]: LDS bytes the figure was computed for, [1]: workgroups on the chip
-    if (resident[0] != (int)lds || resident[1] <= 0) {
-        int per_cu = 0, dev = 0, cus = 0;
+    // (cached per thread, kernel instantiation, DEVICE and LDS size: a thread that moves to a GPU with another CU count must not reuse the figure - ADVICE r4)
+    static thread_local int resident[3] = {-1, 0, 0};   // [0]: device, [1]: LDS bytes the figure was computed for, [2]: workgroups on the chip
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (resident[0] != dev || resident[1] != (int)lds || resident[2] <= 0) {
+        int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_stem_lds_kernel<NFRAG, KS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         (void)hipGetLastError();
-        resident[0] = (int)lds;
-        resident[1] = per_cu * cus;
+        resident[0] = dev;
+        resident[1] = (int)lds;
+        resident[2] = per_cu * cus;
     }
-    const int grid = total < resident[1] ? total : resident[1];
+    const int grid = total < resident[2] ? total : resident[2];
     hipLaunchKernelGGL((conv_stem_lds_kernel<NFRAG, KS>), dim3((unsigned)grid), dim3(256), lds, s, a, g, in_bytes, total);
 }
 
