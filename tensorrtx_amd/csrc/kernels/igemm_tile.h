@@ -454,7 +454,9 @@ constexpr int igemm_lds_bytes() {
 // arithmetic in front of it for a few dozen more; in the one-role kernel that is time the same wave's MFMAs are not being issued (a wave issues in order), and
 // with 3-4 waves per SIMD the others cover it only partly: tools/hip/mfma_f32_rate.hip measures the bare skeleton at 0.66 / 0.77 / 0.82 of the fp32 MFMA peak
 // with 1 / 2 / 4 workgroups per CU, and the same skeleton with roles at 0.80 / 0.89 / 0.89 (profiles/r05_mfma_f32_rate_roles.txt).  Same tiles, same LDS
-// contents, same K order: the same bits as the one-role kernel.
+// contents, same K order: the same bits as the one-role kernel.  Instantiated for the fp32 tiles (conv_igemm_f32.hip, tactic ws == 6: the tuner takes it on the
+// 80-wide detect-head layers, -8..-16 % there).  On the fp16 128-row tiles it was measured too: -3..-17 % on small maps alone, nothing on the three-context
+// bench line (profiles/r05_fp16_roles_*) - not instantiated there.
 template <int NFRAG, int BKT, int TPS, bool I8 = false, int MI = 2, int WN = 1, int NSTO = 0, bool PRE = false, int NW = 4, bool RS = false, bool UP = false,
           bool ONE = false, bool F32 = false, bool ROLES = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, unsigned in_bytes, unsigned w_bytes, const int m0, const int n0, int dbg_flags,

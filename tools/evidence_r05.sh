@@ -68,4 +68,6 @@ fi
 if [ $PART = harness ]; then
   timeout 200 tools/hip/bin/mfma_f32_rate 2>&1 | tee $E/mfma_f32_rate.txt
   timeout 200 tools/hip/bin/igemm_f32_anatomy 2>&1 | tee $E/igemm_f32_anatomy.txt
+  timeout 100 tools/hip/bin/igemm_f32_residency 2>&1 | tee $E/igemm_f32_residency.txt
+  timeout 100 tools/hip/bin/igemm_residency 2>&1 | tee $E/igemm_residency.txt
 fi
