@@ -76,7 +76,7 @@ def _kernel_duration_from_profile(model):
     try:
         calls, tot = 0, 0.0
         for line in open(os.path.join(ROOT, "profiles", name)):
-            if "conv_igemm" in line or "conv_ws" in line or "conv_gemm256" in line:
+            if "conv_igemm" in line or "conv_ws" in line or "conv_gemm256" in line or "conv_patch" in line:
                 m = re.search(r"\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
                 if m:
                     calls += int(m.group(1))
@@ -849,6 +849,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "rocprofv3_avg_launch_us": prof_us, "rocprofv3_frac_hbm": (alg_bytes / max(n_conv, 1) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if prof_us else None,
                 "rocprofv3_source": prof_src,
+                "rocprofv3_like_for_like": "single_context.roofline.avg_launch_us: the committed profile is of the ONE-context engine on one lane (its own tactic set), the figure above of the engine that produced `value`",
                 "arithmetic_intensity_flop_per_byte": intensity,
                 "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": tot_ms, "hbm_view": hbm_view, "mfma_view": mfma_view,
                 "tactics": tactic_summary,
