@@ -89,9 +89,13 @@ def test_a_lost_margin_fails_although_it_is_inside_the_ceiling(tmp_path, monkeyp
     hand-written ceiling (min IoU >= 0.99) and must still fail."""
     monkeypatch.setattr(parity, "RECORD", str(tmp_path / "m.jsonl"))
     monkeypatch.delenv("TRTX_PARITY_DRIFT", raising=False)
-    ok = dict(cls_logit_max_abs_err=0.07, box_ltrb_max_abs_err=0.018, matched_fraction=0.9991, min_iou=0.9970, max_conf_err=0.009)
+    band, ceil = parity.VALUES[("yolov8n_fp16_640", None)], parity.CEILINGS[("yolov8n_fp16_640", None)]
+    ok = dict(cls_logit_max_abs_err=0.6 * band["cls_logit_max_abs_err"], box_ltrb_max_abs_err=0.6 * band["box_ltrb_max_abs_err"], matched_fraction=0.9991, min_iou=0.9970,
+              max_conf_err=0.6 * band["max_conf_err"])
     parity.check("yolov8n_fp16_640", **ok)
+    lost_iou, lost_logit = band["min_iou"] - 2e-3, 1.05 * band["cls_logit_max_abs_err"]   # just outside the fitted band ...
+    assert lost_iou > ceil["min_iou"] and lost_logit < ceil["cls_logit_max_abs_err"]       # ... and well inside the hand-written tolerance
     with pytest.raises(AssertionError, match="PARITY DRIFT"):
-        parity.check("yolov8n_fp16_640", **dict(ok, min_iou=0.9935))
+        parity.check("yolov8n_fp16_640", **dict(ok, min_iou=lost_iou))
     with pytest.raises(AssertionError, match="PARITY DRIFT"):
-        parity.check("yolov8n_fp16_640", **dict(ok, cls_logit_max_abs_err=0.10))
+        parity.check("yolov8n_fp16_640", **dict(ok, cls_logit_max_abs_err=lost_logit))
