@@ -614,13 +614,13 @@ bool plain_gemm(const ConvArgs& a) {   // the ONE instantiation's condition (lau
 }
 // what the single-problem dispatch would run for this layer must be the plain 128-row / 32-wide-step main kernel
 bool group_member_ok(const ConvArgs& a) {
-    return conv_igemm_supported(a) && !a.in_i8 && !a.out_i8 && !a.res_i8 && !a.up_C && !a.scalar_out && a.CinK != 16 && a.bk == 32 && (a.bn == 64 || a.bn == 80) &&
+    return conv_igemm_supported(a) && (a.in_i8 || (!a.out_i8 && !a.res_i8)) && !a.up_C && !a.scalar_out && a.CinK != 16 && a.bk == 32 && (a.bn == 64 || a.bn == 80) &&
            (a.bm == 0 || a.bm == 128) && a.t_r3 == 0 && a.t_wsk != 2 && a.t_ws != 3 && (double)a.N * a.H * a.W * a.ld_in * 2.0 < 2.0e9;
 }
-template <int NFRAG, bool RS, bool ONE>
+template <int NFRAG, bool RS, bool ONE, bool I8 = false>
 void launch_group(const ConvGroupArgs& g, hipStream_t s) {
     const int dbg = options().conv_dbg;
-    TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g, dbg);
+    TRTX_LAUNCH((conv_igemm_group_f16_kernel<NFRAG, 32, RS, ONE, I8>), dim3(g.slot_start[g.n] * 8), dim3(256), 0, s, g, dbg);
 }
 }  // namespace
 
@@ -629,7 +629,9 @@ bool conv_igemm_group_supported(const ConvArgs* a, int n) {
     for (int k = 0; k < n; ++k) {
         if (!group_member_ok(a[k])) return false;
         if (a[k].t_ws != 1 && conv_ws_supported(a[k])) return false;   // that layer belongs to the weight-stationary kernel
-        if (a[k].bn != a[0].bn || (a[k].t_rs != 0) != (a[0].t_rs != 0) || plain_gemm(a[k]) != plain_gemm(a[0])) return false;
+        if (a[k].bn != a[0].bn || a[k].in_i8 != a[0].in_i8) return false;
+        // (int8 members all run the one int8 instantiation of the single-problem dispatch: LDS-DMA operands, the general K walk)
+        if (!a[0].in_i8 && ((a[k].t_rs != 0) != (a[0].t_rs != 0) || plain_gemm(a[k]) != plain_gemm(a[0]))) return false;
     }
     return true;
 }
@@ -668,7 +670,12 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     const bool rs = a[0].t_rs != 0;
     const bool one = plain_gemm(a[0]);
     const int nf = a[0].bn / 16;
-    if (nf == 4) {
+    if (a[0].in_i8) {
+        for (int k = 0; k < n; ++k)
+            if (!a[k].cscale) return TRTX_ERR_UNSUPPORTED;
+        if (nf == 4) launch_group<4, false, false, true>(g, s);
+        else launch_group<5, false, false, true>(g, s);
+    } else if (nf == 4) {
         if (one) rs ? launch_group<4, true, true>(g, s) : launch_group<4, false, true>(g, s);
         else rs ? launch_group<4, true, false>(g, s) : launch_group<4, false, false>(g, s);
     } else {

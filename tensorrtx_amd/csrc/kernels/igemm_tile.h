@@ -942,7 +942,7 @@ struct ConvGroupArgs {
     unsigned in_bytes[kMaxConvGroup], w_bytes[kMaxConvGroup];
     ConvArgs p[kMaxConvGroup];
 };
-template <int NFRAG, int BKT, bool RS, bool ONE>
+template <int NFRAG, int BKT, bool RS, bool ONE, bool I8 = false>   // I8 (round 5): int8 operands - the members of an INT8 plan's sibling layers
 __global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGroupArgs g, int dbg_flags) {
     __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<NFRAG, BKT, 2, 1, 0, 4, RS>()];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void conv_igemm_group_f16_kernel(const ConvGro
     const int tn = g.tiles_n[pid];
     const int m0 = (local / tn) * 128;
     const int n0 = (local % tn) * (16 * NFRAG);
-    conv_igemm_tile<NFRAG, BKT, 1, false, 2, 1, 0, false, 4, RS, false, ONE>(g.p[pid], g.in_bytes[pid], g.w_bytes[pid], m0, n0, dbg_flags, smem);
+    conv_igemm_tile<NFRAG, BKT, 1, I8, 2, 1, 0, false, 4, RS, false, ONE>(g.p[pid], g.in_bytes[pid], g.w_bytes[pid], m0, n0, dbg_flags, smem);
 }
 
 }  // namespace

@@ -193,7 +193,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
                     a.up_in = nullptr;
                     a.wgt = W + mo.w_off;
                     a.bias = reinterpret_cast<const float*>(W + mo.b_off);
-                    a.cscale = nullptr;
+                    a.cscale = a.in_i8 ? reinterpret_cast<const float*>(W + mo.s_off) : nullptr;
                     a.N = nb(plan.tensors[mo.in[0]]);
                     a.M = a.N * a.Ho * a.Wo;
                 }

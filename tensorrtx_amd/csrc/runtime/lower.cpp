@@ -1175,7 +1175,7 @@ struct Lowerer {
     // two groups is dropped) and every group's members are replaced by one op whose in / out are the unions.  Each member is computed
     // exactly as its own launch computes it: bit-identical outputs.  TRTX_GROUP_CONVS=0 keeps one launch per convolution (A/B, tests).
     void group_convs() {
-        if (dt != DT_F16 || net.int8 || CalibrationLowering::active()) return;
+        if (dt != DT_F16 || CalibrationLowering::active()) return;   // (INT8 plans group too since round 5: members of one storage mix - same in / out / shortcut int8 flags)
         bool mark_only = false;   // TRTX_GROUP_CONVS=0: one launch per convolution, but the would-be members keep the group's K order (t_wsk = 1): same bits
         if (!opt.group_convs) mark_only = true;
         const int n = (int)plan.ops.size();
@@ -1236,7 +1236,8 @@ struct Lowerer {
         auto same_layer_shape = [&](const POp& x, const POp& y) {
             const ConvArgs &a = x.conv, &b = y.conv;
             return a.kh == b.kh && a.kw == b.kw && a.stride_h == b.stride_h && a.stride_w == b.stride_w && a.pad_h == b.pad_h && a.pad_w == b.pad_w &&
-                   a.Cout == b.Cout && a.act1 == b.act1 && a.act2 == b.act2 && a.alpha1 == b.alpha1 && a.alpha2 == b.alpha2 && x.in.size() == y.in.size();
+                   a.Cout == b.Cout && a.act1 == b.act1 && a.act2 == b.act2 && a.alpha1 == b.alpha1 && a.alpha2 == b.alpha2 && x.in.size() == y.in.size() &&
+                   a.in_i8 == b.in_i8 && a.out_i8 == b.out_i8 && a.res_i8 == b.res_i8;
         };
         // height = longest dependency path from an op down to a sink: sibling branches that end in the same consumer (the three levels'
         // arms into the fused head op) put their corresponding layers at equal heights; a bottleneck of the neck that merely has the same

@@ -18,6 +18,18 @@ I8_CASES = [
 ]
 
 
+
+def _convs(low):
+    """every convolution of a lowered plan, the members of grouped launches included (INT8 plans group sibling layers since round 5)"""
+    out = []
+    for o in low["ops"]:
+        if o["kind"] == "conv":
+            out.append(o)
+        elif o["kind"] == "conv_group":
+            out.extend(o["members"])
+    return out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", I8_CASES)
 def test_conv_i8_mfma_vs_integer_reference(gpu, case):
@@ -108,8 +120,9 @@ def test_int8_build_from_cache_needs_no_gpu_and_marks_int8_convs():
         plan8 = engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=1, int8=1)
     assert engine.describe_plan(plan8)["int8"] is True
     low = engine.describe_plan(plan8, lowered=True)
-    convs = [o for o in low["ops"] if o["kind"] == "conv"]
-    assert sum(o["i8"][0] for o in convs) >= 55 and not convs[0]["i8"][0]          # everything behind the two Cin <= 16 layers
+    convs = _convs(low)
+    assert sum(o["i8"][0] for o in convs) >= 55 and not convs[0]["i8"][0]
+    assert sum(o["kind"] == "conv_group" for o in low["ops"]) == 6                  # the detect head's 18 int8 convolutions: six launches of three          # everything behind the two Cin <= 16 layers
     assert all(not o["i8"][1] for o in convs if low["ops"][-1]["in"].count(o["out"][0]))  # the detect head reads fp16
     assert low["arena_bytes"] < engine.describe_plan(plan16, lowered=True)["arena_bytes"]
     with pytest.raises(Exception):   # kINT8 without a calibrator / cache is a build error
@@ -209,7 +222,7 @@ def test_yolov8n_int8_detections_at_640(gpu):
         with calibrator.Calibrator(batches=batches, batch_size=B, algorithm=algo).installed():
             plans[algo] = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, int8=1)
         low = engine.describe_plan(plans[algo], lowered=True)
-        assert sum(o["i8"][0] for o in low["ops"] if o["kind"] == "conv") >= 55
+        assert sum(o["i8"][0] for o in _convs(low)) >= 55
     plan16 = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1)
     x = synth.images(B, S, S, seed=1)
     dec = {}
@@ -294,7 +307,7 @@ def test_retinaface_r50_int8_engine(gpu):
     with calibrator.Calibrator(cache=cal.written_cache).installed():      # the cache file rebuilds the same plan without a GPU pass
         assert engine.build_plan("retinaface_r50", path, batch=B, fp16=1, int8=1, h=H, w=W) == plan8
     low = engine.describe_plan(plan8, lowered=True)
-    convs = [o for o in low["ops"] if o["kind"] == "conv"]
+    convs = _convs(low)
     assert sum(o["i8"][0] for o in convs) >= 0.75 * len(convs)   # 64 of 82: the stem, the heads and the deconv stand-ins stay fp16
     with calibrator.Calibrator(batches=batches, batch_size=B, algorithm="minmax").installed():   # TensorRT's IInt8MinMaxCalibrator: nothing clipped
         plan8mm = engine.build_plan("retinaface_r50", path, batch=B, fp16=1, int8=1, h=H, w=W)
