@@ -390,7 +390,7 @@ void launch(const ConvArgs& a, unsigned in_bytes, unsigned w_bytes, hipStream_t 
             return;
         }
     }
-    if constexpr (TPS == 1 && !I8) {
+    if constexpr (TPS == 1) {   // (int8 too since round 5: the addressing and the operand path do not depend on what the 16 bytes hold)
         if (a.kh == 1 && a.kw == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Cin == a.CinK && a.Kpad == a.K) {
             if (rs_on)
                 TRTX_LAUNCH((conv_igemm_f16_kernel<NFRAG, BKT, TPS, I8, MI, 1, 0, false, 4, true, false, true>), dim3(plain ? total : chunk * 8), dim3(256), 0, s, a,
@@ -629,9 +629,7 @@ bool conv_igemm_group_supported(const ConvArgs* a, int n) {
     for (int k = 0; k < n; ++k) {
         if (!group_member_ok(a[k])) return false;
         if (a[k].t_ws != 1 && conv_ws_supported(a[k])) return false;   // that layer belongs to the weight-stationary kernel
-        if (a[k].bn != a[0].bn || a[k].in_i8 != a[0].in_i8) return false;
-        // (int8 members all run the one int8 instantiation of the single-problem dispatch: LDS-DMA operands, the general K walk)
-        if (!a[0].in_i8 && ((a[k].t_rs != 0) != (a[0].t_rs != 0) || plain_gemm(a[k]) != plain_gemm(a[0]))) return false;
+        if (a[k].bn != a[0].bn || a[k].in_i8 != a[0].in_i8 || (a[k].t_rs != 0) != (a[0].t_rs != 0) || plain_gemm(a[k]) != plain_gemm(a[0])) return false;
     }
     return true;
 }
@@ -673,8 +671,13 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     if (a[0].in_i8) {
         for (int k = 0; k < n; ++k)
             if (!a[k].cscale) return TRTX_ERR_UNSUPPORTED;
-        if (nf == 4) launch_group<4, false, false, true>(g, s);
-        else launch_group<5, false, false, true>(g, s);
+        if (nf == 4) {
+            if (one) rs ? launch_group<4, true, true, true>(g, s) : launch_group<4, false, true, true>(g, s);
+            else rs ? launch_group<4, true, false, true>(g, s) : launch_group<4, false, false, true>(g, s);
+        } else {
+            if (one) rs ? launch_group<5, true, true, true>(g, s) : launch_group<5, false, true, true>(g, s);
+            else rs ? launch_group<5, true, false, true>(g, s) : launch_group<5, false, false, true>(g, s);
+        }
     } else if (nf == 4) {
         if (one) rs ? launch_group<4, true, true>(g, s) : launch_group<4, false, true>(g, s);
         else rs ? launch_group<4, true, false>(g, s) : launch_group<4, false, false>(g, s);
