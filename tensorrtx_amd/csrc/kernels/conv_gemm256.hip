@@ -244,21 +244,25 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
         bias[j][0] = b4.x; bias[j][1] = b4.y; bias[j][2] = b4.z; bias[j][3] = b4.w;
     }
     const bool second = res || p.act2 != ACT_NONE;
+    half8 rvs[2][8];
+    auto fetch_shortcut = [&](int c) {
+        if (!res) return;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m0 + wm * 128 + c * 64 + it * 8 + (lane >> 3);
+            const int n = n0 + wn * 64 + (lane & 7) * 8;
+            const int mc = m < p.M ? m : p.M - 1, nc = n < p.Cout ? n : p.Cout - 8;
+            rvs[c][it] = *reinterpret_cast<const half8*>(res + (size_t)mc * p.ld_res + nc);
+        }
+    };
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         // the shortcut values of this 64-row chunk, ALL EIGHT fetched before anything waits for one (unconditional loads from clamped
         // rows): inside the store loop below each load sat in front of its use - 16 dependent HBM round trips per tile, a third of the
         // 512 -> 2048 GEMM's time (round 4: 780 us with them in the loop against 498-535 us for the harness without a shortcut)
-        half8 rvs[8];
-        if (res) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = m0 + wm * 128 + c * 64 + it * 8 + (lane >> 3);
-                const int n = n0 + wn * 64 + (lane & 7) * 8;
-                const int mc = m < p.M ? m : p.M - 1, nc = n < p.Cout ? n : p.Cout - 8;
-                rvs[it] = *reinterpret_cast<const half8*>(res + (size_t)mc * p.ld_res + nc);
-            }
-        }
+        // Round 5: the SECOND chunk's eight are fetched in front of the first chunk's stores too (fetch(1) below) - issued after them, the wait for the shortcut
+        // values was a wait for the stores' acknowledgements as well (tools/isa_store_waits.py: 4 of a wave's 16 stores stood behind a full vmcnt(0)).
+        if (c == 0) fetch_shortcut(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
                 }
                 *reinterpret_cast<half4*>(mine + (i * 16 + (lane & 15)) * EPS + (j * 16 + 4 * (lane >> 4)) * 2) = h;
             }
+        if (c == 0) fetch_shortcut(1);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + (lane >> 3);
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_f16_kernel(const ConvArgs p,
             if (m >= p.M || n >= p.Cout) continue;
             if (second) {
                 half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (res) rv = rvs[it];
+                if (res) rv = rvs[c][it];
                 if (p.act2 == ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = round_to_half((float)v[e] + (float)rv[e]);

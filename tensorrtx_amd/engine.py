@@ -19,6 +19,9 @@ def models_lib():
     if _MODELS is None:
         lib()  # libtrtx_hip first (rpath $ORIGIN resolves it too)
         p = os.path.join(_HERE, "lib", "libtrtx_models.so")
+        ab = os.environ.get("TRTX_HIP_LIB")   # an A/B build directory carries its own host builders (they resolve libtrtx_hip.so next to themselves)
+        if ab and os.path.exists(os.path.join(os.path.dirname(ab), "libtrtx_models.so")):
+            p = os.path.join(os.path.dirname(ab), "libtrtx_models.so")
         if not os.path.exists(p):
             raise ImportError(f"{p} is missing: run __graft_entry__.build()")
         _MODELS = ctypes.CDLL(p)
