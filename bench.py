@@ -412,6 +412,7 @@ def main():
                     help="int8: BuilderFlag::kINT8 engine (entropy calibration on 2 synthetic batches, int8 MFMA convs, fp16 fallback)")
     ap.add_argument("--contexts", type=int, default=3,
                     help="execution contexts kept in flight per GPU (each on its own stream; 1 = the reference's serial loop)")
+    ap.add_argument("--copy-priority", type=int, default=1, help="host-fed leg: 1 = the upload stream is a high-priority stream (default), 0 = a plain one")
     ap.add_argument("--upload-buffers", type=int, default=0,
                     help="host-fed leg: device frame buffers the uploads rotate through (0 = 2 x contexts + 2)")
     ap.add_argument("--repeats", type=int, default=7,
@@ -705,7 +706,7 @@ def main():
         frames = [as_frames(rng_imgs[0])] * n_up if dry else [as_frames(rng_imgs[s % len(rng_imgs)]) for s in range(n_up)]
         raw = [torch.empty((batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n_up)]
         net_in = [torch.empty((batch, 3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
-        copy_stream = tc.Stream()
+        copy_stream = tc.Stream(priority=-1 if args.copy_priority else 0)   # a high-priority stream gets a hardware queue of its own pool: the uploads do not queue behind a context's kernels
         uploaded = [tc.Event() for _ in range(n_up)]
         consumed = [tc.Event() for _ in range(n_up)]
 

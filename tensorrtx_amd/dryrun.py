@@ -24,6 +24,9 @@ class Event:
 class Stream:
     cuda_stream = 0
 
+    def __init__(self, priority=0):
+        self.priority = priority
+
     def wait_event(self, ev):
         pass
 
