@@ -268,6 +268,15 @@ int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, int Cin, in
                                 const int32_t* tile4, trtx_stream_t stream);
 int32_t trtx_op_conv2d_tactics_f32(int N, int H, int W, int Cin, int ld_in, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw,
                                    int has_residual, int ld_res, int32_t* out4, int32_t max_out);
+/* kINT8 convolution, single-kernel entries for the parity tests (what TensorRT runs for a layer of a USE_INT8 build, yolov8/include/config.h:1-3): KCRS fp32 weights ->
+ * int8 [cout_pad][kpad bytes] with per-output-channel symmetric scales (cink = Cin rounded up to 64 channels, kpad = kh*kw*cink; packed / wscale_out NULL: sizes only);
+ * the int8 MFMA convolution on NHWC int8 input: out int8 (out_is_i8, quantised with out_inv_scale) or fp16, cscale[cout_pad] = input scale x weight scale, optional
+ * int8 / fp16 shortcut. */
+int32_t trtx_conv_pack_weights_i8(const float* w_kcrs, int cout, int cin, int kh, int kw, const float* ch_scale, int8_t* packed, float* wscale_out,
+                                  int32_t* cout_pad_out, int32_t* kpad_out);
+int32_t trtx_op_conv2d_nhwc_i8(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked, const float* cscale, const float* bias, void* out,
+                               int out_is_i8, float out_inv_scale, int Cout, int ld_out, int kh, int kw, int sh, int sw, int ph, int pw, int act1,
+                               const void* residual, int res_is_i8, float res_scale, int ld_res, int act2, trtx_stream_t stream);
 int32_t trtx_op_poison_lds(void* device_word, trtx_stream_t stream); /* test support: NaN patterns into every CU's LDS */
 int32_t trtx_op_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int Cpad, int ld_out,
                                      trtx_stream_t stream);
