@@ -20,6 +20,12 @@
 //     the MFMA fragment reads (ds_read_b128) are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0);
 //   * consecutive workgroup ids are dealt round-robin to the 8 XCDs, so ids are remapped to give every XCD a contiguous
 //     range of output tiles (halo rows and the A tile shared by n-tiles stay in one L2): fabric reads 2.3x -> 1.0x.
+//
+// This header holds the DEVICE code (tile function, epilogues, the single-problem and the grouped kernel entry points) and is included by the three
+// translation units that instantiate it: conv_igemm.hip (fp16 and - I8 - int8 operands), conv_igemm_f32.hip (F32: fp32 operands on v_mfma_f32_16x16x4_f32,
+// round 5) and, through patch_tile.h, the resident-patch 3x3 kernels.  Template switches of conv_igemm_tile, all compile-time: NFRAG / MI tile width and
+// height, BKT / TPS k-step width and taps per step, I8 / F32 operand type, RS operands through registers instead of LDS-DMA, UP folded nearest upsample,
+// ONE plain-GEMM addressing, ROLES fetching + multiplying waves (instantiated for F32), WN / NW / NSTO / PRE wave grid, waves, stages, read-ahead.
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
