@@ -45,7 +45,7 @@ struct ConvArgs {
     // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
     int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
-    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 6 = (fp32 launches) fetching + multiplying wave roles; 3 = the resident-patch 3x3
+    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 6 = (fp32 launches) fetching + multiplying wave roles; 3 = the resident-patch 3x3; 7 = the resident-operand 3x3 kernel (conv_res.hip)
                 // kernel instead (conv_igemm.hip, builds with -DTRTX_EXPERIMENTAL_PATCH only)
     int t_rs;   // implicit-GEMM operands through registers (global -> VGPR -> ds_write) instead of LDS-DMA: 0 = no, 1 = yes (same bits)
     int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two
@@ -112,6 +112,12 @@ bool conv_igemm_f32_supported(const ConvArgs& a);
 int32_t conv_igemm_f32(const ConvArgs& a, hipStream_t s);
 int conv_tactics_f32(const ConvArgs& a, ConvTactic* out, int max_out);   // (bn, bm) pairs; out[0] = the untuned choice; every pair returns the same bits
 void conv_pack_weights_igemm_f32(const float* w_kcrs, int cout, int cin, int kh, int kw, int cink, int kpad, int cout_pad, const float* ch_scale, float* packed);
+// Resident-operand 3x3 stride-1 kernel (conv_res.hip, round 6; tactic ConvArgs::t_ws == 7): persistent workgroups keep the layer's whole weight slab in LDS, two
+// role-alternating halves of 4 waves (k-loop | register epilogue + next patch fetch); same packed weights, same K order, same bits as the main kernel.
+// a[0..n): 1..kMaxConvGroup independent layers of one instantiation in one launch (a workgroup is bound to one of them).
+bool conv_res_possible(const ConvArgs& a);
+bool conv_res_group_possible(const ConvArgs* a, int n);
+int32_t conv_res_f16(const ConvArgs* a, int n, hipStream_t s);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);

@@ -131,6 +131,11 @@ TACTIC_CASES = [
     (11, 57, 55, 2048, 512, 1, 1, 0, "none", False, "relu"),  # K = 2048 (res5's 2048 -> 512), odd tile count per XCD
     (11, 56, 56, 512, 512, 3, 1, 1, "relu", False, "none"),   # ... and its im2col form on a 3x3 (res5's 512 -> 512, K = 4608): borders, images, ragged last tile
     (140, 23, 21, 256, 256, 3, 1, 1, "silu", True, "none"),    # small maps: most rows touch a border, tiles straddle several images
+    # round 6: the resident-operand 3x3 kernel (conv_res.hip, ws == 7) joins for 32 -> 32, 64 -> 64, 64 -> 80: persistent workgroups with several tiles each
+    (32, 40, 40, 64, 64, 3, 1, 1, "silu", True, "relu"),      # 480 tiles on 240 workgroups: both halves busy, shortcut + second activation
+    (16, 80, 80, 64, 80, 3, 1, 1, "silu", False, "none"),     # Cout 80: the unpaired fifth fragment's 8-byte stores, 3-4 tiles per workgroup
+    (9, 83, 77, 32, 32, 3, 1, 1, "none", True, "none"),       # 16-row tiles, ragged in both directions, two workgroups per CU, shortcut without activation
+    (5, 13, 9, 64, 64, 3, 1, 1, "relu", False, "none"),       # fewer tiles than workgroup slots: one tile per workgroup, the second half idle
 ]
 
 
@@ -191,7 +196,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
             got = y.float().cpu()
             err = (got - ref).abs().max().item()
             assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"tactic {t}: max err {err} (scale {scale})"
-            if t[3] == 1 and t[4] in (1, 3) and t[5] == 0:  # plain implicit-GEMM tiles (ws 3: the resident-patch kernel of experimental builds walks K in the same order)
+            if t[3] == 1 and t[4] in (1, 3, 7) and t[5] == 0:  # plain implicit-GEMM tiles (ws 3 / 7: the resident-patch and the resident-operand 3x3 kernels walk K in the same order)
                 if exact is None:
                     exact = got
                 else:

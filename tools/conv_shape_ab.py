@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tensorrtx_amd import capi  # noqa: E402
 
-SHAPES = [(32, 80, 80, 64, 64), (32, 80, 80, 64, 80), (32, 80, 80, 80, 80), (32, 40, 40, 128, 64), (32, 40, 40, 64, 64), (32, 40, 40, 128, 128),
+SHAPES = [(32, 80, 80, 32, 32), (32, 20, 20, 64, 64), (32, 80, 80, 64, 64), (32, 80, 80, 64, 80), (32, 80, 80, 80, 80), (32, 40, 40, 128, 64), (32, 40, 40, 64, 64), (32, 40, 40, 128, 128),
           (32, 20, 20, 128, 128), (32, 20, 20, 256, 64), (32, 56, 56, 64, 64), (32, 28, 28, 128, 128)]
 REPS = 20
 
@@ -46,7 +46,7 @@ def one(N, H, W, Cin, Cout):
             if first is None:
                 first = got
             same = "identical to tactic 0" if torch.equal(got, first) else f"max |diff| to tactic 0 {float((got - first).abs().max()):.3g}"
-            kind = "patch" if t[4] == 3 else ("ws" if t[4] == 2 else ("wsk" if t[3] == 2 else "igemm"))
+            kind = "res3" if t[4] == 7 else "patch" if t[4] == 3 else ("ws" if t[4] == 2 else ("wsk" if t[3] == 2 else "igemm"))
             print(f"   {kind:6s} bn {t[0]:3d} bk {t[1]:2d} bm {t[2]:3d}   median {sorted(ts)[len(ts) // 2]:7.1f} us  min {min(ts):7.1f}   {same}")
     finally:
         capi.conv_force_tactic(None)
