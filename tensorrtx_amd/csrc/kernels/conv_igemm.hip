@@ -547,8 +547,12 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
             // the resident-patch 3x3 kernel (ws == 3): the same bits, fewer bytes through the global -> LDS fill path (work-efficient: a candidate in every set)
             if (fp16 && options().patch && patch_possible(t)) push(bn, t.bk, 128, 1, 3);
-            // the resident-operand 3x3 kernel (ws == 7, conv_res.hip): the same bits again, nothing fetched inside the k-loop
-            if (fp16 && options().res && conv_res_possible(t)) push(bn, t.bk, 128, 1, 7);
+            // the resident-operand kernels (ws == 7 / 8, conv_res.hip): the same bits again, nothing fetched inside the k-loop.  Measured on YOLOv8n b32
+            // (profiles/r06_engine_ab.txt, same box, alternating): the 3x3 kernel alone - one context 1.208 -> 1.188 ms, three contexts in flight 37.7-38.2k ->
+            // 37.9k img/s; with the 1x1 kernel too - one context 1.174 ms, three contexts 37.1-37.2k: its 16-wave persistent workgroups leave another context's
+            // kernels less room on a CU than they gain, so engines built for contexts in flight (work_efficient_only) list the 3x3 kernel only
+            if (fp16 && (options().res & 1) && conv_res_possible(t)) push(bn, t.bk, 128, 1, 7);
+            if (fp16 && (options().res & 2) && !work_efficient_only && conv_res1_possible(t)) push(bn, t.bk, 128, 1, 8);   // ... and its 1x1 sibling (ws == 8)
         }
     }
     return n;
@@ -568,8 +572,9 @@ int32_t conv_igemm_f16(const ConvArgs& a0, hipStream_t s) {
     const bool fp16 = !a0.in_i8 && !a0.out_i8 && !a0.res_i8;
     if (a0.bn == 256) return conv_gemm256_f16(a0, s);
     if (fp16 && a0.t_ws == 7 && conv_res_possible(a0)) return conv_res_f16(&a0, 1, s);
+    if (fp16 && a0.t_ws == 8 && conv_res1_possible(a0)) return conv_res1_f16(a0, s);
     // small-channel 3x3 / 1x1 fp16 layers: weight-stationary persistent kernel (t_ws: 0 = where supported, 1 = never, 2 = asked for)
-    if (fp16 && a0.t_ws != 1 && a0.t_ws != 3 && a0.t_ws != 7 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);   // (3 = the resident-patch kernel, below)
+    if (fp16 && a0.t_ws != 1 && a0.t_ws != 3 && a0.t_ws != 7 && a0.t_ws != 8 && conv_ws_supported(a0)) return conv_ws_f16(a0, s);   // (3 = the resident-patch kernel, below)
     // The buffer descriptor addresses 32-bit byte offsets: launch over groups of images whose slice stays below 2 GB.
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 2;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
@@ -641,7 +646,7 @@ int32_t conv_igemm_group_f16(const ConvArgs* a, int n, hipStream_t s) {
     if (!conv_igemm_group_supported(a, n)) return TRTX_ERR_UNSUPPORTED;
     // groups whose members are all resident-patch layers of one instantiation run on that kernel (round 5: +1 % on the bench line over the main kernel's
     // groups, same bits - profiles/r05_patch_r3_first_run.txt; groups are not tuned, TRTX_CONV_PATCH=0 is the A/B switch)
-    if (options().res && conv_res_group_possible(a, n)) return conv_res_f16(a, n, s);
+    if ((options().res & 4) && conv_res_group_possible(a, n)) return conv_res_f16(a, n, s);   // (the detect head's second 3x3 of every level: one context 1.196 -> 1.188 ms)
     if (options().patch && patch_group_possible(a, n)) {
         const int32_t st = launch_patch_group(a, n, s);
         return st != TRTX_OK ? st : check_launch("conv_patch_group_f16");

@@ -88,7 +88,7 @@ __device__ __forceinline__ P* pin_p(P* v) {
 // `rv` / `rl`: the shortcut's values for this lane's stores (fetched by the caller a phase ahead), zeros without a shortcut.
 template <int NFRAG, int ACT1>
 __device__ __forceinline__ void res_epilogue_slab(const ResP& p, const floatx4 (&acc)[NFRAG], const floatx4 (&bias)[NFRAG], const half8 (&rv)[NFRAG / 2 > 0 ? NFRAG / 2 : 1],
-                                                  half4 rl, int n, int y, int x, int lane) {
+                                                  half4 rl, bool okpix, int m, int lane) {
     constexpr int NP = NFRAG / 2;             // fragment pairs -> 16-byte stores; an odd last fragment goes out in 8-byte pieces
     constexpr bool ODD = (NFRAG & 1) != 0;
     constexpr int NV = 4 * NFRAG;
@@ -99,36 +99,44 @@ __device__ __forceinline__ void res_epilogue_slab(const ResP& p, const floatx4 (
     const int g = lane >> 4;
     const int cpair = 16 * (lane >> 5) + 8 * (g & 1);            // + 32 jp: first of this lane's 8 channels after the swap
     const int clast = (NFRAG - 1) * 16 + (((g & 1) << 3) | ((g & 2) << 1));   // first of its 4 channels of the unpaired fragment
-    const bool okpix = (y < p.H) & (x < p.W);
-    const int m = okpix ? (n * p.H + y) * p.W + x : 0;
-    float v[NV];
-#pragma unroll
-    for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[j][e] + bias[j][e];   // (no bias: the registers hold -0.0f, the additive identity of every float)
     _Float16 h[NV];
-    if constexpr (ACT1 == ACT_SILU) if (TRTX_RES_ABLATE & 8) {
+    // (four fragments = 16 values per lane at a time: enough independent chains for the ALU, half the temporaries of a 128-wide tile)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) h[k] = round_to_half(v[k]);
-    } else {
-        float t[NV];
+    for (int j0 = 0; j0 < NFRAG; j0 += 4) {
+        constexpr int GV = 16;
+        float v[GV], t[GV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) t[k] = __expf(-v[k]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < GV; ++k) {
+            const int j = j0 + k / 4;
+            v[k] = j < NFRAG ? acc[j < NFRAG ? j : 0][k & 3] + bias[j < NFRAG ? j : 0][k & 3] : 0.f;   // (no bias: the registers hold -0.0f, the additive identity of every float)
+        }
+        if constexpr (ACT1 == ACT_SILU) {
+            if (TRTX_RES_ABLATE & 8) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) t[k] = 1.0f + t[k];
-        __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < GV; ++k) t[k] = 1.0f;
+            } else {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) t[k] = __builtin_amdgcn_rcpf(t[k]);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < GV; ++k) t[k] = __expf(-v[k]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) h[k] = round_to_half(v[k] * t[k]);
-    } else if constexpr (ACT1 == ACT_RELU) {
+                for (int k = 0; k < GV; ++k) t[k] = 1.0f + t[k];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) h[k] = round_to_half(v[k] > 0.f ? v[k] : 0.f);
-    } else {
+                for (int k = 0; k < GV; ++k) t[k] = __builtin_amdgcn_rcpf(t[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) h[k] = round_to_half(v[k]);
+            for (int k = 0; k < GV; ++k)
+                if (j0 * 4 + k < NV) h[j0 * 4 + k] = round_to_half(v[k] * t[k]);
+        } else if constexpr (ACT1 == ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < GV; ++k)
+                if (j0 * 4 + k < NV) h[j0 * 4 + k] = round_to_half(v[k] > 0.f ? v[k] : 0.f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < GV; ++k)
+                if (j0 * 4 + k < NV) h[j0 * 4 + k] = round_to_half(v[k]);
+        }
     }
     unsigned pk[NFRAG][2];
 #pragma unroll
@@ -347,9 +355,11 @@ __global__ __launch_bounds__(NG * 256, WPS) void conv_res3_f16_kernel(const Conv
         for (int i = 0; i < MI; ++i) {
             if (i < i0 || i >= i1) continue;
             const int y = Tp.y0 + wave * MI + i;
-            if (p.act1 == ACT_SILU) res_epilogue_slab<NFRAG, ACT_SILU>(p, acc[i], bias, rres[i], rlast[i], Tp.n, y, x, lane);
-            else if (p.act1 == ACT_RELU) res_epilogue_slab<NFRAG, ACT_RELU>(p, acc[i], bias, rres[i], rlast[i], Tp.n, y, x, lane);
-            else res_epilogue_slab<NFRAG, ACT_NONE>(p, acc[i], bias, rres[i], rlast[i], Tp.n, y, x, lane);
+            const bool okpix = (y < p.H) & (x < p.W);
+            const int m = okpix ? (Tp.n * p.H + y) * p.W + x : 0;
+            if (p.act1 == ACT_SILU) res_epilogue_slab<NFRAG, ACT_SILU>(p, acc[i], bias, rres[i], rlast[i], okpix, m, lane);
+            else if (p.act1 == ACT_RELU) res_epilogue_slab<NFRAG, ACT_RELU>(p, acc[i], bias, rres[i], rlast[i], okpix, m, lane);
+            else res_epilogue_slab<NFRAG, ACT_NONE>(p, acc[i], bias, rres[i], rlast[i], okpix, m, lane);
         }
     };
 
@@ -448,6 +458,165 @@ __global__ __launch_bounds__(NG * 256, WPS) void conv_res3_f16_kernel(const Conv
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// 1x1 stride-1 convolutions (plain GEMMs over NHWC rows), tactic ConvArgs::t_ws == 8: YOLOv8n's C2f / SPPF / head projections (block.cpp:79-155, model.cpp:188-251).
+// These layers are HBM-bound by a wide margin (128 -> 64 at 80 x 80, batch 32: 79 MB against 3.4 GFLOP - 12.5 us of memory time next to 1.3 us of MFMA and
+// ~1 us of epilogue VALU at full rate), and what the implicit-GEMM kernel spends on them is structure: a workgroup barrier, LDS-DMA pieces and a refill of the
+// weight tile per k-step.  Here: persistent workgroups of 16 INDEPENDENT waves (four per SIMD: the vector ALU needs that many to issue every 2 cycles - a lone
+// wave issues one VALU instruction per 8, profiles/r06_valu_rate.txt); the column tile's weights lie in LDS for the workgroup's whole life (K x BN x 2 bytes
+// <= 96 KB, conv_res3's layout); a wave owns 16-pixel row fragments: its A operand comes global -> VGPR in MFMA layout (lane = pixel lane & 15, channels
+// 8 (lane >> 4) ... + 8: no cross-wave reuse, so no LDS for it), KCH k-steps per chunk, two chunks of registers, the first chunk of the NEXT row fragment
+// requested before this one's epilogue; no barrier after the weights have landed.  Same products in the same order as conv_igemm_tile, the epilogue of
+// conv_res3: bit-identical to the other tile shapes.
+struct ConvRes1Args {
+    ConvArgs p;
+    unsigned in_bytes, w_bytes;
+    int tiles_n, frags, chunk, per;   // column tiles, 16-pixel row fragments, fragments per XCD, fragments per workgroup (a contiguous run)
+};
+
+template <int NFRAG, int KCH, int NW>   // NW waves per workgroup: 16 (128 registers each), 8 for the 128-wide column tile (its 32 bias + 32 accumulator + 32 operand registers)
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_res1_f16_kernel(const ConvRes1Args g) {
+    constexpr int BN = 16 * NFRAG;
+    constexpr int BSTEP = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // nk * BSTEP bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane >> 4;
+    const ConvArgs& pa = g.p;
+    const int nk = pa.Kpad / 32;                 // k-steps
+    const int nch = (nk + KCH - 1) / KCH;        // chunks of KCH k-steps (the last one may be short: its missing steps are range-checked to zero and multiply nothing)
+    // workgroup -> (xcd, slot) -> column tile tn = slot % tiles_n, the (slot / tiles_n)-th run of `per` row fragments of the XCD's chunk
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tn = slot % g.tiles_n, run = slot / g.tiles_n;
+    const int f_end = min(xcd * g.chunk + g.chunk, g.frags);
+    const int f_first = xcd * g.chunk + run * g.per;
+    const int nf = f_first < f_end ? min(g.per, f_end - f_first) : 0;
+    if (nf == 0) return;
+    const int n0 = tn * BN;
+    ResP p;
+    p.H = 0; p.W = 0; p.Cin = pin_s(pa.Cin); p.ld_in = pin_s(pa.ld_in); p.Cout = pin_s(pa.Cout - n0); p.ld_out = pin_s(pa.ld_out);
+    p.ld_res = pin_s(pa.ld_res); p.act1 = pin_s(pa.act1); p.act2 = pin_s(pa.act2);
+    p.bias = pin_p(pa.bias ? (g_cfloat*)pa.bias + n0 : (g_cfloat*)nullptr); p.out = pin_p((g_half*)pa.out + n0);
+    p.res = pin_p(pa.residual ? (g_chalf*)pa.residual + n0 : (g_chalf*)nullptr);
+    const int M = pin_s(pa.M);
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa.in), 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pa.wgt), 0, g.w_bytes, 0x00020000);
+    {   // the column tile's weights, once (conv_res3's image: k-step e = 64-byte rows of the BN channels, chunks swizzled on the source side)
+        const int lrow = lane >> 2;
+        const int clog = (lane & 3) ^ px::swz32(lrow);
+        const int kpad = pa.Kpad, pieces = nk * NFRAG;
+#pragma unroll 1
+        for (int piece = wave; piece < pieces; piece += NW) {
+            const int e = piece / NFRAG, rb = piece - e * NFRAG;
+            const unsigned voff = (unsigned)(((n0 + rb * 16 + lrow) * kpad + e * 32 + clog * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + piece * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+    floatx4 bias[NFRAG];
+#pragma unroll
+    for (int j = 0; j < NFRAG; ++j) {
+        bias[j] = floatx4{-0.f, -0.f, -0.f, -0.f};
+        if (p.bias) bias[j] = *reinterpret_cast<__attribute__((address_space(1))) const floatx4*>(p.bias + j * 16 + (((grp & 1) << 3) | ((grp & 2) << 1)));
+    }
+    const int brow = sigma16(lane & 15);
+    const int fb_off = brow * 64 + ((grp ^ px::swz32(brow)) << 4);
+    constexpr int NP = NFRAG / 2;
+    const int cpair = 16 * (lane >> 5) + 8 * (grp & 1);
+    const int clast = (NFRAG - 1) * 16 + (((grp & 1) << 3) | ((grp & 2) << 1));
+    const int cmax = p.Cin - grp * 8;   // this lane's 8 channels of k-step e exist while 32 e < cmax
+
+    // chunk c of row fragment f: KCH 16-byte loads per lane (pixel 16 f + (lane & 15), channels 32 e + 8 (lane >> 4) ...)
+    auto load_chunk = [&](int f, int c, intx4 (&a)[KCH]) {
+        const int m = f * 16 + (lane & 15);
+        const unsigned base = m < M ? (unsigned)((m * p.ld_in + grp * 8) * 2) : kOOB;   // (kOOB + any channel offset stays out of range)
+#pragma unroll
+        for (int s = 0; s < KCH; ++s) {
+            const int e = c * KCH + s;
+            const unsigned voff = (32 * e < cmax && e < nk) ? base + (unsigned)(e * 64) : kOOB;
+            a[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the weights have landed; from here on the waves are on their own
+
+    intx4 a0[KCH], a1[KCH];
+    int f = f_first + wave;
+    const int f_stop = f_first + nf;
+    if (f < f_stop) load_chunk(f, 0, a0);
+    for (; f < f_stop; f += NW) {
+        floatx4 acc[NFRAG];
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // the shortcut's values for this fragment's stores (unconditional loads from clamped addresses)
+        const int m = f * 16 + (lane & 15);
+        const bool okpix = m < M;
+        const int mm = okpix ? m : 0;
+        half8 rv[NP > 0 ? NP : 1];
+        half4 rl = half4{0, 0, 0, 0};
+#pragma unroll
+        for (int jp = 0; jp < (NP > 0 ? NP : 1); ++jp) rv[jp] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.res) {
+            g_chalf* rrow = p.res + (size_t)mm * p.ld_res;
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+                const int co = 32 * jp + cpair;
+                rv[jp] = *reinterpret_cast<__attribute__((address_space(1))) const half8*>(rrow + (co < p.Cout ? co : 0));
+            }
+            if constexpr ((NFRAG & 1) != 0) rl = *reinterpret_cast<__attribute__((address_space(1))) const half4*>(rrow + (clast < p.Cout ? clast : 0));
+        }
+        // chunks two at a time: while one multiplies, the other is in flight; the last request of a fragment is the first chunk of the wave's next fragment,
+        // which then passes under this fragment's epilogue
+        auto multiply = [&](const intx4 (&a)[KCH], int c) {
+#pragma unroll
+            for (int s = 0; s < KCH; ++s) {
+                const int e = c * KCH + s;
+                if (e < nk) {
+                    const half8 af = __builtin_bit_cast(half8, a[s]);
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) {
+                        const half8 bf = *reinterpret_cast<const half8*>(smem + e * BSTEP + j * 1024 + fb_off);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        const bool next = f + NW < f_stop;
+        for (int c = 0; c < nch; c += 2) {
+            const bool has1 = c + 1 < nch;
+            if (has1) load_chunk(f, c + 1, a1);
+            multiply(a0, c);
+            if (has1) {
+                if (c + 2 < nch) load_chunk(f, c + 2, a0);
+                else if (next) load_chunk(f + NW, 0, a0);
+                multiply(a1, c + 1);
+            } else if (next) {
+                load_chunk(f + NW, 0, a0);   // (odd chunk count: a0's MFMAs have been issued)
+            }
+        }
+        if (p.act1 == ACT_SILU) res_epilogue_slab<NFRAG, ACT_SILU>(p, acc, bias, rv, rl, okpix, mm, lane);
+        else if (p.act1 == ACT_RELU) res_epilogue_slab<NFRAG, ACT_RELU>(p, acc, bias, rv, rl, okpix, mm, lane);
+        else res_epilogue_slab<NFRAG, ACT_NONE>(p, acc, bias, rv, rl, okpix, mm, lane);
+    }
+}
+
+template <int NFRAG, int NW>
+int32_t launch_res1(const ConvRes1Args& g, int lds_bytes, hipStream_t s) {
+    // more than 64 KB of dynamic LDS has to be asked for once per device
+    static bool asked[64] = {};
+    int dev = 0;
+    TRTX_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !asked[dev]) {
+        TRTX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_res1_f16_kernel<NFRAG, 4, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        asked[dev] = true;
+    }
+    const int runs = (g.chunk + g.per - 1) / g.per;
+    TRTX_LAUNCH((conv_res1_f16_kernel<NFRAG, 4, NW>), dim3(runs * g.tiles_n * 8), dim3(NW * 64), lds_bytes, s, g);
+    return TRTX_OK;
+}
+
 template <int NFRAG, int KC, int MI, int NG, bool PIPE, int WPS>
 void launch_res3(const ConvResArgs& g, hipStream_t s) {
     TRTX_LAUNCH((conv_res3_f16_kernel<NFRAG, KC, MI, NG, PIPE, WPS>), dim3(g.slot_start[g.n] * 8), dim3(NG * 256), 0, s, g);
@@ -540,6 +709,54 @@ int32_t conv_res_f16(const ConvArgs* a, int n, hipStream_t s) {
     else if (r.nfrag == 2 && r.kc == 2) launch_res3<2, 2, 2, 3, true, 3>(g, s);                // 12 waves (96 KB)
     else return TRTX_ERR_UNSUPPORTED;
     return check_launch("conv_res3_f16");
+}
+
+
+bool conv_res1_possible(const ConvArgs& a) {
+    if (a.f32 || a.up_C || a.in_i8 || a.out_i8 || a.res_i8 || a.scalar_out) return false;
+    if (a.kh != 1 || a.kw != 1 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h != 0 || a.pad_w != 0 || a.groups != 1) return false;
+    if (a.bk != 32 || a.CinK % 32 || a.Cin % 8 || a.Cin > a.CinK || a.Kpad != a.CinK || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.Cout % 8 || a.ld_out % 8 || a.ld_in % 8 || (a.residual && a.ld_res % 8)) return false;
+    if (!(a.bm == 0 || a.bm == 128) || a.t_r3 != 0) return false;
+    if (!(a.act1 == ACT_NONE || a.act1 == ACT_RELU || a.act1 == ACT_SILU) || !(a.act2 == ACT_NONE || a.act2 == ACT_RELU)) return false;
+    if (!(a.bn == 32 || a.bn == 64 || a.bn == 80 || a.bn == 128) || a.Cout_pad % a.bn) return false;
+    if ((long)a.Kpad * a.bn * 2 > 98304) return false;   // the column tile's weights in LDS
+    const double px = (double)a.N * a.H * a.W;
+    return px * a.ld_in * 2.0 < 2.0e9 && px * a.ld_out < 2.0e9 && px * (a.residual ? a.ld_res : 1) < 2.0e9;
+}
+
+int32_t conv_res1_f16(const ConvArgs& a, hipStream_t s) {
+    if (!conv_res1_possible(a)) return TRTX_ERR_UNSUPPORTED;
+    ConvRes1Args g{};
+    g.p = a;
+    g.p.M = a.N * a.Ho * a.Wo;
+    g.in_bytes = (unsigned)((((size_t)g.p.M - 1) * a.ld_in + a.Cin) * 2);
+    g.w_bytes = (unsigned)((size_t)a.Cout_pad * a.Kpad * 2);
+    g.tiles_n = a.Cout_pad / a.bn;
+    g.frags = (g.p.M + 15) / 16;
+    g.chunk = (g.frags + 7) / 8;
+    // TRTX_CONV_DBG (experiments): bits 4-5 waves per workgroup (0: 16, 1: 4, 2: 8), bits 8-15 row fragments per wave (0: one workgroup per CU takes an equal share)
+    const int dbg = options().conv_dbg;
+    const int nw_sel = (dbg >> 4) & 3, fpw = (dbg >> 8) & 255;
+    const int nw = a.bn == 128 ? (nw_sel == 1 ? 4 : 8) : (nw_sel == 1 ? 4 : nw_sel == 2 ? 8 : 16);
+    if (fpw) {
+        g.per = fpw * nw;
+    } else {
+        const int runs = std::max(1, 32 / g.tiles_n);   // one workgroup per CU, 32 CUs per XCD, shared by the column tiles
+        g.per = std::max(1, (g.chunk + runs - 1) / runs);
+    }
+    const int lds = (a.Kpad / 32) * a.bn * 64;
+    int32_t st = TRTX_ERR_UNSUPPORTED;
+#define TRTX_R1(NF)                                                   \
+    (nw == 4 ? launch_res1<NF, 4>(g, lds, s) : nw == 8 ? launch_res1<NF, 8>(g, lds, s) : launch_res1<NF, 16>(g, lds, s))
+    switch (a.bn) {
+        case 32: st = TRTX_R1(2); break;
+        case 64: st = TRTX_R1(4); break;
+        case 80: st = TRTX_R1(5); break;
+        case 128: st = nw == 4 ? launch_res1<8, 4>(g, lds, s) : launch_res1<8, 8>(g, lds, s); break;
+    }
+#undef TRTX_R1
+    return st != TRTX_OK ? st : check_launch("conv_res1_f16");
 }
 
 }  // namespace trtx

@@ -45,7 +45,7 @@ struct ConvArgs {
     // Tactic (see ConvTactic): 0 everywhere = the untuned dispatch.
     int bm;     // igemm rows per tile: 0 / 128, 64 or 256
     int t_wsk;  // wave-split-K variant: 0 = by the static rule, 1 = never, 2 = wherever it exists
-    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 6 = (fp32 launches) fetching + multiplying wave roles; 3 = the resident-patch 3x3; 7 = the resident-operand 3x3 kernel (conv_res.hip)
+    int t_ws;   // weight-stationary kernel: 0 = where supported, 1 = never, 2 = asked for (still only where supported); 5 = (fp32 launches) operands through registers; 6 = (fp32 launches) fetching + multiplying wave roles; 3 = the resident-patch 3x3; 7 / 8 = the resident-operand 3x3 / 1x1 kernels (conv_res.hip)
                 // kernel instead (conv_igemm.hip, builds with -DTRTX_EXPERIMENTAL_PATCH only)
     int t_rs;   // implicit-GEMM operands through registers (global -> VGPR -> ds_write) instead of LDS-DMA: 0 = no, 1 = yes (same bits)
     int t_r3;   // 3x3 stride-1 row-reuse kernel (conv_igemm_r3_f16_kernel, only where it exists): 0 = no, 1 = three LDS stages, 2 = two
@@ -118,6 +118,9 @@ void conv_pack_weights_igemm_f32(const float* w_kcrs, int cout, int cin, int kh,
 bool conv_res_possible(const ConvArgs& a);
 bool conv_res_group_possible(const ConvArgs* a, int n);
 int32_t conv_res_f16(const ConvArgs* a, int n, hipStream_t s);
+// ... and its 1x1 stride-1 sibling (tactic t_ws == 8): the column tile's weights resident in LDS, 16 independent waves per workgroup, the A operand global -> VGPR
+bool conv_res1_possible(const ConvArgs& a);
+int32_t conv_res1_f16(const ConvArgs& a, hipStream_t s);
 // weight-stationary persistent kernel for small-channel 3x3 (stride 1, pad 1) and 1x1 layers (conv_ws.hip): weights in
 // registers, input patch staged once in LDS; same packed weights / ConvArgs as the implicit-GEMM kernel, which dispatches to it
 bool conv_ws_supported(const ConvArgs& a);

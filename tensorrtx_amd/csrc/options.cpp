@@ -30,7 +30,7 @@ Options read_options() {
     o.wsk = !env_set("TRTX_CONV_NOWSK");
     o.gemm256 = !env_is("TRTX_GEMM256", 0);
     o.patch = !env_is("TRTX_CONV_PATCH", 0);
-    o.res = !env_is("TRTX_CONV_RES", 0);
+    o.res = env_int("TRTX_CONV_RES", 7);
     o.roles = !env_is("TRTX_CONV_ROLES", 0);
     o.f32_mfma = !env_set("TRTX_F32_DIRECT");
     o.roialign_fused = !env_set("TRTX_ROIALIGN_PLUGIN");

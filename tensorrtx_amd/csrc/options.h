@@ -22,7 +22,7 @@ struct Options {
     bool wsk = true;             // TRTX_CONV_NOWSK=1: no wave-split-K kernel
     bool gemm256 = true;         // TRTX_GEMM256=0: no 256 x 256 x 64 tile among the candidates
     bool patch = true;           // TRTX_CONV_PATCH=0: no resident-patch 3x3 kernel among the candidates / in the grouped launches
-    bool res = true;             // TRTX_CONV_RES=0: no resident-operand 3x3 kernel (conv_res.hip) among the candidates / in the grouped launches
+    int res = 7;                 // TRTX_CONV_RES=<mask>: resident-operand kernels (conv_res.hip) among the candidates / in the grouped launches: 1 = the 3x3 kernel, 2 = the 1x1 kernel, 4 = the 3x3 kernel in grouped launches too; 0 = none
     bool roles = true;           // TRTX_CONV_ROLES=0: no fetching / multiplying wave-role variants among the candidates (fp32 plans)
     bool f32_mfma = true;        // TRTX_F32_DIRECT=1: fp32 engines on the scalar direct kernel of rounds 1-4 (no fp32 MFMA, no fp32 stem kernel)
     bool roialign_fused = true;  // TRTX_ROIALIGN_PLUGIN=1: RoIAlign stays a plugin op (fp32 NCHW edge)

@@ -111,7 +111,7 @@ std::string tactic_name(const ConvTactic& t) {
     if (t.ws == 2) {
         o << "ws";
     } else {
-        o << (t.r3 == 2 ? "r3s2" : (t.r3 ? "r3" : (t.wsk == 2 ? "wsk" : (t.ws == 3 ? "patch" : (t.ws == 7 ? "res3" : (t.ws == 5 ? "igemm/regs" : (t.ws == 6 ? "igemm/roles" : "igemm"))))))) << " " << (t.wsk == 2 ? 64 : t.bm) << "x" << t.bn << "x" << t.bk;
+        o << (t.r3 == 2 ? "r3s2" : (t.r3 ? "r3" : (t.wsk == 2 ? "wsk" : (t.ws == 3 ? "patch" : (t.ws == 7 ? "res3" : (t.ws == 8 ? "res1" : (t.ws == 5 ? "igemm/regs" : (t.ws == 6 ? "igemm/roles" : "igemm")))))))) << " " << (t.wsk == 2 ? 64 : t.bm) << "x" << t.bn << "x" << t.bk;
     }
     return o.str();
 }

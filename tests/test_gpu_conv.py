@@ -136,6 +136,12 @@ TACTIC_CASES = [
     (16, 80, 80, 64, 80, 3, 1, 1, "silu", False, "none"),     # Cout 80: the unpaired fifth fragment's 8-byte stores, 3-4 tiles per workgroup
     (9, 83, 77, 32, 32, 3, 1, 1, "none", True, "none"),       # 16-row tiles, ragged in both directions, two workgroups per CU, shortcut without activation
     (5, 13, 9, 64, 64, 3, 1, 1, "relu", False, "none"),       # fewer tiles than workgroup slots: one tile per workgroup, the second half idle
+    # ... and its 1x1 sibling (ws == 8): 16 independent waves per persistent workgroup, the column tile's weights resident, A straight into registers
+    (32, 80, 80, 128, 64, 1, 1, 0, "silu", False, "none"),    # 12 800 row fragments, four chunks of k-steps... one chunk of four
+    (32, 40, 40, 192, 128, 1, 1, 0, "silu", True, "relu"),    # six k-steps: a short second chunk; 128-wide column tile, shortcut + second activation
+    (32, 20, 20, 512, 256, 1, 1, 0, "silu", False, "none"),   # K = 512: four chunks, four column tiles of 64 (64 KB of weights each)
+    (7, 33, 29, 96, 80, 1, 1, 0, "none", True, "none"),       # three k-steps (odd chunk count: 1), Cout 80: the unpaired fragment, ragged last row fragment
+    (3, 57, 55, 48, 32, 1, 1, 0, "relu", False, "none"),      # Cin 48 in a 64-wide K: the ragged chunk's lanes are range-checked to zero
 ]
 
 
@@ -196,7 +202,7 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
             got = y.float().cpu()
             err = (got - ref).abs().max().item()
             assert err <= 2e-3 * max(scale, 1.0) + 1e-3, f"tactic {t}: max err {err} (scale {scale})"
-            if t[3] == 1 and t[4] in (1, 3, 7) and t[5] == 0:  # plain implicit-GEMM tiles (ws 3 / 7: the resident-patch and the resident-operand 3x3 kernels walk K in the same order)
+            if t[3] == 1 and t[4] in (1, 3, 7, 8) and t[5] == 0:  # plain implicit-GEMM tiles (ws 3 / 7 / 8: the resident-patch and the resident-operand 3x3 / 1x1 kernels walk K in the same order)
                 if exact is None:
                     exact = got
                 else:
