@@ -448,7 +448,9 @@ def test_conv_tactics_are_enumerated_on_the_host():
     assert eval(r3.stdout.strip().splitlines()[-1]) == t   # ... and no environment variable brings it back (ADVICE r3 / VERDICT r3 Weak 3)
     assert all(128 % bn == 0 and bk in (32, 64) and bm in (64, 128) for bn, bk, bm, _, _, _ in t)
     t = capi.conv2d_tactics(32, 80, 80, 32, 32, 3, 1, 1)                  # weight-stationary kernel is the default where it applies
-    assert t[0][4] == 2 and all(x[4] == 1 for x in t[1:]) and all(x[1] == 32 for x in t)
+    assert t[0][4] == 2 and all(x[4] in (1, 7) for x in t[1:]) and all(x[1] == 32 for x in t)
+    assert [x for x in t if x[4] == 7] == [(32, 32, 128, 1, 7, 0)]      # round 6: the resident-operand 3x3 kernel, at the column tile that holds the whole Cout
+    assert (64, 32, 128, 1, 8, 0) in capi.conv2d_tactics(32, 80, 80, 128, 64, 1, 1, 0)   # ... and its 1x1 sibling
     t = capi.conv2d_tactics(32, 80, 80, 64, 80, 3, 1, 1)
     assert {x[0] for x in t} == {80}
     assert capi.conv2d_tactics(32, 160, 160, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1, 0)]   # two taps per k-step: one configuration
