@@ -2,7 +2,7 @@
 COMPILED ISA of every MFMA convolution kernel, because nothing in the language makes the compiler keep the property - round 3's row-reuse kernel lost it in
 its three-stage instantiations and returned different results under co-scheduling (profiles/r04_r3_bisect.txt, tools/isa_barrier_reads.py); that kernel left
 the tree in round 5, the property stays under test for everything that ships.
-hipcc cross-compiles gfx950 without a GPU; the five translation units compile side by side (the big one takes about a minute)."""
+hipcc cross-compiles gfx950 without a GPU; the six translation units compile side by side (the big one takes about a minute)."""
 import os
 import subprocess
 import sys
@@ -17,7 +17,7 @@ import isa_barrier_reads as scan  # noqa: E402
 
 CSRC = os.path.join(ROOT, "tensorrtx_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-UNITS = ["conv_igemm", "conv_igemm_f32", "conv_gemm256", "conv_ws", "conv_stem"]
+UNITS = ["conv_igemm", "conv_igemm_f32", "conv_gemm256", "conv_ws", "conv_stem", "conv_res"]
 
 SNIPPET = """
 	.amdhsa_kernel k_%s
