@@ -612,6 +612,8 @@ def main():
         if evs:
             trace["host_enqueue_returned_ms"] = [round(h, 3) for h in host]
             trace["device_step_done_ms"] = [round(evs[0].elapsed_time(evs[k + 1]), 3) for k in range(n_steps)]
+        if trace is not None:
+            trace["per_rank_ms_per_step"] = [round(v / n_steps * 1e3, 4) for v in replicas.gather_over_ranks(dt, dist, dev)]   # (every rank's own clock)
         return replicas.max_over_ranks(dt, dist, dev)
 
     def legs(slots, repeats, with_d2h=False, warmup=None):
@@ -628,7 +630,8 @@ def main():
             traces.append(tr)
         med = sorted(out)[len(out) // 2]
         worst = max(range(len(out)), key=lambda i: out[i])
-        return med, [round(o / args.steps * 1e3, 4) for o in out], dict(traces[worst], leg=worst)
+        med_i = min(range(len(out)), key=lambda i: abs(out[i] - med))
+        return med, [round(o / args.steps * 1e3, 4) for o in out], dict(traces[worst], leg=worst, per_rank_ms_per_step_median_leg=traces[med_i].get("per_rank_ms_per_step"))
 
     slots = make_slots(eng, n_ctx)
     # the single-context engine is built (and its tactics timed) BEFORE any timed leg, so that no timed leg is the first GPU work
@@ -649,6 +652,7 @@ def main():
     tc.synchronize()
     settle_steps = k
     dt, value_legs, value_trace = legs(slots, args.repeats)
+    affinity_all = replicas.gather_notes(affinity_note, dist)   # every rank's pinning report (a mis-pinned straggler would otherwise be invisible)
     detections = None
     if cfg["nms"]:
         tc.synchronize()
@@ -859,6 +863,69 @@ def main():
                                    "whole_step_hbm_view.frac"),
                 "whole_step_hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": alg_bytes / (dt / args.steps) / 1e9,
                                         "frac": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}}
+    # ---- the plugin path on the roofline ("decode / NMS / top-k / RoIAlign / reformat -> HBM bandwidth").  Every launch of
+    # the step that is NOT a convolution: algorithmic bytes (what the lowering pass states for the op: its inputs + outputs once, at this batch), the interval
+    # between the stream events around the op in the same serialized profile passes as above, GB/s, fraction of the HBM peak.  Ops of a few hundred KB
+    # are latency, not bandwidth: their rows say so.  The GPU NMS (outside the engine: trtx_yolo_nms on the decode buffer) is timed the same way.
+    DT_SIZE = {0: 4, 1: 2, 2: 1}
+    tens = {t["id"]: t for t in low.get("tensors", [])}
+
+    def op_bytes(o):
+        if o.get("bytes", 0) > 0:
+            return o["bytes"] * batch
+        tot = 0.0
+        for tid in list(o.get("in", [])) + list(o.get("out", [])):
+            t = tens.get(tid)
+            if t:
+                tot += float(np.prod(t["dims"])) * DT_SIZE.get(t.get("dtype", 0), 4) * batch
+        return tot
+
+    plugins = []
+    if rows and len(rows) == len(low["ops"]):
+        acc = {}
+        for r, o in zip(rows, low["ops"]):
+            if (o["kind"] == "conv" and o.get("igemm")) or o["kind"] == "conv_group":
+                continue
+            key = o["kind"] if o["kind"] != "plugin" else "plugin:" + o.get("name", "")[:40]
+            a = acc.setdefault(key, {"op": key, "launches_per_step": 0, "bytes": 0.0, "us": 0.0})
+            a["launches_per_step"] += 1
+            a["bytes"] += op_bytes(o)
+            a["us"] += r["ms"] * 1e3
+        for a in acc.values():
+            gbps = a["bytes"] / (a["us"] * 1e-6) / 1e9 if a["us"] > 0 else 0.0
+            plugins.append({"op": a["op"], "launches_per_step": a["launches_per_step"], "algorithmic_bytes_per_step": a["bytes"], "us_per_step": round(a["us"], 2),
+                            "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4),
+                            "bound": "hbm" if a["bytes"] / max(a["launches_per_step"], 1) > 8e6 else "latency (under 8 MB per launch: the ~6 us floor of a launch is more than its bytes)"})
+    if cfg["nms"] and not dry:
+        sl0 = slots[0]
+        sl0.run(inputs[0])
+        tc.synchronize()
+        cnt = sl0.keep_cnt.cpu().numpy()
+        n_cand = sl0.out[:, 0].cpu().numpy().clip(0, 1000)
+        ev = [tc.Event(enable_timing=True) for _ in range(2)]
+        nms_us = []
+        for _ in range(7):
+            with tc.stream(sl0.stream):
+                ev[0].record()
+            capi.check(L.trtx_yolo_nms(capi._p(sl0.out), batch, 1000, ctypes.c_float(0.5), ctypes.c_float(0.45), capi._p(sl0.keep_idx), capi._p(sl0.keep_cnt),
+                                       capi._p(sl0.keep_det), capi._p(sl0.ws), ctypes.c_size_t(sl0.ws_bytes), sl0.stream_p), "trtx_yolo_nms")
+            with tc.stream(sl0.stream):
+                ev[1].record()
+            tc.synchronize()
+            nms_us.append(ev[0].elapsed_time(ev[1]) * 1e3)
+        nms_b = float(n_cand.sum()) * 24.0 + float(cnt.sum()) * 28.0 + batch * 8.0   # 6 floats read per candidate, index + 6 floats written per kept box, the counts
+        us = sorted(nms_us)[len(nms_us) // 2]
+        plugins.append({"op": "trtx_yolo_nms (yolo_nms_sort + yolo_nms_mask + yolo_nms_scan, after the engine)", "launches_per_step": 3, "algorithmic_bytes_per_step": nms_b,
+                        "us_per_step": round(us, 2), "GBps": round(nms_b / (us * 1e-6) / 1e9, 2), "frac_hbm": round(nms_b / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 6),
+                        "candidates_per_image": float(n_cand.mean()), "kept_per_image": float(cnt.mean()),
+                        "bound": "latency: three dependent one-workgroup-per-image phases (1024-wide bitonic sort 15 us of it, profiles/r06_nms_fused_ab.txt)"})
+    roofline["plugins"] = plugins
+    roofline["plugins_note"] = ("every non-convolution launch of the step, same serialized profile passes (stream events around the op); per-kernel rocprofv3 durations of the same "
+                                "command: profiles/r06_kernel_stats_*_1ctx_lanes1.txt")
+    # the three fractions side by side: every conv launch alone (serialized), the one-context engine's, the whole timed step's
+    roofline["frac_serialized_kernels"] = roofline["frac"]
+    roofline["frac_whole_step_hbm"] = roofline["whole_step_hbm_view"]["frac"]
+    roofline["frac_single_context_hbm"] = (alg_bytes / (single_prof[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if single_prof else None
     res = {
         "metric": f"images/sec @ batch={cfg['batch']} {W}x{H} {args.precision} ({args.config}" + (" conv backbone + YoloLayer decode + NMS)" if cfg["nms"] else ", IExecutionContext::enqueue)"),
         "value": (global_batch if mode == "strong" else world * batch) * args.steps / dt, "unit": "images/sec", "n_gpus": world,
@@ -875,7 +942,8 @@ def main():
                                f", {len(inputs)} rotating input batches resident in HBM",
                    "contexts": n_ctx,
                    "global_batch": global_batch, "parallelism": f"replica-per-GPU x{world} (image-sharded, no data-path collective; RCCL only brackets the timed region)",
-                   "weights": "seeded synthetic .wts (no trained weights offline)", "cpu_affinity_rank0": affinity_note},
+                   "weights": "seeded synthetic .wts (no trained weights offline)", "cpu_affinity_rank0": affinity_note, "cpu_affinity_per_rank": affinity_all},
+        "per_rank_ms_per_step": value_trace.get("per_rank_ms_per_step_median_leg"),
         "roofline": roofline,
     }
     if dt_single is not None:

@@ -35,6 +35,26 @@ def max_over_ranks(seconds: float, dist, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(seconds: float, dist, device=None):
+    """Every rank's own figure, in rank order (a straggler is invisible in the max alone)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [seconds]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def gather_notes(note: str, dist):
+    """Every rank's short text note (CPU affinity report), in rank order."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [note]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, note)
+    return out
+
+
 def gather_counts(local_counts, dist):
     """Optional batch-splitter epilogue: all ranks learn every image's kept-detection count
     (fixed-size, a few bytes per image — bandwidth-trivial next to 7x153 GB/s of xGMI)."""
