@@ -630,7 +630,7 @@ ResShape res_shape(const ConvArgs& a) {
     ResShape r{0, 0, 0, 0};
     if (a.CinK % 32 || a.bn % 16 || a.bn != a.Cout_pad) return r;
     const int kc = a.CinK / 32, nf = a.bn / 16;
-    if (kc == 1 && nf == 2) r = (a.H >= 16 && !(options().conv_dbg & 1)) ? ResShape{2, 1, 4, 1} : ResShape{2, 1, 2, 2};
+    if (kc == 1 && nf == 2) r = a.H >= 16 ? ResShape{2, 1, 4, 1} : ResShape{2, 1, 2, 2};
     else if (kc == 2 && nf == 4) r = ResShape{4, 2, 2, 1};
     else if (kc == 2 && nf == 5) r = ResShape{5, 2, 2, 1};
     else if (kc == 1 && nf == 4) r = ResShape{4, 1, 2, 1};
@@ -735,27 +735,21 @@ int32_t conv_res1_f16(const ConvArgs& a, hipStream_t s) {
     g.tiles_n = a.Cout_pad / a.bn;
     g.frags = (g.p.M + 15) / 16;
     g.chunk = (g.frags + 7) / 8;
-    // TRTX_CONV_DBG (experiments): bits 4-5 waves per workgroup (0: 16, 1: 4, 2: 8), bits 8-15 row fragments per wave (0: one workgroup per CU takes an equal share)
-    const int dbg = options().conv_dbg;
-    const int nw_sel = (dbg >> 4) & 3, fpw = (dbg >> 8) & 255;
-    const int nw = a.bn == 128 ? (nw_sel == 1 ? 4 : 8) : (nw_sel == 1 ? 4 : nw_sel == 2 ? 8 : 16);
-    if (fpw) {
-        g.per = fpw * nw;
-    } else {
-        const int runs = std::max(1, 32 / g.tiles_n);   // one workgroup per CU, 32 CUs per XCD, shared by the column tiles
-        g.per = std::max(1, (g.chunk + runs - 1) / runs);
-    }
+    // Launch geometry: one persistent workgroup per CU takes an equal, contiguous share of its XCD's row fragments.  (Measured on YOLOv8n b32 against
+    // 4- / 8- / 16-wave workgroups of 4-16 fragments per wave - a grid the hardware balances: every variant within the run-to-run spread of three contexts in
+    // flight, the persistent form the fastest single context: profiles/r06_engine_ab.txt, block v1.)
+    const int nw = a.bn == 128 ? 8 : 16;
+    const int runs = std::max(1, 32 / g.tiles_n);   // 32 CUs per XCD, shared by the column tiles
+    g.per = std::max(1, (g.chunk + runs - 1) / runs);
     const int lds = (a.Kpad / 32) * a.bn * 64;
     int32_t st = TRTX_ERR_UNSUPPORTED;
-#define TRTX_R1(NF)                                                   \
-    (nw == 4 ? launch_res1<NF, 4>(g, lds, s) : nw == 8 ? launch_res1<NF, 8>(g, lds, s) : launch_res1<NF, 16>(g, lds, s))
+    (void)nw;
     switch (a.bn) {
-        case 32: st = TRTX_R1(2); break;
-        case 64: st = TRTX_R1(4); break;
-        case 80: st = TRTX_R1(5); break;
-        case 128: st = nw == 4 ? launch_res1<8, 4>(g, lds, s) : launch_res1<8, 8>(g, lds, s); break;
+        case 32: st = launch_res1<2, 16>(g, lds, s); break;
+        case 64: st = launch_res1<4, 16>(g, lds, s); break;
+        case 80: st = launch_res1<5, 16>(g, lds, s); break;
+        case 128: st = launch_res1<8, 8>(g, lds, s); break;
     }
-#undef TRTX_R1
     return st != TRTX_OK ? st : check_launch("conv_res1_f16");
 }
 

@@ -9,6 +9,7 @@
 #include "calibrator.h"
 #include "common.h"
 #include "models.h"
+#include "options.h"
 
 using namespace nvinfer1;
 
@@ -28,7 +29,7 @@ static int geti(const std::map<std::string, std::string>& m, const char* k, int 
 }
 
 // calibrator used by builds with int8=1: a C v-table supplied by the caller (tests / Python tools), or, when none is set,
-// the reference-style directory calibrator over $TRTX_CALIB_DIR (*.ppm) with the cache file $TRTX_CALIB_TABLE
+// the reference-style directory calibrator over the calibration directory (*.ppm) and cache file of host/options.h (calib_dir= / calib_table= or the environment)
 static trtx_calibrator_vtbl g_calib{};
 static bool g_have_calib = false;
 extern "C" void trtx_host_set_calibrator(const trtx_calibrator_vtbl* v) {
@@ -49,11 +50,10 @@ extern "C" int32_t trtx_host_build(const char* model, const char* wts_path, cons
         if (g_have_calib) {
             calibrator.reset(new trtx_host::CallbackCalibrator(g_calib));
         } else {
-            const char* dir = std::getenv("TRTX_CALIB_DIR");
-            const char* table = std::getenv("TRTX_CALIB_TABLE");
+            const trtx_host::HostOptions ho = trtx_host::read_host_options(o);   // calibration directory / cache: option string, else environment (host/options.h)
             const std::string m0(model);
-            calibrator.reset(new trtx_host::Int8EntropyCalibrator2(geti(o, "calib_batch", 1), geti(o, "w", 640), geti(o, "h", 640), dir ? dir : "./coco_calib/",
-                                                                   table ? table : "int8calib.table", m0 == "yolov8n" ? "images" : "data"));
+            calibrator.reset(new trtx_host::Int8EntropyCalibrator2(geti(o, "calib_batch", 1), geti(o, "w", 640), geti(o, "h", 640), ho.calib_dir.c_str(),
+                                                                   ho.calib_table.c_str(), m0 == "yolov8n" ? "images" : "data"));
         }
         config->setInt8Calibrator(calibrator.get());
     }
