@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/${1:-r06_engine_ab}; mkdir -p $O; cd $R
 timeout 900 python -m pytest tests/test_gpu_engine.py tests/test_gpu_multi_context.py tests/test_gpu_tactics.py -m gpu -q -x -k "not fp32 and not rcnn and not retina and not resnet" 2>&1 | tail -8 | tee $O/pytest_engine.txt
 for rep in 1 2; do
-  for res in 3 0 7; do
+  for res in 7 0; do
     TRTX_CONV_RES=$res TRTX_TUNE_VERBOSE=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-tolerance-engine > $O/bench_res${res}_$rep.json 2> $O/bench_res${res}_$rep.err
     python - <<PY
 import json
