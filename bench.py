@@ -76,7 +76,7 @@ def _kernel_duration_from_profile(model):
     try:
         calls, tot = 0, 0.0
         for line in open(os.path.join(ROOT, "profiles", name)):
-            if "conv_igemm" in line or "conv_ws" in line or "conv_gemm256" in line or "conv_patch" in line:
+            if "conv_igemm" in line or "conv_ws" in line or "conv_gemm256" in line or "conv_patch" in line or "conv_res" in line:
                 m = re.search(r"\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
                 if m:
                     calls += int(m.group(1))
@@ -842,7 +842,7 @@ def main():
     bound = "hbm" if intensity < MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS else "mfma"
     traffic, traffic_src = _traffic_from_profile(args.config)
     prof_us, prof_src = _kernel_duration_from_profile(args.config) if args.precision == "fp16" else (None, None)
-    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_igemm_f16 / conv_igemm_group_f16 / conv_ws_f16 / conv_patch_f16 / conv_gemm256_f16 / conv_igemm_wsk_f16, all instantiations)",
+    roofline = {"bound": bound, "kernel": "fused MFMA convolution kernels (conv_igemm_f16 / conv_igemm_group_f16 / conv_ws_f16 / conv_patch_f16 / conv_res3_f16 / conv_res1_f16 / conv_gemm256_f16 / conv_igemm_wsk_f16, all instantiations)",
                 "launches_per_step": n_conv, "grouped_launches": n_group, "convolutions_inside_groups": convs_in_groups,
                 "bytes_priced": "algorithmic: fp16 activations in + out (+ residual) of every launch + its weights once", "avg_launch_us": avg_launch_s * 1e6,
                 "timing": ("dispatch begin -> end of every conv launch (HIP events attached to the launch, hipExtLaunchKernelGGL), mean of 5 serialized profile passes"
