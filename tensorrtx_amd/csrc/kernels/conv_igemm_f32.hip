@@ -222,6 +222,8 @@ bool conv_igemm_f32_supported(const ConvArgs& a) {
     if ((double)a.H * a.W * a.ld_in * 4.0 >= 2.0e9 || (double)a.Cout_pad * a.Kpad * 4.0 >= 2.0e9) return false;
     if (a.bn || a.bm) {   // a tactic was named
         const int bm = a.bm ? a.bm : 128;
+        if (a.t_ws == 7) return a.bn && conv_res_possible(a);    // the resident-operand kernels (conv_res.hip) have their own shape tables
+        if (a.t_ws == 8) return a.bn && conv_res1_possible(a);
         if (!a.bn || a.Cout_pad % a.bn || !tile_exists(a, a.bn, bm)) return false;
         if (a.t_ws == 5 && (!rs_exists(a, a.bn, bm) || a.bk != 16)) return false;
         if (a.t_ws == 6 && (!roles_exist(a, a.bn, bm) || a.bk != 16)) return false;
@@ -255,6 +257,19 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
             push(bn, 128, 3);
             break;
         }
+    // the resident-operand 3x3 kernel (conv_res.hip, round 6; ws == 7): weights of a column tile resident in LDS, role-rotating wave groups - the same bits
+    if (options().res & 1)
+        for (int bn : bns) {
+            ConvArgs t = a;
+            t.bn = bn; t.bm = 128; t.t_ws = 7;
+            if (a.Cout_pad % bn == 0 && conv_res_possible(t)) push(bn, 128, 7);
+        }
+    if (options().res & 2)   // ... and its 1x1 form (ws == 8)
+        for (int bn : bns) {
+            ConvArgs t = a;
+            t.bn = bn; t.bm = 128; t.t_ws = 8;
+            if (a.Cout_pad % bn == 0 && conv_res1_possible(t)) push(bn, 128, 8);
+        }
     for (int bn : bns) {
         if (a.Cout_pad % bn) continue;
         if (bn <= 32 && a.Cout_pad > 2 * bn) continue;
@@ -271,6 +286,8 @@ int conv_tactics_f32(const ConvArgs& a0, ConvTactic* out, int max_out) {
 
 int32_t conv_igemm_f32(const ConvArgs& a0, hipStream_t s) {
     if (!conv_igemm_f32_supported(a0)) return TRTX_ERR_UNSUPPORTED;
+    if (a0.t_ws == 7 && a0.bn) return conv_res_f16(&a0, 1, s);   // (whole batch in one launch: its slice stays below 2 GB by conv_res_possible)
+    if (a0.t_ws == 8 && a0.bn) return conv_res1_f16(a0, s);
     const size_t img_in = (size_t)a0.H * a0.W * a0.ld_in * 4;
     const int per = (int)std::max<size_t>(1, (size_t)2000000000 / img_in);
     const unsigned w_bytes = (unsigned)((size_t)a0.Cout_pad * a0.Kpad * 4);

@@ -49,6 +49,10 @@ CASES = [
     (2, 40, 40, 32, 32, 3, 1, 1, "silu", False, "none"),     # resident patch: two planes of a 16-row patch
     (1, 20, 20, 128, 64, 3, 1, 1, "silu", False, "none"),    # resident patch: eight planes (one workgroup per CU)
     (1, 20, 20, 128, 128, 3, 1, 1, "silu", True, "none"),    # ... two 64-wide column tiles over one patch; wave roles at 128 columns
+    (16, 80, 80, 32, 32, 3, 1, 1, "silu", True, "none"),     # round 6, the resident-operand kernel with fp32 operands: several tiles per persistent workgroup, shortcut
+    (9, 43, 37, 64, 64, 3, 1, 1, "leaky", False, "relu"),    # ... 64 -> 64 as 2 x 32 and as 4 x 16 columns (column tiles bound to workgroups), ragged map, slow activation
+    (16, 40, 40, 128, 64, 1, 1, 0, "silu", True, "none"),    # ... its 1x1 form: two chunks of four k-steps, many row fragments per wave, shortcut
+    (3, 33, 31, 48, 80, 1, 1, 0, "leaky", False, "none"),    # ... a short chunk (three k-steps), five column fragments, ragged M, slow activation
 ]
 
 
@@ -85,6 +89,10 @@ def test_conv_f32_mfma_vs_torch_and_every_tile_shape_is_the_same_bits(gpu, case)
     kinds = {t[2] for t in tiles}
     if k == 3 and s == 1 and p == 1 and Cin % 16 == 0 and Cin // 16 in (1, 2, 3, 4, 5, 8) and Cout % 4 == 0:
         assert 3 in kinds, "the resident-patch kernel is a candidate for every 3x3 stride-1 layer it can take"
+    if k == 3 and s == 1 and p == 1 and Cin in (16, 32, 64, 80) and Cout % 4 == 0:
+        assert 7 in kinds, "the resident-operand 3x3 kernel (conv_res.hip, fp32 operands) is a candidate for the 16- to 80-channel 3x3 stride-1 layers"
+    if k == 1 and s == 1 and Cin % 16 == 0 and Cout % 4 == 0 and Cin * 16 * 4 <= 98304:
+        assert 8 in kinds, "the resident-weights 1x1 kernel (conv_res.hip, fp32 operands) is a candidate for every 1x1 layer whose narrowest column tile fits LDS"
     if Cin > 8 and ((Cout + 15) // 16 * 16) % 32 == 0:
         assert 6 in kinds and 5 in kinds, "wave roles / register-staged operands are candidates wherever a 32-wide column tile exists"
     for t in tiles[1:]:

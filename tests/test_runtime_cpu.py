@@ -460,22 +460,29 @@ def test_conv_tactics_are_enumerated_on_the_host():
 
 def test_fp32_conv_tactics_are_enumerated_on_the_host():
     """conv_tactics_f32 (kernels/conv_igemm_f32.hip; what the tuner times for a plan built without kFP16): (bn, bm, operand path, channels per k-step);
-    operand path 1 = LDS-DMA, 3 = resident patch, 5 = through registers, 6 = fetching / multiplying wave roles.  Every entry returns the same bits."""
+    operand path 1 = LDS-DMA, 3 = resident patch, 5 = through registers, 6 = fetching / multiplying wave roles, 7 / 8 = the resident-operand kernels of
+    conv_res.hip (3x3 / 1x1, round 6).  Every entry returns the same bits."""
     import subprocess
     import sys
     from tensorrtx_amd import capi
     t = capi.conv2d_tactics_f32(32, 80, 80, 64, 64, 3, 1, 1)
     assert len(set(t)) == len(t) and t[0][2] == 1 and t[0][3] == 16                   # the launcher's own choice: LDS-DMA, 16-channel steps
-    assert {x[2] for x in t} == {1, 3, 5, 6}
+    assert {x[2] for x in t} == {1, 3, 5, 6, 7}
+    assert sorted(x for x in t if x[2] == 7) == [(16, 128, 7, 16), (32, 128, 7, 16)]   # resident operands: 64 -> 64 as 4 x 16 or 2 x 32 columns (LDS)
     assert [x for x in t if x[2] == 3] == [(64, 128, 3, 16)]                           # one resident-patch entry, at the widest column tile
     assert any(x[3] == 32 for x in t) and all(x[3] == 16 for x in t if x[2] != 1)      # 32-channel steps exist for the LDS-DMA path only
     assert all(64 % x[0] == 0 and x[1] in (64, 128, 256) for x in t)
+    t1 = capi.conv2d_tactics_f32(32, 80, 80, 128, 64, 1, 1, 0)
+    assert sorted(x[0] for x in t1 if x[2] == 8) == [16, 32, 64] and not any(x[2] in (3, 7) for x in t1)   # the 1x1 form: every column tile whose weights fit
     assert not any(x[2] == 3 for x in capi.conv2d_tactics_f32(32, 40, 40, 64, 64, 3, 2, 1))      # stride 2: no resident patch
     assert not any(x[2] == 3 for x in capi.conv2d_tactics_f32(32, 20, 20, 256, 64, 3, 1, 1))     # 256 input channels: sixteen planes do not fit
     assert {x[2] for x in capi.conv2d_tactics_f32(32, 320, 320, 3, 16, 3, 2, 1, ld_in=4)} <= {1}  # the padded 3-channel case: two taps per step, DMA only
     off = subprocess.run([sys.executable, "-c", "from tensorrtx_amd import capi; print(capi.conv2d_tactics_f32(32, 80, 80, 64, 64, 3, 1, 1))"],
                          env=dict(os.environ, TRTX_CONV_ROLES="0"), capture_output=True, text=True, check=True)
     assert eval(off.stdout.strip().splitlines()[-1]) == [x for x in t if x[2] != 6]    # TRTX_CONV_ROLES=0 removes exactly the role variants
+    off = subprocess.run([sys.executable, "-c", "from tensorrtx_amd import capi; print(capi.conv2d_tactics_f32(32, 80, 80, 64, 64, 3, 1, 1))"],
+                         env=dict(os.environ, TRTX_CONV_RES="0"), capture_output=True, text=True, check=True)
+    assert eval(off.stdout.strip().splitlines()[-1]) == [x for x in t if x[2] != 7]    # TRTX_CONV_RES=0: exactly the resident-operand entries
 
 
 def test_int8_tensor_on_a_convolution_without_the_mfma_path_falls_back_to_fp16():

@@ -57,7 +57,7 @@ def one(N, H, W, Cin, Cout, k, s, act):
         same = "same bits" if torch.equal(got, first) else f"DIFFERS max {float((got - first).abs().max()):.3g}"
         med = sorted(ts)[len(ts) // 2]
         tiles = -(-N * Ho * Wo // t[1]) * (cout_pad // t[0])
-        print(f"   bn {t[0]:3d} bm {t[1]:3d} { {3: 'ptch', 5: 'regs', 6: 'role'}.get(t[2], 'dma ')} bk {t[3]:2d}  {tiles:6d} tiles ({tiles / 256:5.1f}/CU)  median {med:7.1f} us  min {min(ts):7.1f}  = {gflop / med * 1e3:6.1f} TF/s ({gflop / med * 1e3 / 157.3:.2f})  {same}")
+        print(f"   bn {t[0]:3d} bm {t[1]:3d} { {3: 'ptch', 5: 'regs', 6: 'role', 7: 'res3', 8: 'res1'}.get(t[2], 'dma ')} bk {t[3]:2d}  {tiles:6d} tiles ({tiles / 256:5.1f}/CU)  median {med:7.1f} us  min {min(ts):7.1f}  = {gflop / med * 1e3:6.1f} TF/s ({gflop / med * 1e3 / 157.3:.2f})  {same}")
 
 
 if __name__ == "__main__":
