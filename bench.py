@@ -975,7 +975,7 @@ def main():
             "value": imgs_step * args.steps / tol["dt"], "unit": "images/sec", "ms_per_step": tol["dt"] / args.steps * 1e3, "legs_ms": tol["legs"],
             "dtype": "f32", "contexts": n_ctx,
             "single_context": {"value": imgs_step * args.steps / tol["dt1"], "ms_per_step": tol["dt1"] / args.steps * 1e3, "legs_ms": tol["legs1"]},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16_kernel<..., F32> (kernels/conv_igemm_f32.hip, all instantiations)", "launches_per_step": n32,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16_kernel<..., F32> + conv_res3 / conv_res1 <..., F32> (kernels/conv_igemm_f32.hip, conv_res.hip: every instantiation the tuner picked)", "launches_per_step": n32,
                          "flop_per_step": flop32, "conv_ms_per_step": conv32_ms, "achieved": flop32 / (conv32_ms * 1e-3) / 1e12 if conv32_ms else None,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop32 / (conv32_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if conv32_ms else None,
                          "frac_describes": "every fp32 conv launch alone (serialized profile pass), against the fp32-operand MFMA peak (1/16 of the fp16 one)"},

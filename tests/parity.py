@@ -80,7 +80,7 @@ VALUES = {
     ('retinaface_r50_fp16', '256x320'): {'matched_fraction': 0.99976, 'min_iou': 0.9864, 'max_box_err': 1.13, 'max_conf_err': 0.00808},
     ('retinaface_r50_fp16', '1280x1280'): {'matched_fraction': 0.999976, 'min_iou': 0.9885, 'max_box_err': 1.52, 'max_conf_err': 0.0107},
     ('rcnn_fp32', None): {'feat_err': 1.07e-05, 'score_err': 4.59e-06, 'proposals_matched': 0.98, 'detections_matched': 0.95},
-    ('rcnn_fp16', '320x416'): {'feat_rel_err': 0.00248, 'proposals_matched': 0.988, 'detections_matched': 0.952, 'top_score_err': 0.000377},
+    ('rcnn_fp16', '320x416'): {'feat_rel_err': 0.00248, 'proposals_matched': 0.988, 'detections_matched': 0.952, 'top_score_err': 0.000796},
     ('rcnn_fp16', '800x1067'): {'feat_rel_err': 0.00261, 'proposals_matched': 0.9878, 'detections_matched': 0.962, 'top_score_err': 0.000464},
     ('rcnn_fp16', '800x1333'): {'feat_rel_err': 0.00257, 'proposals_matched': 0.9906, 'detections_matched': 0.962, 'top_score_err': 0.000582},
     ('mask_rcnn_fp32', None): {'mask_err': 1.76e-06},
