@@ -293,25 +293,12 @@ __global__ __launch_bounds__(256) void yolo_head_score_kernel(HeadTable t, int c
         int cells_here = total_cells - g0;
         cells_here = cells_here > 64 ? 64 : cells_here;
         const int n = cells_here * pieces;
-        // U pieces per lane in flight at once (round 6): one piece per trip - a load, its maximum, a conditional LDS store the next load could not pass - was
-        // classes / 8 = 10 dependent memory round trips per wave, 36 us for 77 MB (0.31 of the HBM roof, profiles/r05_kernel_stats_c3_1ctx_lanes1.txt)
-        constexpr int U = 10;
-        for (int j0 = lane; j0 < n; j0 += 64 * U) {
-            float v[U][8];
-            int cu[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + 64 * u;
-                const int jj = j < n ? j : lane;   // (a piece the wave reads anyway)
-                const int c = jj / pieces, q = jj - c * pieces;
-                cu[u] = j < n ? c : -1;
-                load8(cell_ptr(g0 + c) + 64 + q * 8, v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float m = fmaxf(fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])), fmaxf(fmaxf(v[u][4], v[u][5]), fmaxf(v[u][6], v[u][7])));
-                if (cu[u] >= 0 && m > -2.3f) s_list[wave0 + cu[u]] = 1;
-            }
+        for (int j = lane; j < n; j += 64) {
+            const int c = j / pieces, q = j - c * pieces;
+            float v[8];
+            load8(cell_ptr(g0 + c) + 64 + q * 8, v);
+            float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            if (m > -2.3f) s_list[wave0 + c] = 1;
         }
     }
     __syncthreads();
