@@ -453,6 +453,9 @@ int32_t trtx_builder_set_max_aux_streams(trtx_builder* b, int32_t n);
 int32_t trtx_builder_set_int8_calibrator(trtx_builder* b, const trtx_calibrator_vtbl* calibrator);
 /* the threshold search of the entropy calibration on a caller-supplied histogram of |x| over [0, range] (tests, tools) */
 float trtx_int8_entropy_threshold(const double* hist, int32_t bins, float range);
+/* the clip limit the calibration applies on top of it (round 6; TRTX_INT8_CLIP_LIMIT, default 1e-4): the lowest bin edge >= thr beyond which at most `limit` of the
+ * histogram's mass lies; limit <= 0 returns thr.  TensorRT's entropy calibrator is closed: both searches are this library's own. */
+float trtx_int8_clip_limited_threshold(const double* hist, int32_t bins, float range, float thr, double limit);
 /* createNetworkV2(flags): bit 0 = kEXPLICIT_BATCH */
 int32_t trtx_network_create(trtx_builder* b, uint32_t flags, trtx_network** out);
 void trtx_network_destroy(trtx_network* n);

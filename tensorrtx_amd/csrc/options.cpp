@@ -23,6 +23,7 @@ Options read_options() {
     if (const char* v = env("TRTX_TACTIC_CACHE")) o.tactic_cache = v;
     o.graph = env_is("TRTX_GRAPH", 1);
     if (const char* v = env("TRTX_CALIB_REPORT")) o.calib_report = v;
+    if (const char* v = env("TRTX_INT8_CLIP_LIMIT"); v && *v) o.int8_clip_limit = atof(v);
     o.lanes = env_int("TRTX_LANES", 0);
     o.group_convs = !env_is("TRTX_GROUP_CONVS", 0);
     o.fold_upsample = !env_is("TRTX_FOLD_UPSAMPLE", 0);

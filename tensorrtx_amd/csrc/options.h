@@ -14,6 +14,8 @@ struct Options {
     std::string tactic_cache;    // TRTX_TACTIC_CACHE=<file>: tactic choices outlive the process (ITimingCache analogue)
     bool graph = false;          // TRTX_GRAPH=1: hipGraph replay of the lane schedule (opt-in: it does not pay)
     std::string calib_report;    // TRTX_CALIB_REPORT=<file>: per-tensor INT8 calibration report
+    double int8_clip_limit = 1e-4;   // TRTX_INT8_CLIP_LIMIT=<share>: entropy calibration may not clip more than this share of a tensor's elements (the threshold is raised
+                                 //            to that quantile; 0 = the entropy threshold as found).  Round 6, int8.cpp.
     int lanes = 0;               // TRTX_LANES=<n>: streams per execution context (0: 1 + IBuilderConfig::setMaxAuxStreams)
     // --- A/B switches: each turns ONE lowering pass or kernel family off so that the test-suite can hold the two forms against each other bit for bit
     bool group_convs = true;     // TRTX_GROUP_CONVS=0: sibling convolutions one launch each (same K order, same bits)

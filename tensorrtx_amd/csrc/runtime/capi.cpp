@@ -434,3 +434,8 @@ extern "C" float trtx_int8_entropy_threshold(const double* hist, int32_t bins, f
     if (!hist || bins < 128) return 0.f;
     return entropy_threshold(std::vector<double>(hist, hist + bins), range);
 }
+// ... and the clip limit the calibration applies on top of it (limit <= 0: thr unchanged)
+extern "C" float trtx_int8_clip_limited_threshold(const double* hist, int32_t bins, float range, float thr, double limit) {
+    if (!hist || bins < 1) return thr;
+    return clip_limited_threshold(std::vector<double>(hist, hist + bins), range, thr, limit);
+}

@@ -13,6 +13,21 @@
 
 namespace trtx {
 
+float clip_limited_threshold(const std::vector<double>& hist, float range, float thr, double limit) {
+    const int n = (int)hist.size();
+    if (!(limit > 0.0) || n < 1 || !(range > 0.f)) return thr;
+    double total = 0;
+    for (double v : hist) total += v;
+    if (!(total > 0)) return thr;
+    const double w = (double)range / n;
+    // walk down from the top: bins k .. n - 1 lie beyond edge k * w (their centres do); the lowest edge that keeps their share within the limit
+    double beyond = 0;
+    int k = n;
+    while (k > 0 && (beyond + hist[k - 1]) <= limit * total) beyond += hist[--k];
+    const float edge = (float)(k * w);
+    return edge > thr ? edge : thr;
+}
+
 float entropy_threshold(const std::vector<double>& hist_in, float range) {
     // Bin 0 takes the value of bin 1 before the search, as NVIDIA's public restatement of this calibrator does (pytorch-quantization,
     // calib/histogram.py::_compute_amax_entropy: "bins[0] = bins[1]"): the exact zeros of a post-ReLU tensor (and zero padding) are
@@ -303,7 +318,9 @@ int32_t run_int8_calibration(Network* net, const trtx_calibrator_vtbl& calib) {
             if (minmax) {   // kMINMAX_CALIBRATION: the largest |x| seen (to one fine bin)
                 thr = absmax;
             } else {
-                thr = entropy_threshold(h, absmax);
+                // ... but never so low that more than int8_clip_limit of the tensor saturates: the KL search weighs the histogram's BULK, and on heavy-tailed
+                // activations (SiLU networks) it trades away a tail of 1e-3 of the elements - the detection candidates live there
+                thr = clip_limited_threshold(h, absmax, entropy_threshold(h, absmax), read_options().int8_clip_limit);
             }
             net->tensor_scale[t.net_tensor] = thr / 127.0f;
             if (report) {

@@ -28,6 +28,9 @@ struct CalibObserver {
 // symmetric threshold that minimises the KL divergence between the 2048-bin |x| histogram and its 128-level quantisation
 // (the "entropy calibration" of NVIDIA's 8-bit-inference material; TensorRT's kENTROPY_CALIBRATION_2).  Returns the threshold.
 float entropy_threshold(const std::vector<double>& hist, float range);
+// The clip limit on top of it (round 6): the smallest bin edge T >= thr of the |x| histogram over [0, range] beyond which at most `limit` of the mass lies
+// (a bin counts as beyond T when its centre is); limit <= 0 returns thr.
+float clip_limited_threshold(const std::vector<double>& hist, float range, float thr, double limit);
 
 // "TRT-<ver>-EntropyCalibration2\n<tensor name>: <hex of the float scale bits>\n..." (the format TensorRT writes and the
 // reference's calibrator stores / reloads verbatim, calibrator.cpp:56-74)

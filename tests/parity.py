@@ -85,14 +85,14 @@ VALUES = {
     ('rcnn_fp16', '800x1333'): {'feat_rel_err': 0.00257, 'proposals_matched': 0.9906, 'detections_matched': 0.962, 'top_score_err': 0.000582},
     ('mask_rcnn_fp32', None): {'mask_err': 1.76e-06},
     ('mask_rcnn_fp16', None): {'mask_err': 0.00139},
-    ('yolov8n_int8_320', None): {'head_max_abs_err_fp16': 0.0813, 'head_mean_rel_err_int8': 0.0491, 'head_max_err_over_span_int8': 0.435},
-    ('yolov8n_int8_640', 'vs_fp32_oracle'): {'matched_iou50': 0.756, 'mean_iou': 0.838, 'mean_conf_err': 0.246},
-    ('yolov8n_int8_640', 'vs_fp16_engine'): {'matched_iou50': 0.758, 'mean_iou': 0.838, 'mean_conf_err': 0.245},
+    ('yolov8n_int8_320', None): {'head_max_abs_err_fp16': 0.0813, 'head_mean_rel_err_int8': 0.0324, 'head_max_err_over_span_int8': 0.221},
+    ('yolov8n_int8_640', 'vs_fp32_oracle'): {'matched_iou50': 0.9372, 'mean_iou': 0.9176, 'mean_conf_err': 0.151},
+    ('yolov8n_int8_640', 'vs_fp16_engine'): {'matched_iou50': 0.9371, 'mean_iou': 0.918, 'mean_conf_err': 0.151},
     ('yolov8n_int8_640', 'minmax_vs_fp32_oracle'): {'matched_iou50': 0.924, 'matched_iou90': 0.825, 'mean_iou': 0.9473, 'mean_conf_err': 0.0877},
     ('retinaface_r50_int8', 'vs_fp32_oracle'): {'matched_iou50': 0.9725, 'mean_iou': 0.889, 'mean_conf_err': 0.0444},
     ('retinaface_r50_int8', 'vs_fp16_engine'): {'matched_iou50': 0.9725, 'mean_iou': 0.889, 'mean_conf_err': 0.0445},
     ('retinaface_r50_int8', 'minmax_vs_fp32_oracle'): {'matched_iou50': 0.9335, 'mean_iou': 0.871, 'mean_conf_err': 0.053},
-    ('yolov8n_int8_640', 'entropy2_engine_vs_plan_interpreter'): {'matched_iou90': 0.9174, 'matched_iou90_reverse': 0.9118, 'mean_conf_err': 0.0463},
+    ('yolov8n_int8_640', 'entropy2_engine_vs_plan_interpreter'): {'matched_iou90': 0.9109, 'matched_iou90_reverse': 0.9061, 'mean_conf_err': 0.0547},
     ('yolov8n_int8_640', 'minmax_engine_vs_plan_interpreter'): {'matched_iou90': 0.9259, 'matched_iou90_reverse': 0.9137, 'mean_conf_err': 0.0701},
     ('retinaface_r50_int8', 'int8_engine_vs_plan_interpreter'): {'matched_iou50': 0.99315, 'mean_iou': 0.886, 'mean_conf_err': 0.0483},
     ('retinaface_r50_int8', 'int8_minmax_engine_vs_plan_interpreter'): {'matched_iou50': 0.95, 'mean_iou': 0.88, 'mean_conf_err': 0.0557},
@@ -146,12 +146,13 @@ CEILINGS = {
     # IoU > 0.5, the head must stay within 10 % mean relative error, and its worst logit error is bounded by the range
     # of the logits themselves (an error as large as the logit range would mean a dead head).
     ("yolov8n_int8_320", None): {"head_max_abs_err_fp16": fp16_walk(133, 16), "head_mean_rel_err_int8": 0.10, "head_max_err_over_span_int8": 0.5},
-    # YOLOv8n + entropy calibration on the seeded RANDOM weights: tools/int8_budget.py (a CPU emulation of int8 storage with the calibrator's
-    # thresholds, independent of the GPU product; profiles/r04_int8_budget.txt) finds 81 % of the candidates again, ALL of the loss being
-    # clipping (the 8-bit grid alone: 99.6 %), three backbone tensors accounting for most of it.  The engine has to stay within 0.1 of that
-    # emulation; the 0.90 figure is asserted where nothing is clipped (min-max rows) and on RetinaFace (99.8 % since the bin-0 fix).
-    ("yolov8n_int8_640", "vs_fp32_oracle"): {"matched_iou50": 0.81 - 0.10, "mean_iou": 0.88 - 0.08, "mean_conf_err": 0.40},
-    ("yolov8n_int8_640", "vs_fp16_engine"): {"matched_iou50": 0.81 - 0.10, "mean_iou": 0.88 - 0.08, "mean_conf_err": 0.40},
+    # YOLOv8n + entropy calibration on the seeded RANDOM weights.  Rounds 4-5: the plain KL threshold found 81-83 % of the candidates again, ALL of the loss
+    # being clipping (tools/int8_budget.py, a CPU emulation with the KL thresholds: the 8-bit grid alone 99.6 %), and the row was asserted at 0.71.  Round 6
+    # (VERDICT r5 item 7): the calibration never clips more than 1e-4 of a tensor (TRTX_INT8_CLIP_LIMIT; the KL threshold is raised to that quantile - a rule
+    # stated before it was measured: the usual 99.99th percentile) -> 95.5 % at IoU 0.5, 77 % at IoU 0.9 (plain KL: 82.6 % / 48 %; profiles/r06_int8_clip_limit.txt),
+    # and the row is asserted at the same 0.90 as every other int8 row.
+    ("yolov8n_int8_640", "vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.90, "mean_conf_err": 0.20},
+    ("yolov8n_int8_640", "vs_fp16_engine"): {"matched_iou50": 0.90, "mean_iou": 0.90, "mean_conf_err": 0.20},
     ("yolov8n_int8_640", "minmax_vs_fp32_oracle"): {"matched_iou50": 0.90, "matched_iou90": 0.75, "mean_iou": 0.90, "mean_conf_err": 0.10},
     ("retinaface_r50_int8", "vs_fp32_oracle"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},
     ("retinaface_r50_int8", "vs_fp16_engine"): {"matched_iou50": 0.90, "mean_iou": 0.80, "mean_conf_err": 0.15},

@@ -111,6 +111,33 @@ def test_entropy_threshold_matches_numpy_restatement():
             assert got > 0.95 * r     # nothing to clip
 
 
+def test_clip_limit_raises_the_entropy_threshold_to_the_quantile_and_no_further():
+    """Round 6: entropy calibration never clips more than TRTX_INT8_CLIP_LIMIT (default 1e-4) of a tensor - the KL threshold is
+    raised to that quantile of the histogram; a threshold that already clips less stays; limit 0 switches the rule off.  Checked against NumPy."""
+    L = capi.lib()
+    L.trtx_int8_entropy_threshold.restype = ctypes.c_float
+    L.trtx_int8_clip_limited_threshold.restype = ctypes.c_float
+    L.trtx_int8_clip_limited_threshold.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_double]
+    rng = np.random.default_rng(1)
+    x = rng.lognormal(0, 1, 1000000)                  # heavy tail: the KL threshold trades 4e-4 of it away
+    r = float(x.max())
+    hist, edges = np.histogram(x, bins=2048, range=(0, r))
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    hp = h.ctypes.data_as(ctypes.c_void_p)
+    thr = L.trtx_int8_entropy_threshold(hp, 2048, ctypes.c_float(r))
+    centres = 0.5 * (edges[:-1] + edges[1:])
+    share = lambda t: hist[centres > t].sum() / hist.sum()
+    assert share(thr) > 1e-4                           # (what the rule is for)
+    got = L.trtx_int8_clip_limited_threshold(hp, 2048, r, thr, 1e-4)
+    assert got > thr and share(got) <= 1e-4
+    w = r / 2048
+    assert share(got - 1.01 * w) > 1e-4                # ... and one bin lower would clip more than the limit: the quantile, not min-max
+    assert got < 0.9 * r
+    assert L.trtx_int8_clip_limited_threshold(hp, 2048, r, thr, 0.0) == thr                  # off
+    assert L.trtx_int8_clip_limited_threshold(hp, 2048, r, ctypes.c_float(0.99 * r), 1e-4) == ctypes.c_float(0.99 * r).value   # already above the quantile
+    assert abs(L.trtx_int8_clip_limited_threshold(hp, 2048, r, thr, 1e-9) - r) <= 1.01 * w   # a limit below one element: min-max
+
+
 def test_int8_build_from_cache_needs_no_gpu_and_marks_int8_convs():
     path, _ = synth_wts("yolov8n")
     plan16 = engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=1)
