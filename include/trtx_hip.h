@@ -259,8 +259,10 @@ int32_t trtx_op_conv_force_tactic(const int32_t* tactic6);
 /* The same launch in an fp32 engine (builds without BuilderFlag::kFP16: yolov8/include/config.h:1-3 USE_FP32, yolov8/src/model.cpp:314-324):
  * NHWC fp32 in / out / residual, fp32 weights packed [cout_pad][kpad] (k = tap * cink + c, cink = Cin rounded up to the 16-channel k-step, or 8 for
  * Cin <= 8; Cin itself a multiple of 4), fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and sums).  trtx_op_conv2d_tactics_f32 lists the tile
- * configurations of the layer, 4 ints each {column-tile width, rows per tile, operand path: 1 = LDS-DMA, 5 = through registers, channels per k-step: 16 / 32} -
- * entry 0 the launcher's own choice, every entry the same bits -; tile4 pins one for this call (NULL: the launcher's choice). */
+ * configurations of the layer, 4 ints each {column-tile width, rows per tile, operand path: 1 = LDS-DMA, 3 = resident patch, 5 = through registers, 6 = wave roles,
+ * 7 / 8 = the resident-operand 3x3 / 1x1 kernels of conv_res.hip, channels per k-step: 16 / 32} - entry 0 the launcher's own choice, every entry the same bits -;
+ * tile4 pins one for this call (NULL: the launcher's choice).  `bias` (may be NULL) holds cout_pad floats (trtx_conv_packed_dims_f32; Cout rounded up to 16), 16-byte
+ * aligned: the tile starts its accumulators with 16-byte loads of it up to the padded width - a [Cout] array with Cout % 16 != 0 would be read past its end. */
 int32_t trtx_conv_packed_dims_f32(int cout, int cin_pad, int kh, int kw, int32_t* cout_pad, int32_t* kpad, int32_t* cink);
 int32_t trtx_conv_pack_weights_f32(const float* w_kcrs, int cout, int cin, int kh, int kw, int cin_pad, const float* ch_scale, float* packed);
 int32_t trtx_op_conv2d_nhwc_f32(const void* in, int N, int H, int W, int Cin, int ld_in, const void* wpacked, const float* bias, void* out, int Cout,

@@ -267,10 +267,13 @@ def pack_conv_weights_f32(w_kcrs, cin_pad=None, ch_scale=None):
 
 
 def conv2d_nhwc_f32(x, wpacked, bias, cout, kh, kw, stride, pad, act1="none", residual=None, act2="none", out=None, out_ld=None, tile=None):
-    """Single fused conv launch on NHWC fp32 tensors (x: [N,H,W,Cin] CUDA float32, Cin % 4 == 0); tile = (bn, bm, operand path, channels per k-step) or None."""
+    """Single fused conv launch on NHWC fp32 tensors (x: [N,H,W,Cin] CUDA float32, Cin % 4 == 0); tile = (bn, bm, operand path, channels per k-step) or None.
+    bias: cout_pad floats (cout rounded up to 16; pack_conv_weights_f32 returns cout_pad) - the kernel reads it in 16-byte pieces up to the padded width."""
     import torch
     L = lib()
     N, H, W, Cin = x.shape
+    if bias is not None and bias.numel() < (cout + 15) // 16 * 16:
+        raise ValueError(f"bias holds {bias.numel()} floats, the fp32 tile reads cout_pad = {(cout + 15) // 16 * 16}")
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     if out is None:

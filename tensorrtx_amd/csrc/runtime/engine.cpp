@@ -696,6 +696,7 @@ extern "C" int32_t trtx_context_enqueue_frames(trtx_context* c, int32_t batch, c
     for (size_t k = 0; k < plan.ops.size() && stem < 0; ++k)
         if (plan.ops[k].kind == OP_CONV && plan.ops[k].stem) stem = (int)k;
     if (n_in != 1 || stem < 0 || plan.ops[stem].conv.Cin != 3) return TRTX_ERR_UNSUPPORTED;
+    if (plan.ops[stem].conv.f32) return TRTX_ERR_UNSUPPORTED;   // fp32 engines have a stem op too (round 5) but no fused-letterbox form of it: rejected before anything is enqueued
     for (size_t k = 0; k < plan.ops.size(); ++k)   // nothing else may read the input tensor
         for (int t : plan.ops[k].in)
             if ((int)k != stem && t == plan.ops[stem].in[0]) return TRTX_ERR_UNSUPPORTED;

@@ -139,3 +139,25 @@ def test_enqueue_frames_is_letterbox_then_enqueue_bit_for_bit(gpu):
         assert torch.equal(one3[k][:n].view(torch.int32), two3[k][:n].view(torch.int32))
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+def test_enqueue_frames_rejects_an_fp32_engine_before_anything_is_enqueued(gpu):
+    """fp32 engines have a stem op since round 5 but no fused-letterbox form of it - trtx_context_enqueue_frames says UNSUPPORTED up front
+    (it used to pass the validation and fail inside the plan's execution with lanes and events already set up); the engine stays usable."""
+    import torch
+    from tensorrtx_amd import engine, preproc
+    from util import synth_wts
+    path, _ = synth_wts("yolov8n")
+    plan = engine.build_plan("yolov8n", path, batch=1, h=160, w=160, fp16=0)
+    e = engine.Engine(plan)
+    try:
+        frame = torch.randint(0, 256, (120, 200, 3), dtype=torch.uint8, device=gpu)
+        outs = [None if e.is_input[i] else torch.zeros(int(np.prod(e.dims[i])), dtype=torch.float32, device=gpu) for i in range(e.nb_bindings)]
+        with pytest.raises(Exception):
+            e.enqueue_frames(1, [frame], outs)
+        x = preproc.letterbox_batch([frame], 160, 160)
+        e.enqueue(1, [x if t is None else t for t in outs])      # the two-step path still runs
+        torch.cuda.synchronize()
+    finally:
+        e.close()
