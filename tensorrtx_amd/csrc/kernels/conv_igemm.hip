@@ -521,12 +521,13 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
     a.bm = 0; a.t_wsk = 0; a.t_ws = 0; a.t_r3 = 0;
     if (!conv_igemm_supported(a)) return 0;
     const bool fp16 = !a.in_i8 && !a.out_i8 && !a.res_i8;
-    const bool ws_ok = fp16 && conv_ws_supported(a);
+    const bool pinned = a0.k_pinned != 0;   // one summation order whatever the tuner measures: no wave-split-K, no weight-stationary candidate
+    const bool ws_ok = fp16 && !pinned && conv_ws_supported(a);
     // 0: the default.  Work-efficient sets (engines whose contexts share the chip) never split K over the waves, not even as the
     // starting point: measured on YOLOv8n b32 with three contexts in flight it is worth nothing there (33.0k img/s with, 33.1k without,
     // two runs each on one box), and "one summation order per plan" is the simpler contract.
     if (ws_ok) push(a.bn, a.bk, 128, 1, 2);
-    else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only) ? 2 : 1, 1);
+    else push(a.bn, a.bk, 128, (wsk_default(a) && !work_efficient_only && !pinned) ? 2 : 1, 1);
     // the 256 x 256 x 64 role-alternating tile for large plain GEMMs (conv_gemm256.hip): more work-efficient than any 128-row tile
     if (fp16 && options().gemm256 && conv_gemm256_worthwhile(a)) push(256, 64, 256, 1, 1);
     const int bks[2] = {a.bk, (fp16 && a.CinK % 64 == 0 && a.CinK != 16 && a.Kpad % 64 == 0) ? (a.bk == 32 ? 64 : 32) : a.bk};
@@ -544,7 +545,7 @@ int conv_tactics(const ConvArgs& a0, ConvTactic* out, int max_out, bool work_eff
             push(bn, t.bk, 128, 1, 1);
             if (bm64_possible(t) && !work_efficient_only) push(bn, t.bk, 64, 1, 1);
             if (bm256_possible(t) && (long)((a.M + 255) / 256) * (a.Cout_pad / bn) >= 512) push(bn, t.bk, 256, 1, 1);  // >= 2 tiles per CU
-            if (wsk_possible(t) && !work_efficient_only) push(bn, t.bk, 128, 2, 1);
+            if (wsk_possible(t) && !work_efficient_only && !pinned) push(bn, t.bk, 128, 2, 1);
             // the resident-patch 3x3 kernel (ws == 3): the same bits, fewer bytes through the global -> LDS fill path (work-efficient: a candidate in every set)
             if (fp16 && options().patch && patch_possible(t)) push(bn, t.bk, 128, 1, 3);
             // the resident-operand kernels (ws == 7 / 8, conv_res.hip): the same bits again, nothing fetched inside the k-loop.  Measured on YOLOv8n b32

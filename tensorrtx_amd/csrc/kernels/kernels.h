@@ -58,6 +58,9 @@ struct ConvArgs {
     // fp32 engines (builds without kFP16; conv_igemm_f32.hip): activations, residual and packed weights are fp32, the k-step is 16 channels
     // (bk == 16; CinK = Cin rounded up to 16, or 8 for Cin <= 8: two filter taps per step), Kpad = K rounded up to 16.  All fields in channels.
     int f32;
+    // The layer's summation order is pinned to the main kernel's (lowering: members of a grouped launch, and the would-be members under TRTX_GROUP_CONVS=0):
+    // conv_tactics() lists no wave-split-K / weight-stationary candidate for it - the tuner cannot hand it another K order.  Part of the tactic signature.
+    int k_pinned;
 };
 
 // One launch configuration of an implicit-GEMM layer.  All tactics of a layer share its packed weights (Cout_pad, CinK, Kpad), so

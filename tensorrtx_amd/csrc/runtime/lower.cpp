@@ -1314,7 +1314,10 @@ struct Lowerer {
         if (groups.empty()) return;
         if (mark_only) {
             for (const auto& mem : groups)
-                for (int m : mem) plan.ops[m].conv.t_wsk = 1;
+                for (int m : mem) {
+                    plan.ops[m].conv.t_wsk = 1;
+                    plan.ops[m].conv.k_pinned = 1;   // ... and the tuner keeps it that way (its candidates for a pinned layer all walk K as the main kernel does)
+                }
             return;
         }
         // new order: Kahn over the contracted graph, ready nodes taken in the order of their first member's old position
@@ -1369,6 +1372,7 @@ struct Lowerer {
                 // the fallback the executor takes at a batch where the members no longer share an instantiation, and TRTX_GROUP_CONVS=0 - must not pick
                 // the wave-split-K variant (different K order: the same engine rounded differently depending on batch size and on the switch)
                 mo.conv.t_wsk = 1;
+                mo.conv.k_pinned = 1;
                 g.group.push_back(mo);
                 g.name += (g.name.empty() ? "" : " + ") + mo.name;
                 for (int t : mo.in)

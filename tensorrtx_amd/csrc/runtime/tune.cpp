@@ -152,7 +152,7 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
         a.residual = op.in.size() > 1 ? reinterpret_cast<const void*>(1) : nullptr;  // only its presence matters here
         Item it;
         it.op = (int)k;
-        it.key = signature(a, a.act1 * 16 + a.act2 + (throughput ? 4096 : 0) + (a.f32 ? 8192 : 0));
+        it.key = signature(a, a.act1 * 16 + a.act2 + (throughput ? 4096 : 0) + (a.f32 ? 8192 : 0) + (a.k_pinned ? 16384 : 0));   // (a pinned layer has its own candidate set: its own decision)
         // (fp32 engines: the tile shapes of conv_igemm_f32.hip - every one the same bits, the choice is tile balance over the 256 CUs)
         it.n = a.f32 ? conv_tactics_f32(a, it.cand, kMaxTactics) : conv_tactics(a, it.cand, kMaxTactics, throughput);
         if (it.n < 1) continue;

@@ -468,16 +468,21 @@ def test_conv_bn_mish_engine_matches_the_reference_expression(gpu, fp16, fused):
     assert (ref.abs() > 1).any() and (ref < 0).any()   # both tails of the activation are exercised
 
 
-def test_grouped_sibling_convolutions_return_the_bits_of_one_launch_each(gpu):
+@pytest.mark.parametrize("tuned", [False, True], ids=["static", "tuned"])
+def test_grouped_sibling_convolutions_return_the_bits_of_one_launch_each(gpu, tuned):
     """lower.cpp group_convs / conv_igemm_group_f16_kernel: the detect head's 18 convolutions in 6 launches of 3 sibling layers each - every
     member computed exactly as its own launch computes it.  Both engines on the static kernel choice, same input: every head tensor and the
     decode buffer equal bit for bit; and the grouped plan really has the 6 groups.  No TRTX_CONV_NOWSK since round 5: a group member
     is marked "never wave-split-K", so its own launch - TRTX_GROUP_CONVS=0 here, or the executor's per-member fallback at another batch - walks K in
     the grouped kernel's order even on the 20 x 20 level, where the static rule would otherwise split K over the waves.  (Own process: the switch
-    is read while the plan is lowered, and engines cache per-process tactic choices.)"""
+    is read while the plan is lowered, and engines cache per-process tactic choices.)
+    "tuned" (round 6): the same with the tactics TIMED at build, in a latency engine (whose candidate sets hold the wave-split-K and weight-stationary
+    kernels - another K order): the would-be members carry ConvArgs::k_pinned, conv_tactics() lists only main-kernel-order candidates for them, and every other
+    layer has one signature in both plans, i.e. one choice per process."""
     import subprocess
     code = r'''
 import sys, numpy as np, torch
+TUNED = %d
 sys.path.insert(0, "tests")
 from tensorrtx_amd import engine, synth
 from util import synth_wts
@@ -488,7 +493,7 @@ x = torch.from_numpy(synth.images(B, S, S, seed=31)).cuda()
 outs = []
 for grp in ("1", "0"):
     os.environ["TRTX_GROUP_CONVS"] = grp
-    plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1, aux_streams=0)
+    plan = engine.build_plan("yolov8n", path, batch=B, h=S, w=S, fp16=1, mark_heads=1, **({} if TUNED else {"aux_streams": 0}))
     kinds = [o["kind"] for o in engine.describe_plan(plan, lowered=True)["ops"]]
     assert kinds.count("conv_group") == (6 if grp == "1" else 0), kinds
     e = engine.Engine(plan)
@@ -508,8 +513,12 @@ for k in outs[0]:
     else:
         assert torch.equal(a, b), k
 print("GROUPED_EQUALS_SINGLE", sorted(outs[0]))
-'''
-    env = dict(os.environ, TRTX_TUNE="0")
+''' % (1 if tuned else 0)
+    env = dict(os.environ)
+    env.pop("TRTX_TUNE", None)
+    env.pop("TRTX_TACTIC_CACHE", None)
+    if not tuned:
+        env["TRTX_TUNE"] = "0"
     env.pop("TRTX_CONV_NOWSK", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "GROUPED_EQUALS_SINGLE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
