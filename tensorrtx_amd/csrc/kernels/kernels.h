@@ -160,8 +160,9 @@ int32_t nhwc_to_nchw_f32(const void* in, int dtype, float* out, int N, int C, in
 
 // --- NHWC element ops (dtype = DT_F16 / DT_F32), strided channel slices ---------------------------------
 // SPPF: three chained k x k stride-1 'same' max-pools (fp16, C % 8 == 0, H*W*32 B <= 60 KB of LDS)
+// (f32: fp32 NHWC tensors, 4-channel chunks - the fp32 engines' SPPF)
 int32_t nhwc_maxpool_chain3_f16(const void* in, void* o1, void* o2, void* o3, int N, int H, int W, int C, int ld_in, int ld1,
-                                int ld2, int ld3, int k, hipStream_t s);
+                                int ld2, int ld3, int k, hipStream_t s, int f32 = 0);
 // [N,H,W,(r,q,c)] -> [N,H*bh,W*bw,c], fp16, C % 8 == 0
 int32_t nhwc_depth_to_space_f16(const void* in, void* out, int N, int H, int W, int C, int bh, int bw, int ld_in, int ld_out,
                                 hipStream_t s);

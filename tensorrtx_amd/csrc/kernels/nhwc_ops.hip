@@ -180,27 +180,30 @@ __global__ void pool_kernel(const T* __restrict__ in, T* __restrict__ out, int o
 // SPPF: three chained k x k stride-1 'same' max-pools of one small map.  A workgroup owns (image, 8-channel chunk): the whole
 // H x W map of that chunk sits in LDS (two ping-pong planes), every stage reads k*k neighbours from LDS and writes its
 // output both to global memory (a channel slice of the SPPF concat buffer) and to the other plane.
-__global__ __launch_bounds__(256) void maxpool_chain3_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o1,
-                                                                 _Float16* __restrict__ o2, _Float16* __restrict__ o3, int H,
-                                                                 int W, int C, int ld_in, int ld1, int ld2, int ld3, int k) {
-    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-    extern __shared__ __attribute__((aligned(16))) half8_t s_map[];  // [2][(H + 2r) * (W + 2r)], -inf border: no bound tests
+// T / V: _Float16 x 8 (fp16 engines) or float x 4 (round 6: fp32 engines ran the three pools as three launches) - a 16-byte chunk of channels either way.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool_chain3_kernel(const T* __restrict__ in, T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3, int H,
+                                                             int W, int C, int ld_in, int ld1, int ld2, int ld3, int k) {
+    typedef T half8_t __attribute__((ext_vector_type(V)));
+    extern __shared__ __attribute__((aligned(16))) char s_map_raw[];  // [2][(H + 2r) * (W + 2r)], -inf border: no bound tests
+    half8_t* s_map = reinterpret_cast<half8_t*>(s_map_raw);
     const int HW = H * W;
-    const int chunks = C / 8;
+    const int chunks = C / V;
     const int cv = blockIdx.x % chunks;
     const long n = blockIdx.x / chunks;
     const int r = k / 2;
     const int PW = W + 2 * r, PHW = (H + 2 * r) * PW;
-    const _Float16 ninf = -__builtin_inff16();
-    const half8_t vinf = half8_t{ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+    half8_t vinf;
+#pragma unroll
+    for (int e = 0; e < V; ++e) vinf[e] = (T)(-__builtin_inff());
     for (int p = threadIdx.x; p < 2 * PHW; p += 256) s_map[p] = vinf;
     __syncthreads();
     for (int p = threadIdx.x; p < HW; p += 256) {
         const int h = p / W, w = p - h * W;
-        s_map[(h + r) * PW + w + r] = *reinterpret_cast<const half8_t*>(in + (n * HW + p) * ld_in + cv * 8);
+        s_map[(h + r) * PW + w + r] = *reinterpret_cast<const half8_t*>(in + (n * HW + p) * ld_in + cv * V);
     }
     __syncthreads();
-    _Float16* outs[3] = {o1, o2, o3};
+    T* outs[3] = {o1, o2, o3};
     const int lds[3] = {ld1, ld2, ld3};
 #pragma unroll
     for (int stage = 0; stage < 3; ++stage) {
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(256) void maxpool_chain3_f16_kernel(const _Float16*
             const half8_t* win = src + h * PW + w;  // top-left corner of the k x k window in padded coordinates
             half8_t m = win[0];
             for (int dy = 0; dy < k; ++dy)
-                for (int dx = 0; dx < k; ++dx) m = __builtin_elementwise_max(m, win[dy * PW + dx]);  // v_pk_max_f16
+                for (int dx = 0; dx < k; ++dx) m = __builtin_elementwise_max(m, win[dy * PW + dx]);  // v_pk_max_f16 / v_max_f32
             dst[(h + r) * PW + w + r] = m;
-            *reinterpret_cast<half8_t*>(outs[stage] + (n * HW + p) * lds[stage] + cv * 8) = m;
+            *reinterpret_cast<half8_t*>(outs[stage] + (n * HW + p) * lds[stage] + cv * V) = m;
         }
         __syncthreads();
     }
@@ -503,13 +506,18 @@ int32_t nhwc_pool(const void* in, void* out, int dtype, int op, int N, int H, in
 }
 
 int32_t nhwc_maxpool_chain3_f16(const void* in, void* o1, void* o2, void* o3, int N, int H, int W, int C, int ld_in, int ld1,
-                                int ld2, int ld3, int k, hipStream_t s) {
+                                int ld2, int ld3, int k, hipStream_t s, int f32) {
     const size_t lds = (size_t)2 * (H + k - 1) * (W + k - 1) * 16;  // two padded planes
-    if (C % 8 || lds > 64 * 1024) return TRTX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(maxpool_chain3_f16_kernel, dim3((unsigned)(N * (C / 8))), dim3(256), lds, s, static_cast<const _Float16*>(in),
-                       static_cast<_Float16*>(o1), static_cast<_Float16*>(o2), static_cast<_Float16*>(o3), H, W, C, ld_in, ld1, ld2,
-                       ld3, k);
-    return check_launch("nhwc_maxpool_chain3_f16");
+    const int V = f32 ? 4 : 8;
+    if (C % V || lds > 64 * 1024) return TRTX_ERR_UNSUPPORTED;
+    if (f32)
+        hipLaunchKernelGGL((maxpool_chain3_kernel<float, 4>), dim3((unsigned)(N * (C / 4))), dim3(256), lds, s, static_cast<const float*>(in),
+                           static_cast<float*>(o1), static_cast<float*>(o2), static_cast<float*>(o3), H, W, C, ld_in, ld1, ld2, ld3, k);
+    else
+        hipLaunchKernelGGL((maxpool_chain3_kernel<_Float16, 8>), dim3((unsigned)(N * (C / 8))), dim3(256), lds, s, static_cast<const _Float16*>(in),
+                           static_cast<_Float16*>(o1), static_cast<_Float16*>(o2), static_cast<_Float16*>(o3), H, W, C, ld_in, ld1, ld2,
+                           ld3, k);
+    return check_launch("nhwc_maxpool_chain3");
 }
 
 // depth to space (fp16, 8-channel chunks): out[n][h*bh + r][w*bw + q][c] = in[n][h][w][(r*bw + q)*C + c]

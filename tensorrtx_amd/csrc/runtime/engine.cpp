@@ -213,7 +213,7 @@ int32_t execute_plan(trtx_context* c, int batch, void* const* bindings, hipStrea
             case OP_POOL_CHAIN: {
                 const PTensor &y1 = plan.tensors[op.out[0]], &y2 = plan.tensors[op.out[1]], &y3 = plan.tensors[op.out[2]];
                 st = nhwc_maxpool_chain3_f16(R.ptr(op.in[0]), R.ptr(op.out[0]), R.ptr(op.out[1]), R.ptr(op.out[2]), nb(t0), t0.H,
-                                             t0.W, t0.C, t0.ld, y1.ld, y2.ld, y3.ld, op.i[1], stream);
+                                             t0.W, t0.C, t0.ld, y1.ld, y2.ld, y3.ld, op.i[1], stream, op.dtype == DT_F32 ? 1 : 0);
                 break;
             }
             case OP_D2S:

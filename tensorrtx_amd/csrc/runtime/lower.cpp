@@ -1675,12 +1675,13 @@ struct Lowerer {
             };
             POp &a = plan.ops[k], &b = plan.ops[k + 1], &c3 = plan.ops[k + 2];
             if (!same_max(a) || !same_max(b) || !same_max(c3) || a.i[1] != b.i[1] || a.i[1] != c3.i[1]) continue;
-            if (b.in[0] != a.out[0] || c3.in[0] != b.out[0] || dt != DT_F16) continue;
+            if (b.in[0] != a.out[0] || c3.in[0] != b.out[0] || (dt != DT_F16 && dt != DT_F32)) continue;
             const PTensor& tx = plan.tensors[a.in[0]];
-            bool ok = tx.C % 8 == 0 && tx.ld % 8 == 0 && tx.rcoff % 8 == 0 && (long)(tx.H + a.i[1] - 1) * (tx.W + a.i[1] - 1) * 32 <= 64 * 1024 && tx.nmul == 1;
+            const int cv = dt == DT_F16 ? 8 : 4;   // channels per 16-byte chunk (round 6: fp32 engines too)
+            bool ok = tx.C % cv == 0 && tx.ld % cv == 0 && tx.rcoff % cv == 0 && (long)(tx.H + a.i[1] - 1) * (tx.W + a.i[1] - 1) * 32 <= 64 * 1024 && tx.nmul == 1;
             for (const POp* o : {&a, &b, &c3}) {
                 const PTensor& ty = plan.tensors[o->out[0]];
-                ok = ok && ty.ld % 8 == 0 && ty.rcoff % 8 == 0 && ty.H == tx.H && ty.W == tx.W && ty.C == tx.C;
+                ok = ok && ty.ld % cv == 0 && ty.rcoff % cv == 0 && ty.H == tx.H && ty.W == tx.W && ty.C == tx.C;
             }
             if (!ok) continue;
             a.kind = OP_POOL_CHAIN;

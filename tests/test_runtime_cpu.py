@@ -152,6 +152,9 @@ def test_yolov8n_lowering_at_benchmark_size(monkeypatch):
     #                          are folded into the A-gather of the 1x1 convolutions that read them (384 -> 128 @40x40, 192 -> 64 @80x80)
     ups = [o for o in convs if o["up_c"]]
     assert [(o["cin"], o["cout"], o["up_c"], o["hw_in"]) for o in ups] == [(384, 128, 256, [40, 40]), (192, 64, 128, [80, 80])]
+    # ... and the fp32 build (round 6): the same 65 launches - its SPPF pools share the chained kernel (4-channel chunks) instead of three launches
+    low32 = engine.describe_plan(engine.build_plan("yolov8n", path, batch=2, h=160, w=160, fp16=0), lowered=True)
+    assert sorted(o["kind"] for o in low32["ops"]) == sorted(kinds)
     assert low["bytes_per_sample"] < unfolded["bytes_per_sample"] - 1.8e6   # the convolutions' own reads: 3/4 of 0.8 + 1.6 MB per image gone
     #                                                                          (the resize launches' 0.6 MB read + 2.5 MB written were never priced)
     assert all(o["act1"] == 3 for o in convs if o["bn_folded"])  # SiLU epilogue on every Conv+BN
