@@ -620,7 +620,12 @@ struct ConvRes1Args {
 
 // F32: fp32 operands, conv_res3's conventions (input side in 2-byte units; a k-step = 16 channels = the same 64-byte rows; two-level K sum starting at the bias;
 // the fp32 epilogue).  8 waves: an fp32 step is four MFMAs of 32 cycles per 16 bytes a lane loads - two waves per SIMD keep the matrix pipe and the loads busy.
-template <int NFRAG, int KCH, int NW, bool F32 = false>   // NW waves per workgroup: 16 (128 registers each), 8 for the 128-wide column tile (its 32 bias + 32 accumulator + 32 operand registers)
+// TAPS2 (round 6, last): the same kernel for the THIN 3x3 layers - 16 input channels, two filter taps per 32-wide k-step (the implicit GEMM's CinK == 16 packing:
+// k = tap * 16 + c), stride 1 or 2, output rows a multiple of 16 pixels wide: lane (pixel p, group g) loads the 8 channels 8 (g & 1) ... of the input pixel under
+// tap 2 e + (g >> 1) of its output pixel - border taps and tap 9 out of range, i.e. zero.  YOLOv8n's first C2f block at 160 x 160 (16 -> 16, twice) and the
+// 16 -> 32 stride-2 layer in front of it: 0.8 M pixels of 32 bytes - HBM-streaming layers on which the implicit GEMM spends a barrier, DMA pieces and a refill per
+// k-step for two MFMAs (36 us against 8 of memory time).  Same operand placement as conv_igemm_tile's two-taps-per-step form: the same bits.
+template <int NFRAG, int KCH, int NW, bool F32 = false, bool TAPS2 = false>   // NW waves per workgroup: 16 (128 registers each), 8 for the 128-wide column tile (its 32 bias + 32 accumulator + 32 operand registers)
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_res1_f16_kernel(const ConvRes1Args g) {
     constexpr int BN = 16 * NFRAG;
     constexpr int BSTEP = BN * 64;
@@ -677,8 +682,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_res1_f16_kernel(const Co
     const int cmax = p.Cin - grp * 8;   // this lane's 8 channels of k-step e exist while 32 e < cmax
     const int f_stop = f_first + nf;
 
+    // (TAPS2) geometry of the map: fragments per output row, input extent, stride, padding
+    const int fpr = TAPS2 ? pin_s(pa.Wo >> 4) : 1, Hin = TAPS2 ? pin_s(pa.H) : 0, Win = TAPS2 ? pin_s(pa.W) : 0, Hout = TAPS2 ? pin_s(pa.Ho) : 1;
+    const int cstride = TAPS2 ? pin_s(pa.stride_h) : 1, cpad = TAPS2 ? pin_s(pa.pad_h) : 0;
     // chunk c of row fragment f: KCH 16-byte loads per lane (pixel 16 f + (lane & 15), channels 32 e + 8 (lane >> 4) ...)
     auto load_chunk = [&](int f, int c, intx4 (&a)[KCH]) {
+        if constexpr (TAPS2) {
+            const int row = f / fpr, x0 = (f - row * fpr) << 4;   // (scalar: a fragment lies inside one output row)
+            const int n = row / Hout, yo = row - n * Hout;
+            const int xi0 = (x0 + (lane & 15)) * cstride - cpad, yi0 = yo * cstride - cpad;
+            const bool okf = f < f_stop;
+#pragma unroll
+            for (int s = 0; s < KCH; ++s) {
+                const int e = c * KCH + s;
+                const int tap = 2 * e + (grp >> 1);            // 0 .. 9 (9: the padding of K = 144 to 160)
+                const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;   // tap / 3, tap % 3 for tap <= 10
+                const int yi = yi0 + dy, xi = xi0 + dx;
+                const bool ok = okf & (tap < 9) & (e < nk) & ((unsigned)yi < (unsigned)Hin) & ((unsigned)xi < (unsigned)Win);
+                const unsigned voff = ok ? (unsigned)((((n * Hin + yi) * Win + xi) * p.ld_in + (grp & 1) * 8) * 2) : kOOB;
+                a[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+            }
+            return;
+        }
         const int m = f * 16 + (lane & 15);
         const unsigned base = ((m < M) & (f < f_stop)) ? (unsigned)((m * p.ld_in + grp * 8) * 2) : kOOB;   // (kOOB + any channel offset stays out of range)
 #pragma unroll
@@ -817,18 +842,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_res1_f16_kernel(const Co
     }
 }
 
-template <int NFRAG, int NW, bool F32 = false>
+template <int NFRAG, int NW, bool F32 = false, bool TAPS2 = false>
 int32_t launch_res1(const ConvRes1Args& g, int lds_bytes, hipStream_t s) {
     // more than 64 KB of dynamic LDS has to be asked for once per device
     static bool asked[64] = {};
     int dev = 0;
     TRTX_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !asked[dev]) {
-        TRTX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_res1_f16_kernel<NFRAG, 4, NW, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        TRTX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_res1_f16_kernel<NFRAG, 4, NW, F32, TAPS2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         asked[dev] = true;
     }
     const int runs = (g.chunk + g.per - 1) / g.per;
-    TRTX_LAUNCH((conv_res1_f16_kernel<NFRAG, 4, NW, F32>), dim3(runs * g.tiles_n * 8), dim3(NW * 64), lds_bytes, s, g);
+    TRTX_LAUNCH((conv_res1_f16_kernel<NFRAG, 4, NW, F32, TAPS2>), dim3(runs * g.tiles_n * 8), dim3(NW * 64), lds_bytes, s, g);
     return TRTX_OK;
 }
 
@@ -964,8 +989,23 @@ int32_t conv_res_f16(const ConvArgs* a, int n, hipStream_t s) {
 }
 
 
+// the thin 3x3 form (TAPS2): 16 input channels packed two taps per k-step, stride 1 / 2, output rows of whole 16-pixel fragments
+static bool res1_taps2(const ConvArgs& a) {
+    return !a.f32 && a.kh == 3 && a.kw == 3 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && a.groups == 1 && a.stride_h == a.stride_w &&
+           (a.stride_h == 1 || a.stride_h == 2) && a.Cin == 16 && a.CinK == 16 && a.bk == 32 && a.Kpad == 160 && a.Wo % 16 == 0 && a.Wo > 0 &&
+           a.Ho == (a.H + 2 - 3) / a.stride_h + 1 && a.Wo == (a.W + 2 - 3) / a.stride_w + 1;
+}
+
 bool conv_res1_possible(const ConvArgs& a) {
     if (a.up_C || a.in_i8 || a.out_i8 || a.res_i8 || a.scalar_out) return false;
+    if (res1_taps2(a)) {
+        if (a.Cout % 8 || a.ld_out % 8 || a.ld_in % 8 || (a.residual && a.ld_res % 8)) return false;
+        if (!(a.bm == 0 || a.bm == 128) || a.t_r3 != 0) return false;
+        if (!(a.act1 == ACT_NONE || a.act1 == ACT_RELU || a.act1 == ACT_SILU) || !(a.act2 == ACT_NONE || a.act2 == ACT_RELU)) return false;
+        if (!(a.bn == 16 || a.bn == 32) || a.Cout_pad % a.bn) return false;
+        const double pin = (double)a.N * a.H * a.W, pout = (double)a.N * a.Ho * a.Wo;
+        return pin * a.ld_in * 2.0 < 2.0e9 && pout * a.ld_out < 2.0e9 && pout * (a.residual ? a.ld_res : 1) < 2.0e9;
+    }
     if (a.kh != 1 || a.kw != 1 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h != 0 || a.pad_w != 0 || a.groups != 1) return false;
     if (a.f32) {   // fp32 engines: 16-channel k-steps, 4-byte elements, every activation the fp32 epilogue knows
         if (a.bk != 16 || a.CinK % 16 || a.Cin % 4 || a.Cin > a.CinK || a.Kpad != a.CinK || a.Ho != a.H || a.Wo != a.W) return false;
@@ -991,7 +1031,7 @@ int32_t conv_res1_f16(const ConvArgs& a, hipStream_t s) {
     g.p = a;
     g.p.M = a.N * a.Ho * a.Wo;
     const int es = a.f32 ? 4 : 2;
-    g.in_bytes = (unsigned)((((size_t)g.p.M - 1) * a.ld_in + a.Cin) * es);
+    g.in_bytes = (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ld_in + a.Cin) * es);
     g.w_bytes = (unsigned)((size_t)a.Cout_pad * a.Kpad * es);
     if (a.f32) {   // the kernel's view: the input side in 2-byte units
         g.p.Cin = 2 * a.Cin; g.p.ld_in = 2 * a.ld_in; g.p.CinK = 2 * a.CinK; g.p.K = 2 * a.K; g.p.Kpad = 2 * a.Kpad;
@@ -1016,6 +1056,11 @@ int32_t conv_res1_f16(const ConvArgs& a, hipStream_t s) {
             case 80: st = launch_res1<5, 8, true>(g, lds, s); break;
         }
         return st != TRTX_OK ? st : check_launch("conv_res1_f32");
+    }
+    if (res1_taps2(a)) {
+        if (a.bn == 16) st = launch_res1<1, 16, false, true>(g, lds, s);
+        else st = launch_res1<2, 16, false, true>(g, lds, s);
+        return st != TRTX_OK ? st : check_launch("conv_res1_taps2_f16");
     }
     switch (a.bn) {
         case 32: st = launch_res1<2, 16>(g, lds, s); break;

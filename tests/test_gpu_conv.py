@@ -142,6 +142,10 @@ TACTIC_CASES = [
     (32, 20, 20, 512, 256, 1, 1, 0, "silu", False, "none"),   # K = 512: four chunks, four column tiles of 64 (64 KB of weights each)
     (7, 33, 29, 96, 80, 1, 1, 0, "none", True, "none"),       # three k-steps (odd chunk count: 1), Cout 80: the unpaired fragment, ragged last row fragment
     (3, 57, 55, 48, 32, 1, 1, 0, "relu", False, "none"),      # Cin 48 in a 64-wide K: the ragged chunk's lanes are range-checked to zero
+    # ... and its thin 3x3 form (TAPS2): 16 input channels, two filter taps per k-step, A straight into registers from the tap-shifted pixels
+    (8, 160, 160, 16, 16, 3, 1, 1, "silu", True, "none"),     # YOLOv8n model.2.m.0.cv2 (+ shortcut): one column fragment, borders on every side, many fragments per wave
+    (5, 50, 64, 16, 32, 3, 2, 1, "silu", False, "none"),      # stride 2 (model.1: 16 -> 32): output rows of 32 pixels, odd output height
+    (3, 21, 48, 16, 16, 3, 1, 1, "none", False, "relu"),      # fewer fragments than waves on most workgroups
 ]
 
 
@@ -193,6 +197,8 @@ def test_every_conv_tactic_is_the_same_convolution(gpu, case):
         assert (128, 64, 256, 1, 1, 0) in tactics   # the large-GEMM configurations (experiments: tools/gemm_tactics.py)
     if Cin % 64 == 0 and Cout % 256 == 0 and s == 1 and k * k * Cin >= 256 and (k == 3 or (k == 1 and p == 0)) and ((N * Ho * Wo + 255) // 256) * (Cout // 256) >= 96:
         assert (256, 64, 256, 1, 1, 0) in tactics   # conv_gemm256_possible
+    if Cin == 16 and k == 3 and p == 1 and Wo % 16 == 0:
+        assert any(t[4] == 8 for t in tactics), "the A-direct kernel's thin 3x3 form is a candidate for 16-channel 3x3 layers with whole 16-pixel output rows"
     exact = None
     try:
         for t in tactics:

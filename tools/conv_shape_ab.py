@@ -1,7 +1,7 @@
 """Per-shape A/B of one convolution layer's exchangeable tactics on the GPU (whatever library TRTX_HIP_LIB points at): every tactic conv_tactics() lists
 for the shape is forced in turn, timed with events over REPS launches after a warm-up, checked against the first tactic's output (bit-identical where the
 summation order is the same).  Default shapes: the 3x3 stride-1 layers of the YOLOv8n b32 step that dominate its LDS-fill bytes (tools/lds_fill_model.py).
-    python tools/conv_shape_ab.py [N H W Cin Cout]..."""
+    python tools/conv_shape_ab.py [--k 1] [--stride 2] [N H W Cin Cout]..."""
 import os
 import sys
 
@@ -18,6 +18,7 @@ REPS = 20
 
 
 K = 3
+STRIDE = 1
 
 
 def one(N, H, W, Cin, Cout):
@@ -32,16 +33,16 @@ def one(N, H, W, Cin, Cout):
     first = None
     print(f"{K}x{K} {Cin} -> {Cout} @ {H}x{W} b{N}: {2 * N * H * W * K * K * Cin * Cout / 1e9:.1f} GFLOP")
     try:
-        for t in capi.conv2d_tactics(N, H, W, Cin, Cout, K, 1, K // 2):
+        for t in capi.conv2d_tactics(N, H, W, Cin, Cout, K, STRIDE, K // 2):
             capi.conv_force_tactic(t)
-            y = capi.conv2d_nhwc_f16(x, wg, bias, Cout, K, K, 1, K // 2, "silu")
+            y = capi.conv2d_nhwc_f16(x, wg, bias, Cout, K, K, STRIDE, K // 2, "silu")
             torch.cuda.synchronize()
             ts = []
             for _ in range(REPS):
                 flush.fill_(1)    # the layer's input comes from memory, as after its producer's launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                capi.conv2d_nhwc_f16(x, wg, bias, Cout, K, K, 1, K // 2, "silu", out=y)
+                capi.conv2d_nhwc_f16(x, wg, bias, Cout, K, K, STRIDE, K // 2, "silu", out=y)
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
@@ -59,6 +60,9 @@ if __name__ == "__main__":
     argv = sys.argv[1:]
     if argv[:1] == ["--k"]:
         K = int(argv[1])
+        argv = argv[2:]
+    if argv[:1] == ["--stride"]:
+        STRIDE = int(argv[1])
         argv = argv[2:]
     a = [int(v) for v in argv]
     shapes = [tuple(a[i:i + 5]) for i in range(0, len(a), 5)] if a else SHAPES
