@@ -456,7 +456,8 @@ def test_conv_tactics_are_enumerated_on_the_host():
     assert (64, 32, 128, 1, 8, 0) in capi.conv2d_tactics(32, 80, 80, 128, 64, 1, 1, 0)   # ... and its 1x1 sibling
     t = capi.conv2d_tactics(32, 80, 80, 64, 80, 3, 1, 1)
     assert {x[0] for x in t} == {80}
-    assert capi.conv2d_tactics(32, 160, 160, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1, 0)]   # two taps per k-step: one configuration
+    assert capi.conv2d_tactics(32, 160, 160, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1, 0), (16, 32, 128, 1, 8, 0)]   # two taps per k-step: one tile + (round 6) the A-direct kernel's thin 3x3 form
+    assert capi.conv2d_tactics(32, 150, 150, 16, 16, 3, 1, 1) == [(16, 32, 128, 1, 1, 0)]                          # ... which wants output rows of whole 16-pixel fragments
     assert not any(x[5] for x in capi.conv2d_tactics(32, 40, 40, 64, 64, 3, 2, 1))        # stride 2: no row reuse
     assert not any(x[5] for x in capi.conv2d_tactics(32, 40, 40, 128, 128, 1, 1, 0))
 
