@@ -20,6 +20,7 @@ Options read_options() {
     Options o;
     o.tune = env_int("TRTX_TUNE", -1);
     o.tune_verbose = env_set("TRTX_TUNE_VERBOSE");
+    o.tune_margin = env_int("TRTX_TUNE_MARGIN", -1);
     if (const char* v = env("TRTX_TACTIC_CACHE")) o.tactic_cache = v;
     o.graph = env_is("TRTX_GRAPH", 1);
     if (const char* v = env("TRTX_CALIB_REPORT")) o.calib_report = v;

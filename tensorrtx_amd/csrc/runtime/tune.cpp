@@ -19,7 +19,13 @@
 //   * a layer leaves its default only for a candidate that is at least 3 % faster, and only if, with all the winners in place,
 //     putting it back on the default does not make it and its neighbours faster together (second look: a kernel switch costs
 //     the NEXT launch 7-10 us of cold instruction fetches); the choice is remembered per layer signature for the life of the
-//     process, so that two engines built from the same plan run the same kernels.
+//     process, so that two engines built from the same plan run the same kernels;
+//   * engines built for SEVERAL CONTEXTS IN FLIGHT (setMaxAuxStreams(0)) ask for 30 % instead of 3 % (round 6; TRTX_TUNE_MARGIN): every candidate is timed
+//     ALONE on an idle chip, and what such an engine is built for is the aggregate of three batches sharing it.  Measured on YOLOv8n b32, alternating on one box
+//     (profiles/r06_tune_margin_ab.txt): 3 % - the kernels 5 % faster alone (serialized conv time 0.253 vs 0.239 of the HBM roof) and the three-context rate 1.7 %
+//     LOWER (38.0-38.2k vs 38.7k img/s); 20 % 38.4k, 45 % / 90 % / no timing at all 37.8-38.5k.  A candidate a few per cent faster alone has bought that with
+//     co-residency (a wider tile, a deeper pipeline: more LDS per workgroup) or with work (64-row tiles re-read their weights); only the large wins - the
+//     resident-operand 3x3 kernel's 25-30 % - are less work for the chip as well.
 //
 // Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
 // convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its static default.
@@ -134,6 +140,9 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
     // on YOLOv8n b32, 3 contexts: full candidate set 32.1k img/s against 33.6k untuned, although the same choices make a lone
     // context 5.7 % faster (profiles/r02_tactics_*.txt).  Such engines choose among the work-efficient configurations only.
     const bool throughput = e->net && e->net->max_aux_streams == 0;
+    // what a candidate has to beat its default by, timed alone, to be taken (round 6: see the comment at the top of this file)
+    const int margin_pct = !throughput ? 3 : (read_options().tune_margin >= 0 ? read_options().tune_margin : 30);
+    const float keep = 1.0f - 0.01f * (float)std::min(margin_pct, 90);
     struct Item {
         int op;
         SigKey key;
@@ -249,7 +258,7 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
             float base = 0.f;
             total(&base);
             int best_p = -1;
-            float best_t = 0.98f * base;
+            float best_t = std::min(0.98f, keep) * base;
             for (int pi = 0; pi < (int)(sizeof(palettes) / sizeof(palettes[0])) && st == TRTX_OK; ++pi) {
                 const Palette& P = palettes[pi];
                 int hits = 0;
@@ -300,7 +309,7 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
             for (size_t x = 0; x < items.size(); ++x) {
                 const Item& it = items[x];
                 for (int i = 1; i < it.n; ++i)
-                    if (it.best_ms[i] < it.best_ms[win[x]] && it.best_ms[i] < 0.97f * it.best_ms[0]) win[x] = i;
+                    if (it.best_ms[i] < it.best_ms[win[x]] && it.best_ms[i] < keep * it.best_ms[0]) win[x] = i;
                 conv_apply_tactic(&plan.ops[it.op].conv, it.cand[win[x]]);
             }
             auto measure = [&](int runs, std::vector<float>* out) {
