@@ -12,7 +12,7 @@ struct Options {
                                  //            deserialize a plan that carries no tactics
     bool tune_verbose = false;   // TRTX_TUNE_VERBOSE: per-layer tactic report on stderr
     int tune_margin = -1;        // TRTX_TUNE_MARGIN=<percent>: engines built for several contexts in flight (setMaxAuxStreams(0)): a layer leaves its default kernel only
-                                 //            for a candidate at least this much faster when timed alone (unset: 30; engines with auxiliary streams always use 3 - tune.cpp)
+                                 //            for a candidate at least this much faster when timed alone (unset: 3, as every engine; round 6, tune.cpp)
     std::string tactic_cache;    // TRTX_TACTIC_CACHE=<file>: tactic choices outlive the process (ITimingCache analogue)
     bool graph = false;          // TRTX_GRAPH=1: hipGraph replay of the lane schedule (opt-in: it does not pay)
     std::string calib_report;    // TRTX_CALIB_REPORT=<file>: per-tensor INT8 calibration report

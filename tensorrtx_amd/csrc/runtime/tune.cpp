@@ -20,12 +20,13 @@
 //     putting it back on the default does not make it and its neighbours faster together (second look: a kernel switch costs
 //     the NEXT launch 7-10 us of cold instruction fetches); the choice is remembered per layer signature for the life of the
 //     process, so that two engines built from the same plan run the same kernels;
-//   * engines built for SEVERAL CONTEXTS IN FLIGHT (setMaxAuxStreams(0)) ask for 30 % instead of 3 % (round 6; TRTX_TUNE_MARGIN): every candidate is timed
-//     ALONE on an idle chip, and what such an engine is built for is the aggregate of three batches sharing it.  Measured on YOLOv8n b32, alternating on one box
-//     (profiles/r06_tune_margin_ab.txt): 3 % - the kernels 5 % faster alone (serialized conv time 0.253 vs 0.239 of the HBM roof) and the three-context rate 1.7 %
-//     LOWER (38.0-38.2k vs 38.7k img/s); 20 % 38.4k, 45 % / 90 % / no timing at all 37.8-38.5k.  A candidate a few per cent faster alone has bought that with
-//     co-residency (a wider tile, a deeper pipeline: more LDS per workgroup) or with work (64-row tiles re-read their weights); only the large wins - the
-//     resident-operand 3x3 kernel's 25-30 % - are less work for the chip as well.
+//   * TRTX_TUNE_MARGIN=<percent> (round 6) replaces the 3 % for engines built for SEVERAL CONTEXTS IN FLIGHT (setMaxAuxStreams(0)).  Every candidate is timed
+//     ALONE on an idle chip, and such an engine is built for the aggregate of three batches sharing it: on YOLOv8n fp16 b32, alternating on one box
+//     (profiles/r06_tune_margin_ab.txt), 30 % gave kernels 5 % SLOWER alone (serialized conv time 0.239 vs 0.253 of the HBM roof) and a three-context rate 1.7 %
+//     HIGHER (38.7k vs 38.0-38.2k img/s; no timing at all: 37.8-38.5k) - a candidate a few per cent faster alone has bought that with co-residency (a wider tile,
+//     a deeper pipeline: more LDS per workgroup) or with work (64-row tiles re-read their weights).  NOT the default: the same 30 % cost the MFMA-bound configurations
+//     what their timing had found - Faster R-CNN 503 -> 389 img/s, RetinaFace 1517 -> 1373, the fp32 engine 11.2k -> 10.6k, ResNet-50 -3 %, int8 -2.5 % - where a
+//     kernel that is faster alone is faster in company too.  A switch for small-layer fp16 networks, off (3 %) unless set.
 //
 // Plugins, the fused detect head and RoIAlign are skipped in those runs (they would chew on uninitialised proposals); the
 // convolutions do not care what the numbers are.  TRTX_TUNE=0 keeps every layer on its static default.
@@ -141,7 +142,7 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
     // context 5.7 % faster (profiles/r02_tactics_*.txt).  Such engines choose among the work-efficient configurations only.
     const bool throughput = e->net && e->net->max_aux_streams == 0;
     // what a candidate has to beat its default by, timed alone, to be taken (round 6: see the comment at the top of this file)
-    const int margin_pct = !throughput ? 3 : (read_options().tune_margin >= 0 ? read_options().tune_margin : 30);
+    const int margin_pct = !throughput ? 3 : (read_options().tune_margin >= 0 ? read_options().tune_margin : 3);
     const float keep = 1.0f - 0.01f * (float)std::min(margin_pct, 90);
     struct Item {
         int op;
