@@ -10,6 +10,7 @@ struct Options {
     // --- documented knobs
     int tune = -1;               // TRTX_TUNE: unset = time the tactics when a plan is BUILT on a machine with a GPU; 0 = never (static defaults); 1 = also time at
                                  //            deserialize a plan that carries no tactics
+                                 //            2 = as unset, without the third look of engines built for contexts in flight (tune.cpp)
     bool tune_verbose = false;   // TRTX_TUNE_VERBOSE: per-layer tactic report on stderr
     int tune_margin = -1;        // TRTX_TUNE_MARGIN=<percent>: engines built for several contexts in flight (setMaxAuxStreams(0)): a layer leaves its default kernel only
                                  //            for a candidate at least this much faster when timed alone (unset: 3, as every engine; round 6, tune.cpp)
