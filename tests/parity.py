@@ -77,7 +77,7 @@ VALUES = {
     ('yolov8n_fp16_640', None): {'cls_logit_max_abs_err': 0.108, 'box_ltrb_max_abs_err': 0.0281, 'matched_fraction': 0.99807, 'min_iou': 0.99553, 'max_conf_err': 0.0142},
     ('yolov8n_fp16_640_fused', None): {'matched_fraction': 0.99807, 'min_iou': 0.99572, 'max_conf_err': 0.0142},
     ('yolov8n_fp16_640_b32', None): {'matched_fraction': 0.99886, 'min_iou': 0.99834, 'max_conf_err': 0.00736},
-    ('retinaface_r50_fp16', '256x320'): {'matched_fraction': 0.99976, 'min_iou': 0.9864, 'max_box_err': 1.13, 'max_conf_err': 0.00808},
+    ('retinaface_r50_fp16', '256x320'): {'matched_fraction': 0.99976, 'min_iou': 0.9864, 'max_box_err': 1.15, 'max_conf_err': 0.00808},
     ('retinaface_r50_fp16', '1280x1280'): {'matched_fraction': 0.999976, 'min_iou': 0.9885, 'max_box_err': 1.52, 'max_conf_err': 0.0107},
     ('rcnn_fp32', None): {'feat_err': 1.07e-05, 'score_err': 4.59e-06, 'proposals_matched': 0.98, 'detections_matched': 0.95},
     ('rcnn_fp16', '320x416'): {'feat_rel_err': 0.00248, 'proposals_matched': 0.988, 'detections_matched': 0.952, 'top_score_err': 0.000796},
