@@ -430,7 +430,7 @@ int32_t tune_engine(trtx_engine* e, bool time_now) {
                             const int want = (*keep_set)[x];
                             if (want == win[x]) continue;
                             for (int i = 1; i < it.n; ++i) it.best_ms[i] = 1e30f;
-                            if (want) it.best_ms[want] = 0.5f * it.best_ms[0];   // (the launcher's own choice under a palette: it has to win the final comparison)
+                            if (want) it.best_ms[want] = 0.989f * it.best_ms[0];   // (the launcher's own choice under a palette: it has to win the final comparison - reported at the palette's time)
                         }
                 }
                 for (int k = 0; k < 2; ++k) {
